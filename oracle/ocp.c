@@ -1,0 +1,537 @@
+/*
+ * ocp.c — NLP / QP / SQP layer of the CPU oracle (TEST INFRASTRUCTURE, see oracle.h).
+ *
+ * Restates, for one (start,target) pair, what MotionPlanner::solve_trajectory -> mpc.solve()
+ * computes (mpc_solver/motionPlanner.cpp:177-208):
+ *   - minTime_ocp                       mpc_solver/robot_ocp.hpp:31-213
+ *   - MySolver (SQP customisation)      mpc_solver/polympc_redef.hpp:41-147
+ *   - boxADMM QP                        mpc_solver/motionPlanner.hpp:10-11 (type alias only)
+ *   - solver settings / bounds          mpc_solver/motionPlanner.cpp:15-20, 27-100
+ * polympc itself (collocation assembly, SQPBase::solve, boxADMM::solve) is an EMPTY submodule in
+ * /root/reference (.gitmodules:1-4), so that layer follows the published algorithms
+ * (Chebyshev-Gauss-Lobatto collocation on splines; OSQP-form ADMM, Stellato et al. 2020;
+ * l1-merit line-search SQP, Nocedal&Wright ch.18) with every free choice explicit in orc_config.
+ * PARITY UNPINNED at digit level for this layer (see oracle.h).
+ *
+ * NLP:
+ *   z = [x_0..x_{N-1} | u_0..u_{N-1} | T],  N = 3*NUM_SEG+1, ascending time
+ *   min T
+ *   s.t. sum_j D[i][j] x_{3s+j} - ts*T*[qd_k;u_k] = 0     k=3s+i, i in {0,1,2}    (14 rows / node)
+ *        lbg <= [rnea(q_k,qd_k,u_k); z_tool(q_k)] <= ubg   all nodes              ( 8 rows / node)
+ *        x_0 = x_start, x_{N-1} in x_target +- eps, boxes on x,u,T
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#define MAXN (3 * ORC_MAXSEG + 1)
+#define MAXROWNZ 24
+
+int orc_num_nodes(int num_seg) { return 3 * num_seg + 1; }
+
+void orc_time_nodes(int num_seg, double *tau) {
+    /* cubic Chebyshev-Gauss-Lobatto points xi = -cos(pi*j/3) = {-1,-1/2,1/2,1} on each segment */
+    static const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    for (int s = 0; s < num_seg; s++)
+        for (int j = 0; j < 4; j++) tau[3 * s + j] = (s + 0.5 * (xi[j] + 1.0)) / num_seg;
+}
+
+void orc_diff_matrix(double *D) {
+    /* Lagrange differentiation matrix on xi = {-1,-1/2,1/2,1}: D[i][j] = l_j'(xi_i) */
+    static const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double den = 1.0;
+            for (int k = 0; k < 4; k++) if (k != j) den *= (xi[j] - xi[k]);
+            double num = 0.0;
+            for (int l = 0; l < 4; l++) if (l != j) {
+                double pr = 1.0;
+                for (int k = 0; k < 4; k++) if (k != j && k != l) pr *= (xi[i] - xi[k]);
+                num += pr;
+            }
+            D[4 * i + j] = num / den;
+        }
+}
+
+void orc_set_margins(orc_config *c, double mp, double mv, double ma, double mt) {
+    /* motionPlanner.cpp:56-100 */
+    double qmin[7], qmax[7], vmax[7], amax[7], tmax[7];
+    orc_default_limits(qmin, qmax, vmax, amax, 0, tmax);
+    for (int j = 0; j < 7; j++) {
+        double s = (1.0 - mp) * (qmax[j] - qmin[j]) / 2.0;
+        c->lbx[j] = qmin[j] + s; c->ubx[j] = qmax[j] - s;
+        c->lbx[7 + j] = -mv * vmax[j]; c->ubx[7 + j] = mv * vmax[j];
+        c->lbu[j] = -ma * amax[j]; c->ubu[j] = ma * amax[j];
+        c->lbg[j] = -mt * tmax[j]; c->ubg[j] = mt * tmax[j];
+    }
+    c->lbg[7] = 0.05; c->ubg[7] = INFINITY;   /* pandaWrapper.hpp:40, motionPlanner.cpp:95-96 */
+    c->lbT = 0.0; c->ubT = 10.0;              /* motionPlanner.cpp:77-78 */
+}
+
+void orc_default_config(orc_config *c, int num_seg, int sqp_iters) {
+    memset(c, 0, sizeof *c);
+    c->num_seg = num_seg; c->sqp_iters = sqp_iters;
+    c->qp_iters = 700; c->ls_iters = 10;       /* motionPlanner.cpp:16-17 */
+    c->check_every = 25; c->quirk_dtau_dT = 1;
+    c->eps_abs = 1e-3; c->eps_rel = 1e-3;      /* motionPlanner.cpp:19-20 */
+    c->rho = 0.1; c->sigma = 1e-6; c->alpha = 1.6; c->rho_eq_scale = 1e3;
+    c->ls_eta = 0.25; c->ls_tau = 0.5;
+    c->hess_reg = 1e-3;                        /* polympc_redef.hpp:68 */
+    c->eps_target = 1e-2;                      /* motionPlanner.hpp:44 */
+    orc_set_margins(c, 1.0, 1.0, 1.0, 1.0);    /* motionPlanner.cpp:24 */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int N, n, meq, min, m;      /* nodes, variables, rows */
+    double ts;
+    double D[16];
+    /* sparse general rows */
+    int    *nnz; int *col; double *val;   /* m x MAXROWNZ */
+    double *ceq, *g;            /* constraint values */
+    double *Gk;                 /* N x 8 x 22 path Jacobians */
+    double *hd, *ha;            /* Hessian: diagonal (n) and arrow (n, entry T unused) */
+    double *l, *u, *rho;        /* QP bounds and ADMM rho, size m+n */
+    double *zlb, *zub;          /* variable boxes, size n */
+    /* linear solver */
+    int *perm, *iperm, *first;  /* internal->external, external->internal, skyline start */
+    double *K;                  /* n x n (permuted), overwritten by L */
+} work;
+
+static inline int IX(int k, int r) { return 14 * k + r; }
+static inline int IU(const work *w, int k, int r) { return 14 * w->N + 7 * k + r; }
+static inline int IT(const work *w) { return 21 * w->N; }
+
+static work *work_new(const orc_config *c) {
+    work *w = (work *)calloc(1, sizeof(work));
+    int N = w->N = orc_num_nodes(c->num_seg);
+    w->n = 21 * N + 1; w->meq = 14 * (N - 1); w->min = 8 * N; w->m = w->meq + w->min;
+    w->ts = 1.0 / (2.0 * c->num_seg);       /* (t_f - t_0)/(2 NUM_SEG) with set_time_limits(0,1), motionPlanner.cpp:18 */
+    orc_diff_matrix(w->D);
+    int n = w->n, m = w->m;
+    w->nnz = (int *)calloc(m, sizeof(int)); w->col = (int *)calloc((size_t)m * MAXROWNZ, sizeof(int));
+    w->val = (double *)calloc((size_t)m * MAXROWNZ, sizeof(double));
+    w->ceq = (double *)calloc(w->meq, sizeof(double)); w->g = (double *)calloc(w->min, sizeof(double));
+    w->Gk = (double *)calloc((size_t)N * 8 * 22, sizeof(double));
+    w->hd = (double *)calloc(n, sizeof(double)); w->ha = (double *)calloc(n, sizeof(double));
+    w->l = (double *)calloc(m + n, sizeof(double)); w->u = (double *)calloc(m + n, sizeof(double));
+    w->rho = (double *)calloc(m + n, sizeof(double));
+    w->zlb = (double *)calloc(n, sizeof(double)); w->zub = (double *)calloc(n, sizeof(double));
+    w->perm = (int *)calloc(n, sizeof(int)); w->iperm = (int *)calloc(n, sizeof(int));
+    w->first = (int *)calloc(n, sizeof(int));
+    w->K = (double *)calloc((size_t)n * n, sizeof(double));
+    /* chain ordering: [x_0 | u_3s, x_3s+1, u_3s+1, x_3s+2, u_3s+2, x_3s+3 | ... | u_{N-1} | T] */
+    int p = 0;
+    for (int r = 0; r < 14; r++) w->perm[p++] = IX(0, r);
+    for (int s = 0; s < c->num_seg; s++) {
+        for (int r = 0; r < 7; r++) w->perm[p++] = IU(w, 3 * s, r);
+        for (int i = 1; i <= 2; i++) {
+            for (int r = 0; r < 14; r++) w->perm[p++] = IX(3 * s + i, r);
+            for (int r = 0; r < 7; r++) w->perm[p++] = IU(w, 3 * s + i, r);
+        }
+        for (int r = 0; r < 14; r++) w->perm[p++] = IX(3 * s + 3, r);
+    }
+    for (int r = 0; r < 7; r++) w->perm[p++] = IU(w, N - 1, r);
+    w->perm[p++] = IT(w);
+    for (int i = 0; i < n; i++) w->iperm[w->perm[i]] = i;
+    return w;
+}
+static void work_free(work *w) {
+    free(w->nnz); free(w->col); free(w->val); free(w->ceq); free(w->g); free(w->Gk); free(w->hd); free(w->ha);
+    free(w->l); free(w->u); free(w->rho); free(w->zlb); free(w->zub); free(w->perm); free(w->iperm);
+    free(w->first); free(w->K); free(w);
+}
+
+static void set_boxes(work *w, const orc_config *c, const double *x0, const double *xf) {
+    int N = w->N;
+    for (int k = 0; k < N; k++) {
+        for (int r = 0; r < 14; r++) {
+            double lo = c->lbx[r], hi = c->ubx[r];
+            if (k == 0) { lo = hi = x0[r]; }                                           /* motionPlanner.cpp:47 */
+            if (k == N - 1) { lo = xf[r] - c->eps_target; hi = xf[r] + c->eps_target; } /* motionPlanner.cpp:33 */
+            w->zlb[IX(k, r)] = lo; w->zub[IX(k, r)] = hi;
+        }
+        for (int r = 0; r < 7; r++) { w->zlb[IU(w, k, r)] = c->lbu[r]; w->zub[IU(w, k, r)] = c->ubu[r]; }
+    }
+    w->zlb[IT(w)] = c->lbT; w->zub[IT(w)] = c->ubT;
+}
+
+/* values of all constraints at z (no derivatives): used by the line search (robot_ocp.hpp:80-96) */
+static void eval_values(const orc_model *mdl, const work *w, const double *z, double *ceq, double *g) {
+    int N = w->N; double T = z[IT(w)];
+    for (int k = 0; k < N - 1; k++) {
+        int s = k / 3, i = k % 3;
+        for (int r = 0; r < 14; r++) {
+            double acc = 0.0;
+            for (int j = 0; j < 4; j++) acc += w->D[4 * i + j] * z[IX(3 * s + j, r)];
+            double f = (r < 7) ? z[IX(k, 7 + r)] : z[IU(w, k, r - 7)];   /* robot_ocp.hpp:55-73 */
+            ceq[14 * k + r] = acc - w->ts * T * f;
+        }
+    }
+    for (int k = 0; k < N; k++) orc_eval_constraints(mdl, 0, z + IX(k, 0), z + IU(w, k, 0), g + 8 * k, 0);
+}
+
+static double viol(double v, double lo, double hi) { return v < lo ? lo - v : (v > hi ? v - hi : 0.0); }
+
+static double l1_violation(const work *w, const orc_config *c, const double *z, const double *ceq, const double *g) {
+    double s = 0.0;
+    for (int i = 0; i < w->meq; i++) s += fabs(ceq[i]);
+    for (int k = 0; k < w->N; k++) for (int r = 0; r < 8; r++) s += viol(g[8 * k + r], c->lbg[r], c->ubg[r]);
+    for (int i = 0; i < w->n; i++) s += viol(z[i], w->zlb[i], w->zub[i]);
+    return s;
+}
+
+/* full linearisation at (z, lam): rows of A, constraint values, Hessian (polympc_redef.hpp:133-147 forces this
+   every iteration), QP bounds */
+static void linearise(const orc_model *mdl, const orc_config *c, work *w, const double *z, const double *lam) {
+    int N = w->N, n = w->n; double T = z[IT(w)], ts = w->ts;
+    memset(w->hd, 0, sizeof(double) * n); memset(w->ha, 0, sizeof(double) * n);
+    for (int k = 0; k < N - 1; k++) {
+        int s = k / 3, i = k % 3;
+        for (int r = 0; r < 14; r++) {
+            int row = 14 * k + r, nz = 0;
+            int *col = w->col + (size_t)row * MAXROWNZ; double *val = w->val + (size_t)row * MAXROWNZ;
+            double acc = 0.0;
+            for (int j = 0; j < 4; j++) {
+                double d = w->D[4 * i + j];
+                acc += d * z[IX(3 * s + j, r)];
+                col[nz] = IX(3 * s + j, r); val[nz++] = d;
+            }
+            int fcol = (r < 7) ? IX(k, 7 + r) : IU(w, k, r - 7);
+            double f = z[fcol];
+            col[nz] = fcol; val[nz++] = -ts * T;      /* never coincides with a D column */
+            col[nz] = IT(w); val[nz++] = -ts * f;
+            w->nnz[row] = nz;
+            w->ceq[row] = acc - ts * T * f;
+            /* exact Lagrangian Hessian: only d2/dT d(f-variable) = -ts * lam_row */
+            w->ha[fcol] += -ts * lam[row];
+        }
+    }
+    for (int k = 0; k < N; k++) {
+        double *G = w->Gk + (size_t)k * 176;
+        orc_eval_constraints(mdl, c->quirk_dtau_dT, z + IX(k, 0), z + IU(w, k, 0), w->g + 8 * k, G);
+        for (int r = 0; r < 8; r++) {
+            int row = w->meq + 8 * k + r, nz = 0;
+            int *col = w->col + (size_t)row * MAXROWNZ; double *val = w->val + (size_t)row * MAXROWNZ;
+            if (r < 7) {
+                for (int j = 0; j < 14; j++) { col[nz] = IX(k, j); val[nz++] = G[22 * r + j]; }
+                for (int j = 0; j < 7; j++) { col[nz] = IU(w, k, j); val[nz++] = G[22 * r + 14 + j]; }
+                col[nz] = IT(w); val[nz++] = G[22 * r + 21];
+            } else {
+                for (int j = 0; j < 7; j++) { col[nz] = IX(k, j); val[nz++] = G[22 * r + j]; }
+            }
+            w->nnz[row] = nz;
+        }
+    }
+    /* Gershgorin regularisation, polympc_redef.hpp:57-70 (sparse variant, +hess_reg) */
+    double rT = 0.0;
+    for (int i = 0; i < n - 1; i++) {
+        double ri = fabs(w->ha[i]);
+        rT += ri;
+        w->hd[i] = ri + c->hess_reg;      /* a_ii = 0 -> a_ii - r_i <= 0 always */
+    }
+    w->hd[n - 1] = rT + c->hess_reg;
+    /* QP bounds in the step p */
+    for (int i = 0; i < w->meq; i++) { w->l[i] = w->u[i] = -w->ceq[i]; }
+    for (int k = 0; k < N; k++) for (int r = 0; r < 8; r++) {
+        w->l[w->meq + 8 * k + r] = c->lbg[r] - w->g[8 * k + r];
+        w->u[w->meq + 8 * k + r] = c->ubg[r] - w->g[8 * k + r];
+    }
+    for (int i = 0; i < n; i++) { w->l[w->m + i] = w->zlb[i] - z[i]; w->u[w->m + i] = w->zub[i] - z[i]; }
+    /* per-row rho: OSQP rule, equality rows (l==u) scaled by rho_eq_scale */
+    for (int i = 0; i < w->m + n; i++)
+        w->rho[i] = (w->u[i] - w->l[i] < 1e-4) ? c->rho * c->rho_eq_scale : c->rho;
+}
+
+/* K = H + sigma I + diag(rho_box) + A^T diag(rho) A in the chain ordering, then skyline Cholesky */
+static int factor(const orc_config *c, work *w) {
+    int n = w->n, m = w->m;
+    double *K = w->K;
+    memset(K, 0, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; i++) {
+        int pi = w->iperm[i];
+        K[(size_t)pi * n + pi] += w->hd[i] + c->sigma + w->rho[m + i];
+        if (i != n - 1 && w->ha[i] != 0.0) {
+            int pT = w->iperm[n - 1];
+            int a = pi > pT ? pi : pT, b = pi > pT ? pT : pi;
+            K[(size_t)a * n + b] += w->ha[i];
+        }
+    }
+    for (int r = 0; r < m; r++) {
+        const int *col = w->col + (size_t)r * MAXROWNZ; const double *val = w->val + (size_t)r * MAXROWNZ;
+        int nz = w->nnz[r]; double rho = w->rho[r];
+        for (int a = 0; a < nz; a++) for (int b = 0; b < nz; b++) {
+            int pa = w->iperm[col[a]], pb = w->iperm[col[b]];
+            if (pa >= pb) K[(size_t)pa * n + pb] += rho * val[a] * val[b];
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        int f = i;
+        for (int j = 0; j < i; j++) if (K[(size_t)i * n + j] != 0.0) { f = j; break; }
+        w->first[i] = f;
+    }
+    for (int i = 0; i < n; i++) {
+        int fi = w->first[i];
+        for (int j = fi; j <= i; j++) {
+            int fj = w->first[j], k0 = fi > fj ? fi : fj;
+            double s = K[(size_t)i * n + j];
+            for (int k = k0; k < j; k++) s -= K[(size_t)i * n + k] * K[(size_t)j * n + k];
+            if (j < i) K[(size_t)i * n + j] = s / K[(size_t)j * n + j];
+            else { if (!(s > 0.0)) return 1; K[(size_t)i * n + i] = sqrt(s); }
+        }
+    }
+    return 0;
+}
+
+static void kkt_solve(const work *w, const double *b /*external order*/, double *x /*external order*/, double *tmp) {
+    int n = w->n; const double *L = w->K;
+    for (int i = 0; i < n; i++) {
+        double s = b[w->perm[i]];
+        for (int k = w->first[i]; k < i; k++) s -= L[(size_t)i * n + k] * tmp[k];
+        tmp[i] = s / L[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double xi = tmp[i] / L[(size_t)i * n + i];
+        tmp[i] = xi;
+        for (int k = w->first[i]; k < i; k++) tmp[k] -= L[(size_t)i * n + k] * xi;
+    }
+    for (int i = 0; i < n; i++) x[w->perm[i]] = tmp[i];
+}
+
+static void A_mul(const work *w, const double *x, double *out /*m*/) {
+    for (int r = 0; r < w->m; r++) {
+        const int *col = w->col + (size_t)r * MAXROWNZ; const double *val = w->val + (size_t)r * MAXROWNZ;
+        double s = 0.0;
+        for (int a = 0; a < w->nnz[r]; a++) s += val[a] * x[col[a]];
+        out[r] = s;
+    }
+}
+static void AT_mul_add(const work *w, const double *y /*m*/, double *out /*n, accumulated*/) {
+    for (int r = 0; r < w->m; r++) {
+        const int *col = w->col + (size_t)r * MAXROWNZ; const double *val = w->val + (size_t)r * MAXROWNZ;
+        double yr = y[r];
+        for (int a = 0; a < w->nnz[r]; a++) out[col[a]] += val[a] * yr;
+    }
+}
+static void H_mul(const work *w, const double *x, double *out) {
+    int n = w->n; double xT = x[n - 1], s = w->hd[n - 1] * xT;
+    for (int i = 0; i < n - 1; i++) { out[i] = w->hd[i] * x[i] + w->ha[i] * xT; s += w->ha[i] * x[i]; }
+    out[n - 1] = s;
+}
+static double inf_norm(const double *v, int n) { double s = 0; for (int i = 0; i < n; i++) { double a = fabs(v[i]); if (a > s) s = a; } return s; }
+
+/* box-ADMM in OSQP form on the stacked constraint [A; I], reduced KKT. cold start. */
+static int admm(const orc_config *c, work *w, double *x, double *y, int *status) {
+    int n = w->n, m = w->m, mn = m + n;
+    double *zz = (double *)calloc(mn, sizeof(double)), *xt = (double *)calloc(n, sizeof(double));
+    double *rhs = (double *)calloc(n, sizeof(double)), *zt = (double *)calloc(mn, sizeof(double));
+    double *tmp = (double *)calloc(n, sizeof(double)), *wv = (double *)calloc(mn, sizeof(double));
+    double *t1 = (double *)calloc(mn, sizeof(double)), *t2 = (double *)calloc(n, sizeof(double));
+    memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * mn);
+    const double sigma = c->sigma, alpha = c->alpha;
+    int it = 0;
+    *status = 0;
+    if (factor(c, w)) { *status = 2; goto done; }
+    for (it = 1; it <= c->qp_iters; it++) {
+        for (int i = 0; i < mn; i++) wv[i] = w->rho[i] * zz[i] - y[i];
+        for (int i = 0; i < n; i++) rhs[i] = sigma * x[i] + wv[m + i];
+        rhs[n - 1] -= 1.0;                           /* q = cost gradient = e_T (robot_ocp.hpp:201-213) */
+        AT_mul_add(w, wv, rhs);
+        kkt_solve(w, rhs, xt, tmp);
+        A_mul(w, xt, zt);
+        for (int i = 0; i < n; i++) zt[m + i] = xt[i];
+        for (int i = 0; i < n; i++) x[i] = alpha * xt[i] + (1.0 - alpha) * x[i];
+        for (int i = 0; i < mn; i++) {
+            double zr = alpha * zt[i] + (1.0 - alpha) * zz[i];
+            double zn = zr + y[i] / w->rho[i];
+            zn = zn < w->l[i] ? w->l[i] : (zn > w->u[i] ? w->u[i] : zn);
+            y[i] += w->rho[i] * (zr - zn);
+            zz[i] = zn;
+        }
+        if (it % c->check_every == 0) {
+            /* r_prim = ||[A;I]x - z||, r_dual = ||Hx + q + [A;I]^T y|| */
+            A_mul(w, x, t1);
+            for (int i = 0; i < n; i++) t1[m + i] = x[i];
+            double nAx = inf_norm(t1, mn), nz = inf_norm(zz, mn), rp = 0.0;
+            for (int i = 0; i < mn; i++) { double d = fabs(t1[i] - zz[i]); if (d > rp) rp = d; }
+            H_mul(w, x, t2);
+            double nHx = inf_norm(t2, n);
+            for (int i = 0; i < n; i++) tmp[i] = y[m + i];
+            AT_mul_add(w, y, tmp);
+            double nAty = inf_norm(tmp, n), rd = 0.0;
+            for (int i = 0; i < n; i++) { double d = fabs(t2[i] + tmp[i] + (i == n - 1 ? 1.0 : 0.0)); if (d > rd) rd = d; }
+            double ep = c->eps_abs + c->eps_rel * (nAx > nz ? nAx : nz);
+            double mx = nHx > nAty ? nHx : nAty; if (mx < 1.0) mx = 1.0;   /* ||q||_inf = 1 */
+            double ed = c->eps_abs + c->eps_rel * mx;
+            if (rp <= ep && rd <= ed) break;
+        }
+    }
+    if (it > c->qp_iters) it = c->qp_iters;
+done:
+    free(zz); free(xt); free(rhs); free(zt); free(tmp); free(wv); free(t1); free(t2);
+    return it;
+}
+
+static void pack(const work *w, const double *xs, const double *us, double T, double *z) {
+    memcpy(z, xs, sizeof(double) * 14 * w->N); memcpy(z + 14 * w->N, us, sizeof(double) * 7 * w->N); z[21 * w->N] = T;
+}
+
+void orc_solve(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,
+               const double *xg, const double *ug, double Tg, double *xs, double *us, double *Tout, orc_info *info) {
+    work *w = work_new(c);
+    int n = w->n, m = w->m, mn = m + n;
+    double *z = (double *)calloc(n, sizeof(double)), *lam = (double *)calloc(mn, sizeof(double));
+    double *p = (double *)calloc(n, sizeof(double)), *y = (double *)calloc(mn, sizeof(double));
+    double *zs = (double *)calloc(n, sizeof(double)), *ce = (double *)calloc(w->meq, sizeof(double));
+    double *gg = (double *)calloc(w->min, sizeof(double));
+    orc_info inf; memset(&inf, 0, sizeof inf);
+    pack(w, xg, ug, Tg, z);
+    set_boxes(w, c, x0, xf);
+    linearise(mdl, c, w, z, lam);
+    for (int it = 0; it < c->sqp_iters; it++) {
+        int st;
+        inf.qp_iters_total += admm(c, w, p, y, &st);
+        if (st) inf.status |= st;
+        /* l1 merit line search, polympc_redef.hpp:73-121 */
+        double mu = inf_norm(lam, mn);                                   /* :86 */
+        double constr = l1_violation(w, c, z, w->ceq, w->g);             /* :79 */
+        double phi = z[n - 1] + mu * constr;                             /* :93 */
+        double Dphi = p[n - 1] - mu * constr;                            /* :94  cost gradient = e_T */
+        double alpha = 1.0;
+        for (int i = 1; i < c->ls_iters; i++) {                          /* :97 */
+            for (int k = 0; k < n; k++) zs[k] = z[k] + alpha * p[k];
+            eval_values(mdl, w, zs, ce, gg);
+            double phis = zs[n - 1] + mu * l1_violation(w, c, zs, ce, gg);
+            if (phis <= phi + alpha * c->ls_eta * Dphi) break;            /* :108 */
+            alpha *= c->ls_tau;
+        }
+        for (int k = 0; k < n; k++) z[k] += alpha * p[k];
+        for (int k = 0; k < mn; k++) lam[k] += alpha * (y[k] - lam[k]);
+        inf.last_alpha = alpha; inf.sqp_iters = it + 1;
+        linearise(mdl, c, w, z, lam);
+    }
+    /* report */
+    inf.T = z[n - 1];
+    inf.viol_l1 = l1_violation(w, c, z, w->ceq, w->g);
+    inf.defect_inf = inf_norm(w->ceq, w->meq);
+    for (int k = 0; k < w->N; k++) for (int r = 0; r < 8; r++) {
+        double v = viol(w->g[8 * k + r], c->lbg[r], c->ubg[r]); if (v > inf.path_viol_inf) inf.path_viol_inf = v;
+    }
+    for (int r = 0; r < 14; r++) { double d = fabs(z[IX(w->N - 1, r)] - xf[r]); if (d > inf.term_err_inf) inf.term_err_inf = d; }
+    for (int k = 0; k < n; k++) if (!isfinite(z[k])) inf.status |= 1;
+    memcpy(xs, z, sizeof(double) * 14 * w->N); memcpy(us, z + 14 * w->N, sizeof(double) * 7 * w->N); *Tout = z[n - 1];
+    if (info) *info = inf;
+    free(z); free(lam); free(p); free(y); free(zs); free(ce); free(gg);
+    work_free(w);
+}
+
+int orc_debug_qp(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,
+                 const double *xs, const double *us, double T, const double *lam, double *p, double *y) {
+    work *w = work_new(c);
+    double *z = (double *)calloc(w->n, sizeof(double));
+    double *l0 = (double *)calloc(w->m + w->n, sizeof(double));
+    pack(w, xs, us, T, z);
+    set_boxes(w, c, x0, xf);
+    linearise(mdl, c, w, z, lam ? lam : l0);
+    int st, it = admm(c, w, p, y, &st);
+    free(z); free(l0); work_free(w);
+    return st ? -it : it;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { const orc_model *m; const orc_config *c; int B, t, nt; const double *x0, *xf, *xg, *ug, *Tg;
+                 double *xs, *us, *T; orc_info *info; } job;
+static void *job_run(void *a) {
+    job *j = (job *)a; int N = orc_num_nodes(j->c->num_seg);
+    for (int b = j->t; b < j->B; b += j->nt)
+        orc_solve(j->m, j->c, j->x0 + 14 * b, j->xf + 14 * b, j->xg + (size_t)14 * N * b, j->ug + (size_t)7 * N * b, j->Tg[b],
+                  j->xs + (size_t)14 * N * b, j->us + (size_t)7 * N * b, j->T + b, j->info ? j->info + b : 0);
+    return 0;
+}
+void orc_solve_batch(const orc_model *m, const orc_config *c, int B, const double *x0, const double *xf,
+                     const double *xg, const double *ug, const double *Tg, double *xs, double *us, double *T,
+                     orc_info *info, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256]; job jb[256];
+    for (int t = 0; t < threads; t++) {
+        job j = {m, c, B, t, threads, x0, xf, xg, ug, Tg, xs, us, T, info};
+        jb[t] = j;
+        if (threads == 1) job_run(&jb[0]); else pthread_create(&th[t], 0, job_run, &jb[t]);
+    }
+    if (threads > 1) for (int t = 0; t < threads; t++) pthread_join(th[t], 0);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Stand-in for the Ruckig warm start (motionPlanner.cpp:146-175): per-joint quintic with zero boundary
+   accelerations (Ruckig is also called with zero current/target acceleration, motionPlanner.cpp:27-54),
+   common duration = smallest T on a geometric grid for which |qd|<=vmax and |qdd|<=amax at 65 samples. */
+static void quintic_coef(double q0, double v0, double q1, double v1, double T, double *c) {
+    double h = q1 - q0, T2 = T * T, T3 = T2 * T;
+    c[0] = q0; c[1] = v0; c[2] = 0.0;
+    c[3] = (20.0 * h - (8.0 * v1 + 12.0 * v0) * T) / (2.0 * T3);
+    c[4] = (-30.0 * h + (14.0 * v1 + 16.0 * v0) * T) / (2.0 * T3 * T);
+    c[5] = (12.0 * h - 6.0 * (v1 + v0) * T) / (2.0 * T3 * T2);
+}
+static void quintic_eval(const double *c, double t, double *q, double *v, double *a) {
+    *q = c[0] + t * (c[1] + t * (c[2] + t * (c[3] + t * (c[4] + t * c[5]))));
+    *v = c[1] + t * (2 * c[2] + t * (3 * c[3] + t * (4 * c[4] + t * 5 * c[5])));
+    *a = 2 * c[2] + t * (6 * c[3] + t * (12 * c[4] + t * 20 * c[5]));
+}
+void orc_warm_start(const orc_config *c, const double *amax_used, const double *x0, const double *xf,
+                    double *xg, double *ug, double *Tg) {
+    int N = orc_num_nodes(c->num_seg);
+    double tau[MAXN]; orc_time_nodes(c->num_seg, tau);
+    double T = 0.05, coef[7][6];
+    for (int it = 0; it < 200; it++) {
+        int ok = 1;
+        for (int j = 0; j < 7 && ok; j++) {
+            quintic_coef(x0[j], x0[7 + j], xf[j], xf[7 + j], T, coef[j]);
+            for (int s = 0; s <= 64; s++) {
+                double q, v, a; quintic_eval(coef[j], T * s / 64.0, &q, &v, &a);
+                if (fabs(v) > c->ubx[7 + j] || fabs(a) > amax_used[j]) { ok = 0; break; }
+            }
+        }
+        if (ok || T * 1.05 > c->ubT) break;
+        T *= 1.05;
+    }
+    for (int j = 0; j < 7; j++) quintic_coef(x0[j], x0[7 + j], xf[j], xf[7 + j], T, coef[j]);
+    for (int k = 0; k < N; k++) for (int j = 0; j < 7; j++) {
+        double q, v, a; quintic_eval(coef[j], tau[k] * T, &q, &v, &a);
+        xg[14 * k + j] = q; xg[14 * k + 7 + j] = v; ug[7 * k + j] = a;
+    }
+    for (int r = 0; r < 14; r++) { xg[r] = x0[r]; xg[14 * (N - 1) + r] = xf[r]; }
+    *Tg = T;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* MPC<>::solution_x_at / solution_u_at + rnea  (motionPlanner.hpp:99-116): Lagrange interpolation on the
+   segment that contains t */
+void orc_sample(const orc_model *mdl, int num_seg, const double *xs, const double *us, double T, int n_pts, double *out) {
+    static const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    for (int ip = 0; ip <= n_pts; ip++) {
+        double t = (double)ip / n_pts;                 /* motionPlanner.hpp:103 */
+        int s = (int)floor(t * num_seg); if (s >= num_seg) s = num_seg - 1; if (s < 0) s = 0;
+        double x = 2.0 * (t * num_seg - s) - 1.0, L[4];
+        for (int j = 0; j < 4; j++) {
+            double v = 1.0;
+            for (int k = 0; k < 4; k++) if (k != j) v *= (x - xi[k]) / (xi[j] - xi[k]);
+            L[j] = v;
+        }
+        double q[7], v[7], a[7], tau[7];
+        for (int r = 0; r < 7; r++) {
+            q[r] = v[r] = a[r] = 0.0;
+            for (int j = 0; j < 4; j++) {
+                q[r] += L[j] * xs[14 * (3 * s + j) + r];
+                v[r] += L[j] * xs[14 * (3 * s + j) + 7 + r];
+                a[r] += L[j] * us[7 * (3 * s + j) + r];
+            }
+        }
+        orc_rnea(mdl, q, v, a, tau);
+        double *o = out + (size_t)ip * 29;
+        o[0] = t * T;                                   /* motionPlanner.hpp:115 */
+        memcpy(o + 1, q, sizeof q); memcpy(o + 8, v, sizeof v); memcpy(o + 15, a, sizeof a); memcpy(o + 22, tau, sizeof tau);
+    }
+}

@@ -1,0 +1,133 @@
+/*
+ * oracle.h — CPU restatement (TEST INFRASTRUCTURE ONLY) of the hot path of
+ * AlbericDeLajarte/mpc_motion_planner: minimum-time joint-space OCP for the 7-DoF Panda.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or load
+ * this library. The product (mpc_motion_planner_amd/) never does.
+ *
+ * Parity status
+ *   - rigid-body layer (RNEA / FK / Jacobian):  PINNED by the reference's stored Pinocchio
+ *     outputs (tests/golden/kat_rnea.csv, kat_fk_link8.csv, kat_jac.json).
+ *   - RNEA derivatives / mass matrix: pinned indirectly (finite differences of the pinned RNEA).
+ *   - collocation / SQP / box-ADMM layer: "PARITY UNPINNED" at digit level. The arithmetic of
+ *     that layer lives in polympc (https://gitlab.epfl.ch/listov/polympc.git, branch
+ *     collocation_fix_jw, commit not recoverable), which is an empty submodule in the
+ *     reference snapshot. It is restated from the reference's call sites
+ *     (mpc_solver/robot_ocp.hpp, polympc_redef.hpp, motionPlanner.cpp) and the published
+ *     OSQP/SQP algorithms; the one stored solve (tests/golden/gold_traj.json) pins it at
+ *     regime level only (T between the converged optimum and the Ruckig warm start).
+ *
+ * Reference files followed: mpc_solver/robot_ocp.hpp (whole), mpc_solver/polympc_redef.hpp
+ * (whole), mpc_solver/motionPlanner.cpp:15-20,27-100,146-208, mpc_solver/motionPlanner.hpp:99-172,
+ * robot_utils/pandaWrapper.hpp:28-40, robot_utils/panda-model/panda_arm.urdf.
+ */
+#ifndef MPCMP_ORACLE_H
+#define MPCMP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NJ 7          /* joints of the serial chain                              */
+#define ORC_NX 14         /* state  x=[q;qd]         robot_ocp.hpp:38                 */
+#define ORC_NU 7          /* control u=qdd           robot_ocp.hpp:38                 */
+#define ORC_NG 8          /* path constraints [tau(7); z_tool]  robot_ocp.hpp:38,91   */
+#define ORC_NV 21         /* NX+NU per node                                           */
+#define ORC_MAXSEG 8
+
+typedef struct {
+    double R0[ORC_NJ][9];  /* fixed part of joint placement rotation (row-major), parent <- joint */
+    double p[ORC_NJ][3];   /* joint origin in parent joint frame                                  */
+    double mass[ORC_NJ];
+    double com[ORC_NJ][3]; /* centre of mass of the (lumped) body in its joint frame              */
+    double I[ORC_NJ][9];   /* rotational inertia about the COM, joint-frame axes                  */
+    double tool[3];        /* frame panda_tool in joint-7 frame   (panda_arm.urdf:134-153)        */
+    double link8[3];       /* frame panda_link8 in joint-7 frame  (panda_arm.urdf:134-139)        */
+    double gravity[3];     /* (0,0,-9.81)                                                         */
+} orc_model;
+
+/* solver configuration. Everything the reference leaves to polympc defaults is explicit here. */
+typedef struct {
+    int    num_seg;         /* NUM_SEG (robot_ocp.hpp:32); POLY_ORDER is fixed at 3 (robot_ocp.hpp:31) */
+    int    sqp_iters;       /* mpc.settings().max_iter              motionPlanner.cpp:15 */
+    int    qp_iters;        /* mpc.qp_settings().max_iter           motionPlanner.cpp:16 */
+    int    ls_iters;        /* line_search_max_iter                 motionPlanner.cpp:17 */
+    int    check_every;     /* ADMM termination test interval (25)                       */
+    int    quirk_dtau_dT;   /* keep robot_ocp.hpp:124,138 column 21                      */
+    double eps_abs, eps_rel;/* motionPlanner.cpp:19-20                                   */
+    double rho, sigma, alpha, rho_eq_scale; /* ADMM parameters (build's choice) */
+    double ls_eta, ls_tau;  /* Armijo slope fraction / shrink factor                     */
+    double hess_reg;        /* +0.001 of polympc_redef.hpp:68                            */
+    double eps_target;      /* terminal box half width 1e-2, motionPlanner.hpp:44        */
+    double lbx[ORC_NX], ubx[ORC_NX]; /* state box      motionPlanner.cpp:66-70 */
+    double lbu[ORC_NU], ubu[ORC_NU]; /* control box    motionPlanner.cpp:73    */
+    double lbg[ORC_NG], ubg[ORC_NG]; /* path bounds    motionPlanner.cpp:92-98 */
+    double lbT, ubT;                 /* motionPlanner.cpp:76-79                */
+} orc_config;
+
+typedef struct {
+    double T;            /* final time                                             */
+    double viol_l1;      /* l1 constraint violation of the returned iterate        */
+    double defect_inf;   /* inf-norm of collocation defects                        */
+    double path_viol_inf;/* inf-norm violation of torque/height bounds at nodes    */
+    double term_err_inf; /* || x_N - x_target ||_inf                               */
+    double last_alpha;   /* step length taken in the last SQP iteration            */
+    int    qp_iters_total;
+    int    sqp_iters;
+    int    status;       /* 0 ok, 1 NaN encountered                                */
+    int    pad;
+} orc_info;
+
+/* ---- model ---- */
+void orc_default_model(orc_model *m);                 /* compiled-in Panda (panda_arm.urdf) */
+void orc_default_limits(double *qmin, double *qmax, double *vmax, double *amax, double *jmax,
+                        double *taumax);              /* pandaWrapper.hpp:29-34 */
+void orc_default_config(orc_config *c, int num_seg, int sqp_iters);
+void orc_set_margins(orc_config *c, double mp, double mv, double ma, double mt); /* motionPlanner.cpp:56-100 */
+
+/* ---- rigid body ---- */
+void orc_rnea(const orc_model *m, const double *q, const double *v, const double *a, double *tau);
+/* JVP-based analytic derivatives: dq,dv,M are 7x7 row-major (row = torque index) */
+void orc_rnea_derivatives(const orc_model *m, const double *q, const double *v, const double *a,
+                          double *tau, double *dtau_dq, double *dtau_dv, double *M);
+void orc_fk(const orc_model *m, const double *q, double *p_joint7, double *R_joint7 /*9*/,
+            double *p_link8, double *p_tool);
+/* world-aligned 6x7 Jacobian of a point rigidly attached to joint 7 at local offset `off` */
+void orc_frame_jacobian(const orc_model *m, const double *q, const double *off, double *J /*6x7 row-major*/);
+/* g(8) and dg/d[x,u,T] (8x22 row-major) exactly as robot_ocp.hpp:98-163 */
+void orc_eval_constraints(const orc_model *m, int quirk, const double *x, const double *u,
+                          double *g, double *G /*8x22 or NULL*/);
+
+/* ---- discretisation ---- */
+int  orc_num_nodes(int num_seg);
+void orc_time_nodes(int num_seg, double *tau);   /* ascending, [0,1] */
+void orc_diff_matrix(double *D /*4x4*/);         /* cubic CGL differentiation matrix, ascending nodes */
+
+/* ---- warm start stand-in for Ruckig (motionPlanner.cpp:146-175) ---- */
+void orc_warm_start(const orc_config *c, const double *amax_used, const double *x0, const double *xf,
+                    double *xg, double *ug, double *Tg);
+
+/* ---- the hot path: one OCP ---- */
+/* z layout: xs[N][14], us[N][7], T.  lam (optional, size m_eq+m_in+n) receives final multipliers */
+void orc_solve(const orc_model *m, const orc_config *c, const double *x0, const double *xf,
+               const double *xg, const double *ug, double Tg,
+               double *xs, double *us, double *T, orc_info *info);
+/* batch helper used by the cpu_baseline leg: sequential loop, or `threads` std pthreads */
+void orc_solve_batch(const orc_model *m, const orc_config *c, int B, const double *x0, const double *xf,
+                     const double *xg, const double *ug, const double *Tg,
+                     double *xs, double *us, double *T, orc_info *info, int threads);
+
+/* ---- resampling (motionPlanner.hpp:99-128) ---- */
+void orc_sample(const orc_model *m, int num_seg, const double *xs, const double *us, double T,
+                int n_pts, double *out /* (n_pts+1) x 29: t,q,v,a,tau */);
+
+/* ---- pieces exposed for unit tests of the QP layer ---- */
+/* Assemble the QP of one SQP iteration at (xs,us,T,lam) and run ADMM; returns iterations used. */
+int orc_debug_qp(const orc_model *m, const orc_config *c, const double *x0, const double *xf,
+                 const double *xs, const double *us, double T, const double *lam,
+                 double *p /*n*/, double *y /*m+n*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
