@@ -1,0 +1,149 @@
+/*
+ * mpcmp.h — C ABI of the MI355X-native batched minimum-time joint-space MPC solver.
+ *
+ * Drop-in boundary for the hot path of AlbericDeLajarte/mpc_motion_planner. The reference has no FFI
+ * layer: its boundary is the C++ class `MotionPlanner` (mpc_solver/motionPlanner.hpp:16-176) whose
+ * solve_trajectory() (mpc_solver/motionPlanner.cpp:177-208) calls polympc's mpc.solve() once per
+ * (start,target) pair on one CPU thread (examples/benchmark.cpp:16 loops it 1000 times).  This ABI is what
+ * a batched `MotionPlanner` binds instead; include/mpcmp_motion_planner.hpp is that binding.
+ *
+ * Conventions: every entry point returns 0 on success or a negative MPCMP_E* code and never throws; plain
+ * pointers and sizes only; doubles everywhere (the reference is `double`, robot_ocp.hpp:38).  `*_device`
+ * entry points take DEVICE pointers and a hipStream_t (as void*) and are asynchronous on that stream;
+ * the others take HOST pointers and are synchronous.
+ *
+ * Layouts (node-major, ascending time — motionPlanner.cpp:158-174,202-203):
+ *   x0, xf   [B][14]        = [q(7); qd(7)]            current_state / target_state (motionPlanner.hpp:40-41)
+ *   sol_x    [B][N][14]     state at collocation node k  (mpc.solution_x(),  traj_state_t)
+ *   sol_u    [B][N][7]      control (= qdd) at node k    (mpc.solution_u(),  traj_control_t)
+ *   sol_T    [B]            final time                   (mpc.solution_p()[0])
+ *   N = 3*num_seg + 1       (POLY_ORDER 3, robot_ocp.hpp:31-36)
+ */
+#ifndef MPCMP_H
+#define MPCMP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCMP_NDOF 7
+#define MPCMP_NX 14
+#define MPCMP_NU 7
+#define MPCMP_NG 8
+
+#define MPCMP_OK 0
+#define MPCMP_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define MPCMP_ENODEVICE (-2)   /* no HIP device, or the HIP runtime failed: the product has NO CPU fallback */
+#define MPCMP_ERUNTIME (-3)    /* a HIP call failed; see mpcmp_last_error */
+#define MPCMP_ETOOBIG (-4)     /* batch larger than the context's capacity */
+
+typedef struct mpcmp_ctx mpcmp_ctx;
+
+/* Serial chain of 7 revolute-z joints + tool frame; replaces pinocchio::Model built from the URDF
+ * (robot_ocp.hpp:50-53, robot_utils/pandaWrapper.cpp:3-12). Same memory layout as the oracle's model. */
+typedef struct {
+    double R0[7][9];   /* fixed rotation of the joint placement (row-major), parent <- joint at q=0 */
+    double p[7][3];    /* joint origin in the parent joint frame                                     */
+    double mass[7];
+    double com[7][3];  /* COM of the lumped body in its joint frame                                  */
+    double I[7][9];    /* rotational inertia about the COM                                           */
+    double tool[3];    /* frame "panda_tool" in the joint-7 frame (height constraint, robot_ocp.hpp:52,91) */
+    double link8[3];   /* frame "panda_link8" in the joint-7 frame                                    */
+    double gravity[3];
+} mpcmp_model;
+
+/* Solver settings + bounds; replaces mpc.settings()/qp_settings()/..._bounds() (motionPlanner.cpp:15-20,56-100). */
+typedef struct {
+    int    num_seg;          /* NUM_SEG, robot_ocp.hpp:32 (4 -> 13 nodes, 6 -> 19 nodes as shipped)        */
+    int    sqp_iters;        /* mpc.settings().max_iter,             motionPlanner.cpp:15 (2 as shipped)   */
+    int    qp_iters;         /* mpc.qp_settings().max_iter,          motionPlanner.cpp:16 (700)            */
+    int    ls_iters;         /* mpc.settings().line_search_max_iter, motionPlanner.cpp:17 (10)             */
+    int    check_every;      /* ADMM termination-test interval (25)                                         */
+    int    quirk_dtau_dT;    /* keep the non-physical d tau/dT column of robot_ocp.hpp:124,138 (1)          */
+    double eps_abs, eps_rel; /* mpc.qp_settings().eps_*,             motionPlanner.cpp:19-20 (1e-3)        */
+    double rho, sigma, alpha, rho_eq_scale;   /* box-ADMM parameters (0.1, 1e-6, 1.6, 1e3)                  */
+    double ls_eta, ls_tau;   /* Armijo fraction and backtracking factor (0.25, 0.5)                         */
+    double hess_reg;         /* Gershgorin shift, polympc_redef.hpp:68 (1e-3)                               */
+    double eps_target;       /* terminal box half-width, motionPlanner.hpp:44 (1e-2)                        */
+    double lbx[14], ubx[14]; /* mpc.state_bounds,       motionPlanner.cpp:66-70 */
+    double lbu[7], ubu[7];   /* mpc.control_bounds,     motionPlanner.cpp:73    */
+    double lbg[8], ubg[8];   /* mpc.constraints_bounds, motionPlanner.cpp:92-98 */
+    double lbT, ubT;         /* mpc.parameters_bounds,  motionPlanner.cpp:76-79 */
+} mpcmp_config;
+
+/* Per-problem result record; replaces mpc.info() (never read by the reference, motionPlanner.cpp:191). */
+typedef struct {
+    double T;             /* final time                                                   */
+    double viol_l1;       /* l1 constraint violation of the returned iterate              */
+    double defect_inf;    /* inf-norm of the collocation defects                          */
+    double path_viol_inf; /* inf-norm violation of torque / height bounds at the nodes    */
+    double term_err_inf;  /* || x_N - x_target ||_inf                                     */
+    double last_alpha;    /* step length of the last SQP iteration                        */
+    int    qp_iters_total;/* ADMM iterations executed over all SQP iterations             */
+    int    sqp_iters;
+    int    status;        /* 0 ok; bit0 NaN/Inf in the iterate; bit1 KKT factorisation lost positive definiteness */
+    int    pad;
+} mpcmp_info;
+
+/* ---- configuration helpers (host, no GPU needed) ---- */
+int mpcmp_default_model(mpcmp_model *m);                                    /* Panda arm, panda_arm.urdf */
+int mpcmp_model_from_urdf(const char *urdf_path, mpcmp_model *m);           /* MotionPlanner(std::string urdf_path), motionPlanner.cpp:3 */
+int mpcmp_default_limits(double *qmin, double *qmax, double *vmax, double *amax, double *jmax,
+                         double *taumax);                                    /* pandaWrapper.hpp:29-34 */
+int mpcmp_default_config(mpcmp_config *c, int num_seg, int sqp_iters);      /* motionPlanner.cpp:15-24 */
+int mpcmp_set_margins(mpcmp_config *c, double margin_position, double margin_velocity,
+                      double margin_acceleration, double margin_torque);    /* set_constraint_margins, motionPlanner.cpp:56-90 */
+int mpcmp_set_min_height(mpcmp_config *c, double min_height);               /* set_min_height, motionPlanner.cpp:92-100 */
+int mpcmp_num_nodes(int num_seg);
+int mpcmp_time_nodes(int num_seg, double *tau);                             /* mpc.ocp().time_nodes, ascending */
+const char *mpcmp_version(void);
+
+/* ---- context ---- */
+/* model == NULL -> compiled-in Panda. Allocates all device workspaces for up to max_batch problems;
+ * no allocation happens in the solve calls. Fails with MPCMP_ENODEVICE when no GPU is present. */
+int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, int device, int max_batch, mpcmp_ctx **out);
+int mpcmp_destroy(mpcmp_ctx *ctx);
+int mpcmp_set_config(mpcmp_ctx *ctx, const mpcmp_config *cfg);             /* num_seg must not change */
+const char *mpcmp_last_error(const mpcmp_ctx *ctx);
+
+/* ---- the hot path: B independent OCPs == B calls of MotionPlanner::solve_trajectory ---- */
+/* warm_x/warm_u/warm_T: x_guess/u_guess/p_guess (motionPlanner.cpp:172-174); all NULL -> built-in
+ * initialiser standing in for warm_start_RK (motionPlanner.cpp:146-175). info may be NULL. */
+int mpcmp_solve_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf,
+                      const double *warm_x, const double *warm_u, const double *warm_T,
+                      double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info);
+int mpcmp_solve_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf,
+                             const double *d_warm_x, const double *d_warm_u, const double *d_warm_T,
+                             double *d_sol_x, double *d_sol_u, double *d_sol_T, mpcmp_info *d_info,
+                             void *hip_stream);
+/* built-in initialiser alone (what solve_batch uses when warm_* are NULL) */
+int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf,
+                           double *warm_x, double *warm_u, double *warm_T);
+
+/* ---- leaf kernels exposed for parity tests and for callers that only need the rigid-body layer ---- */
+/* pinocchio::rnea (robot_ocp.hpp:91; motionPlanner.hpp:92,111,127,141): n x [q7],[qd7],[qdd7] -> n x [tau7] */
+int mpcmp_rnea_batch(mpcmp_ctx *ctx, int n, const double *q, const double *qd, const double *qdd, double *tau);
+/* minTime_ocp::evalConstraints AD overload (robot_ocp.hpp:98-163): n x [x14],[u7] -> g [n][8], G [n][8][22] */
+int mpcmp_eval_constraints_batch(mpcmp_ctx *ctx, int n, const double *x, const double *u, double *g, double *G);
+/* one QP of the SQP (linearise at (x,u,T,lam=0) + box-ADMM): p [B][21N+1] (layout xs|us|T), y [B][m+n],
+ * iters [B]; m = 14(N-1) + 8N rows ordered [dynamics | path], then the n box rows. */
+int mpcmp_qp_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *xs,
+                   const double *us, const double *T, double *p, double *y, int *iters);
+
+/* ---- resampling: MotionPlanner::get_MPC_trajectory<n_pts> (motionPlanner.hpp:99-116) ---- */
+/* out [B][n_pts+1][29] = time, q(7), qd(7), qdd(7), tau(7) — the row format of analysis/optimal_solution.txt
+ * (examples/offline_trajectory.cpp:88-105) */
+int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double *sol_u, const double *sol_T,
+                       int n_pts, double *out);
+int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sol_x, const double *d_sol_u,
+                              const double *d_sol_T, int n_pts, double *d_out, void *hip_stream);
+
+/* ---- measurement hooks used by bench.py ---- */
+/* name and accumulated device time (ms, HIP events on the solve stream) of the dominant kernel since the
+ * last reset; launches = number of launches accumulated. */
+int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name, double *ms_total, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

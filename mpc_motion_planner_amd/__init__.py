@@ -1,0 +1,14 @@
+"""mpc_motion_planner_amd — host-side binding of libmpcmp.so (HIP / gfx950).
+
+The product is the C-ABI shared library declared in include/mpcmp.h; this module is the thin ctypes
+binding used by bench.py and the parity tests, plus `BatchMotionPlanner`, a batched mirror of the
+reference's `MotionPlanner` façade (mpc_solver/motionPlanner.hpp:16-176).  There is no CPU fallback:
+loading fails loudly when the HIP library is missing, and every compute call fails when no GPU is present.
+"""
+from .capi import (Config, Info, Model, INFO_DTYPE, MpcmpError, build_library, default_config, default_limits,
+                   default_model, lib, library_path, model_from_urdf, num_nodes, time_nodes)
+from .planner import BatchMotionPlanner, Solver
+
+__all__ = ["Config", "Info", "Model", "INFO_DTYPE", "MpcmpError", "build_library", "default_config",
+           "default_limits", "default_model", "lib", "library_path", "model_from_urdf", "num_nodes",
+           "time_nodes", "BatchMotionPlanner", "Solver"]

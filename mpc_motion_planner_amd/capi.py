@@ -1,0 +1,126 @@
+"""ctypes declarations for include/mpcmp.h."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmpcmp.so")
+
+
+class MpcmpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mpcmp error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Model(C.Structure):
+    _fields_ = [("R0", C.c_double * 9 * 7), ("p", C.c_double * 3 * 7), ("mass", C.c_double * 7),
+                ("com", C.c_double * 3 * 7), ("I", C.c_double * 9 * 7), ("tool", C.c_double * 3),
+                ("link8", C.c_double * 3), ("gravity", C.c_double * 3)]
+
+
+class Config(C.Structure):
+    _fields_ = [("num_seg", C.c_int), ("sqp_iters", C.c_int), ("qp_iters", C.c_int), ("ls_iters", C.c_int),
+                ("check_every", C.c_int), ("quirk_dtau_dT", C.c_int),
+                ("eps_abs", C.c_double), ("eps_rel", C.c_double),
+                ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("rho_eq_scale", C.c_double),
+                ("ls_eta", C.c_double), ("ls_tau", C.c_double), ("hess_reg", C.c_double), ("eps_target", C.c_double),
+                ("lbx", C.c_double * 14), ("ubx", C.c_double * 14), ("lbu", C.c_double * 7), ("ubu", C.c_double * 7),
+                ("lbg", C.c_double * 8), ("ubg", C.c_double * 8), ("lbT", C.c_double), ("ubT", C.c_double)]
+
+
+class Info(C.Structure):
+    _fields_ = [("T", C.c_double), ("viol_l1", C.c_double), ("defect_inf", C.c_double),
+                ("path_viol_inf", C.c_double), ("term_err_inf", C.c_double), ("last_alpha", C.c_double),
+                ("qp_iters_total", C.c_int), ("sqp_iters", C.c_int), ("status", C.c_int), ("pad", C.c_int)]
+
+
+INFO_DTYPE = np.dtype([("T", "f8"), ("viol_l1", "f8"), ("defect_inf", "f8"), ("path_viol_inf", "f8"),
+                       ("term_err_inf", "f8"), ("last_alpha", "f8"), ("qp_iters_total", "i4"),
+                       ("sqp_iters", "i4"), ("status", "i4"), ("pad", "i4")])
+
+# every symbol include/mpcmp.h declares (the CPU test suite checks the library exports all of them)
+SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_default_limits", "mpcmp_default_config",
+           "mpcmp_set_margins", "mpcmp_set_min_height", "mpcmp_num_nodes", "mpcmp_time_nodes", "mpcmp_version",
+           "mpcmp_create", "mpcmp_destroy", "mpcmp_set_config", "mpcmp_last_error", "mpcmp_solve_batch",
+           "mpcmp_solve_batch_device", "mpcmp_warm_start_batch", "mpcmp_rnea_batch",
+           "mpcmp_eval_constraints_batch", "mpcmp_qp_batch", "mpcmp_sample_batch", "mpcmp_sample_batch_device",
+           "mpcmp_kernel_timing"]
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "rbd_device.hpp", "structure.hpp")]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "mpcmp.h"))
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
+        subprocess.check_call(["make", "-C", src, "-B"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise MpcmpError(-2, "libmpcmp.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                                 "there is no CPU fallback" % _SO)
+        L = C.CDLL(_SO)
+        L.mpcmp_version.restype = C.c_char_p
+        L.mpcmp_last_error.restype = C.c_char_p
+        L.mpcmp_last_error.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().mpcmp_last_error(ctx)
+        raise MpcmpError(rc, (msg or b"").decode())
+
+
+def dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def default_model():
+    m = Model(); check(lib().mpcmp_default_model(C.byref(m))); return m
+
+
+def model_from_urdf(path):
+    m = Model(); check(lib().mpcmp_model_from_urdf(path.encode(), C.byref(m))); return m
+
+
+def default_limits():
+    out = [np.zeros(7) for _ in range(6)]
+    check(lib().mpcmp_default_limits(*[dp(o) for o in out]))
+    return dict(zip(["qmin", "qmax", "vmax", "amax", "jmax", "taumax"], out))
+
+
+def default_config(num_seg=4, sqp_iters=20, margins=None, **kw):
+    c = Config(); check(lib().mpcmp_default_config(C.byref(c), int(num_seg), int(sqp_iters)))
+    if margins is not None:
+        check(lib().mpcmp_set_margins(C.byref(c), *[C.c_double(x) for x in margins[:4]]))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def num_nodes(num_seg):
+    return lib().mpcmp_num_nodes(int(num_seg))
+
+
+def time_nodes(num_seg):
+    t = np.zeros(3 * num_seg + 1); check(lib().mpcmp_time_nodes(int(num_seg), dp(t))); return t

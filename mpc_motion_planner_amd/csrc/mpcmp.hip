@@ -1,0 +1,609 @@
+// mpcmp.hip — C-ABI entry points (include/mpcmp.h) of the MI355X-native batched min-time MPC solver.
+// Host logic only orchestrates HIP launches; there is NO CPU fallback: without a HIP device every compute
+// entry point fails with MPCMP_ENODEVICE.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/mpcmp.h"
+#include "solver_kernels.hpp"
+
+using namespace mpcmp;
+
+struct mpcmp_ctx {
+    mpcmp_config cfg;
+    int device = 0, max_batch = 0, nseg = 0;
+    int N = 0, n = 0, meq = 0, m = 0, mn = 0;
+    std::string err;
+    hipStream_t stream = nullptr;
+    // device buffers
+    mpcmp_model *d_model = nullptr;
+    int *d_ext_of_int = nullptr, *d_entry_ptr = nullptr;
+    uint32_t *d_terms = nullptr;
+    WS ws{};
+    std::vector<void *> allocs;
+    // host-API staging (device side)
+    double *d_x0 = nullptr, *d_xf = nullptr, *d_wx = nullptr, *d_wu = nullptr, *d_wT = nullptr;
+    double *d_sx = nullptr, *d_su = nullptr, *d_sT = nullptr;
+    mpcmp_info *d_info = nullptr;
+    // timing of the dominant kernel (k_qp)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t ev_used = 0;
+    double qp_ms = 0.0;
+    int qp_launches = 0;
+    bool timing = true;
+};
+
+static thread_local std::string g_err;
+
+#define HIPCHK(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            std::ostringstream os_;                                                           \
+            os_ << #call << " failed: " << hipGetErrorString(e_) << " (" << __FILE__ << ":" << __LINE__ << ")"; \
+            if (ctx) (ctx)->err = os_.str();                                                  \
+            g_err = os_.str();                                                                \
+            return MPCMP_ERUNTIME;                                                            \
+        }                                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// configuration helpers (host only)
+extern "C" const char *mpcmp_version(void) { return "mpcmp 0.1 (gfx950)"; }
+
+extern "C" int mpcmp_num_nodes(int num_seg) { return 3 * num_seg + 1; }
+
+extern "C" int mpcmp_time_nodes(int num_seg, double *tau) {
+    if (num_seg < 1 || !tau) return MPCMP_EINVAL;
+    static const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    for (int s = 0; s < num_seg; s++)
+        for (int j = 0; j < 4; j++) tau[3 * s + j] = (s + 0.5 * (xi[j] + 1.0)) / num_seg;
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_default_limits(double *qmin, double *qmax, double *vmax, double *amax, double *jmax,
+                                    double *taumax) {
+    // Franka Emika limits as tabulated by the reference, robot_utils/pandaWrapper.hpp:29-34
+    static const double t[6][7] = {{-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973},
+                                   {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973},
+                                   {2.1750, 2.1750, 2.1750, 2.1750, 2.6100, 2.6100, 2.6100},
+                                   {15.0, 7.5, 10.0, 12.5, 15.0, 20.0, 20.0},
+                                   {7500, 3750, 5000, 6250, 7500, 10000, 10000},
+                                   {87, 87, 87, 87, 12, 12, 12}};
+    double *o[6] = {qmin, qmax, vmax, amax, jmax, taumax};
+    for (int k = 0; k < 6; k++)
+        if (o[k]) std::memcpy(o[k], t[k], sizeof t[k]);
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_set_min_height(mpcmp_config *c, double min_height) {
+    if (!c) return MPCMP_EINVAL;
+    c->lbg[7] = min_height;
+    c->ubg[7] = INFINITY;
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_set_margins(mpcmp_config *c, double mp, double mv, double ma, double mt) {
+    if (!c) return MPCMP_EINVAL;
+    double qmin[7], qmax[7], vmax[7], amax[7], tmax[7];
+    mpcmp_default_limits(qmin, qmax, vmax, amax, nullptr, tmax);
+    for (int j = 0; j < 7; j++) {
+        const double s = (1.0 - mp) * (qmax[j] - qmin[j]) / 2.0;   // motionPlanner.cpp:66
+        c->lbx[j] = qmin[j] + s; c->ubx[j] = qmax[j] - s;
+        c->lbx[7 + j] = -mv * vmax[j]; c->ubx[7 + j] = mv * vmax[j];
+        c->lbu[j] = -ma * amax[j]; c->ubu[j] = ma * amax[j];
+        c->lbg[j] = -mt * tmax[j]; c->ubg[j] = mt * tmax[j];
+    }
+    c->lbT = 0.0; c->ubT = 10.0;                                  // motionPlanner.cpp:77-78
+    return mpcmp_set_min_height(c, 0.05);                         // pandaWrapper.hpp:40
+}
+
+extern "C" int mpcmp_default_config(mpcmp_config *c, int num_seg, int sqp_iters) {
+    if (!c || num_seg < 1) return MPCMP_EINVAL;
+    std::memset(c, 0, sizeof *c);
+    c->num_seg = num_seg; c->sqp_iters = sqp_iters;
+    c->qp_iters = 700; c->ls_iters = 10; c->check_every = 25; c->quirk_dtau_dT = 1;
+    c->eps_abs = 1e-3; c->eps_rel = 1e-3;
+    c->rho = 0.1; c->sigma = 1e-6; c->alpha = 1.6; c->rho_eq_scale = 1e3;
+    c->ls_eta = 0.25; c->ls_tau = 0.5; c->hess_reg = 1e-3; c->eps_target = 1e-2;
+    return mpcmp_set_margins(c, 1.0, 1.0, 1.0, 1.0);              // motionPlanner.cpp:24
+}
+
+static void lump_last_body(mpcmp_model *m, const double mk[3], const double ck[3][3], const double Ik[3][9]) {
+    double M = mk[0] + mk[1] + mk[2], c[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) for (int d = 0; d < 3; d++) c[d] += mk[k] * ck[k][d];
+    for (int d = 0; d < 3; d++) c[d] /= M;
+    double It[9] = {0};
+    for (int k = 0; k < 3; k++) {
+        const double d[3] = {ck[k][0] - c[0], ck[k][1] - c[1], ck[k][2] - c[2]};
+        const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        for (int r = 0; r < 3; r++) for (int s = 0; s < 3; s++)
+            It[3 * r + s] += Ik[k][3 * r + s] + mk[k] * ((r == s ? d2 : 0.0) - d[r] * d[s]);
+    }
+    m->mass[6] = M;
+    std::memcpy(m->com[6], c, sizeof c);
+    std::memcpy(m->I[6], It, sizeof It);
+}
+
+static void rpy_to_R(const double rpy[3], double R[9]) {
+    const double cr = std::cos(rpy[0]), sr = std::sin(rpy[0]), cp = std::cos(rpy[1]), sp = std::sin(rpy[1]),
+                 cy = std::cos(rpy[2]), sy = std::sin(rpy[2]);
+    // R = Rz(yaw) Ry(pitch) Rx(roll)
+    R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+    R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+    R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+
+extern "C" int mpcmp_default_model(mpcmp_model *m) {
+    if (!m) return MPCMP_EINVAL;
+    // Kinematic / inertial parameters of the Panda arm (robot_utils/panda-model/panda_arm.urdf)
+    static const double rpy[7][3] = {{0, 0, 0}, {-1.57079632679, 0, 0}, {1.57079632679, 0, 0}, {1.57079632679, 0, 0},
+                                     {-1.57079632679, 0, 0}, {1.57079632679, 0, 0}, {1.57079632679, 0, 0}};
+    static const double xyz[7][3] = {{0, 0, 0.333}, {0, 0, 0}, {0, -0.316, 0}, {0.0825, 0, 0},
+                                     {-0.0825, 0.384, 0}, {0, 0, 0}, {0.088, 0, 0}};
+    static const double mass[7] = {4.970684, 0.646926, 3.228604, 3.587895, 1.225946, 1.666555, 0.735522};
+    static const double com[7][3] = {{3.875e-03, 2.081e-03, -0.1750}, {-3.141e-03, -2.872e-02, 3.495e-03},
+                                     {2.7518e-02, 3.9252e-02, -6.6502e-02}, {-5.317e-02, 1.04419e-01, 2.7454e-02},
+                                     {-1.1953e-02, 4.1065e-02, -3.8437e-02}, {6.0149e-02, -1.4117e-02, -1.0517e-02},
+                                     {1.0517e-02, -4.252e-03, 6.1597e-02}};
+    static const double in6[7][6] = {{7.0337e-01, -1.3900e-04, 6.7720e-03, 7.0661e-01, 1.9169e-02, 9.1170e-03},
+                                     {7.9620e-03, -3.9250e-03, 1.0254e-02, 2.8110e-02, 7.0400e-04, 2.5995e-02},
+                                     {3.7242e-02, -4.7610e-03, -1.1396e-02, 3.6155e-02, -1.2805e-02, 1.0830e-02},
+                                     {2.5853e-02, 7.7960e-03, -1.3320e-03, 1.9552e-02, 8.6410e-03, 2.8323e-02},
+                                     {3.5549e-02, -2.1170e-03, -4.0370e-03, 2.9474e-02, 2.2900e-04, 8.6270e-03},
+                                     {1.9640e-03, 1.0900e-04, -1.1580e-03, 4.3540e-03, 3.4100e-04, 5.4330e-03},
+                                     {1.2516e-02, -4.2800e-04, -1.1960e-03, 1.0027e-02, -7.4100e-04, 4.8150e-03}};
+    std::memset(m, 0, sizeof *m);
+    for (int i = 0; i < 7; i++) {
+        rpy_to_R(rpy[i], m->R0[i]);
+        std::memcpy(m->p[i], xyz[i], sizeof xyz[i]);
+        m->mass[i] = mass[i];
+        std::memcpy(m->com[i], com[i], sizeof com[i]);
+        const double *I = in6[i];
+        const double F[9] = {I[0], I[1], I[2], I[1], I[3], I[4], I[2], I[4], I[5]};
+        std::memcpy(m->I[i], F, sizeof F);
+    }
+    m->link8[2] = 0.107;
+    m->tool[2] = 0.107 + 0.15;
+    m->gravity[2] = -9.81;
+    // fixed children of link7: link8 (m=0, I=1e-3 Id) and panda_tool (m=1, I=1e-3 Id) are lumped into body 7
+    const double mk[3] = {mass[6], 0.0, 1.0};
+    const double ck[3][3] = {{com[6][0], com[6][1], com[6][2]}, {0, 0, 0.107}, {0, 0, 0.257}};
+    double Ik[3][9];
+    std::memcpy(Ik[0], m->I[6], sizeof Ik[0]);
+    for (int k = 1; k < 3; k++) { std::memset(Ik[k], 0, sizeof Ik[k]); Ik[k][0] = Ik[k][4] = Ik[k][8] = 1e-3; }
+    lump_last_body(m, mk, ck, Ik);
+    return MPCMP_OK;
+}
+
+// ---- minimal URDF reader for a serial chain of revolute-z joints followed by fixed links --------
+namespace {
+struct UrdfLink { double mass = 0, com[3] = {0, 0, 0}, I[9] = {0}; bool has_inertial = false; };
+struct UrdfJoint { std::string type, parent, child; double xyz[3] = {0, 0, 0}, rpy[3] = {0, 0, 0}, axis[3] = {0, 0, 1}; };
+
+static std::string attr(const std::string &tag, const std::string &key) {
+    size_t p = 0;
+    while ((p = tag.find(key + "=", p)) != std::string::npos) {
+        if (p > 0 && (isalnum((unsigned char)tag[p - 1]) || tag[p - 1] == '_')) { p += key.size(); continue; }
+        const size_t q0 = p + key.size() + 1;
+        const char quote = tag[q0];
+        const size_t q1 = tag.find(quote, q0 + 1);
+        return tag.substr(q0 + 1, q1 - q0 - 1);
+    }
+    return "";
+}
+static void parse3(const std::string &s, double *o) {
+    if (s.empty()) return;
+    std::istringstream is(s);
+    is >> o[0] >> o[1] >> o[2];
+}
+}  // namespace
+
+extern "C" int mpcmp_model_from_urdf(const char *path, mpcmp_model *m) {
+    if (!path || !m) return MPCMP_EINVAL;
+    std::ifstream f(path);
+    if (!f) { g_err = std::string("cannot open URDF ") + path; return MPCMP_EINVAL; }
+    std::stringstream ss; ss << f.rdbuf();
+    const std::string xml = ss.str();
+    std::map<std::string, UrdfLink> links;
+    std::vector<UrdfJoint> joints;
+    size_t pos = 0;
+    std::string cur_link; UrdfJoint cur_joint; bool in_link = false, in_joint = false, in_inertial = false;
+    while ((pos = xml.find('<', pos)) != std::string::npos) {
+        const size_t end = xml.find('>', pos);
+        if (end == std::string::npos) break;
+        const std::string tag = xml.substr(pos + 1, end - pos - 1);
+        pos = end + 1;
+        if (tag.empty() || tag[0] == '?' || tag[0] == '!') continue;
+        std::istringstream ts(tag); std::string name; ts >> name;
+        if (!name.empty() && name.back() == '/') name.pop_back();
+        if (name == "link") { cur_link = attr(tag, "name"); links[cur_link]; in_link = tag.back() != '/'; }
+        else if (name == "/link") in_link = false;
+        else if (name == "joint" && tag.find("type=") != std::string::npos) {
+            cur_joint = UrdfJoint(); cur_joint.type = attr(tag, "type"); in_joint = true;
+        } else if (name == "/joint") { if (in_joint) joints.push_back(cur_joint); in_joint = false; }
+        else if (name == "inertial") in_inertial = true;
+        else if (name == "/inertial") in_inertial = false;
+        else if (name == "origin") {
+            if (in_joint) { parse3(attr(tag, "xyz"), cur_joint.xyz); parse3(attr(tag, "rpy"), cur_joint.rpy); }
+            else if (in_link && in_inertial) {
+                parse3(attr(tag, "xyz"), links[cur_link].com);
+                double rpy[3] = {0, 0, 0}; parse3(attr(tag, "rpy"), rpy);
+                if (rpy[0] != 0 || rpy[1] != 0 || rpy[2] != 0) { g_err = "rotated inertial frames are not supported"; return MPCMP_EINVAL; }
+            }
+        } else if (name == "mass" && in_link && in_inertial) { links[cur_link].mass = atof(attr(tag, "value").c_str()); links[cur_link].has_inertial = true; }
+        else if (name == "inertia" && in_link && in_inertial) {
+            UrdfLink &L = links[cur_link];
+            const double xx = atof(attr(tag, "ixx").c_str()), xy = atof(attr(tag, "ixy").c_str()), xz = atof(attr(tag, "ixz").c_str()),
+                         yy = atof(attr(tag, "iyy").c_str()), yz = atof(attr(tag, "iyz").c_str()), zz = atof(attr(tag, "izz").c_str());
+            const double F[9] = {xx, xy, xz, xy, yy, yz, xz, yz, zz};
+            std::memcpy(L.I, F, sizeof F);
+        } else if (name == "parent" && in_joint) cur_joint.parent = attr(tag, "link");
+        else if (name == "child" && in_joint) cur_joint.child = attr(tag, "link");
+        else if (name == "axis" && in_joint) parse3(attr(tag, "xyz"), cur_joint.axis);
+    }
+    std::vector<UrdfJoint> rev, fixed;
+    for (auto &j : joints) (j.type == "revolute" || j.type == "continuous" ? rev : fixed).push_back(j);
+    if (rev.size() != 7) { g_err = "URDF must contain exactly 7 revolute joints"; return MPCMP_EINVAL; }
+    std::memset(m, 0, sizeof *m);
+    for (int i = 0; i < 7; i++) {
+        const UrdfJoint &j = rev[i];
+        if (i > 0 && j.parent != rev[i - 1].child) { g_err = "revolute joints do not form a serial chain"; return MPCMP_EINVAL; }
+        if (!(j.axis[0] == 0 && j.axis[1] == 0 && j.axis[2] == 1)) { g_err = "only +z joint axes are supported"; return MPCMP_EINVAL; }
+        rpy_to_R(j.rpy, m->R0[i]);
+        std::memcpy(m->p[i], j.xyz, sizeof j.xyz);
+        const UrdfLink &L = links[j.child];
+        m->mass[i] = L.mass; std::memcpy(m->com[i], L.com, sizeof L.com); std::memcpy(m->I[i], L.I, sizeof L.I);
+    }
+    // fixed chain after the last revolute joint: link7 -> link8 -> panda_tool (panda_arm.urdf:134-153)
+    double mk[3] = {m->mass[6], 0, 0}, ck[3][3] = {{m->com[6][0], m->com[6][1], m->com[6][2]}, {0, 0, 0}, {0, 0, 0}}, Ik[3][9];
+    std::memcpy(Ik[0], m->I[6], sizeof Ik[0]); std::memset(Ik[1], 0, sizeof Ik[1]); std::memset(Ik[2], 0, sizeof Ik[2]);
+    std::string parent = rev[6].child; double off[3] = {0, 0, 0}; int nfix = 0;
+    for (int guard = 0; guard < 2; guard++) {
+        const UrdfJoint *fj = nullptr;
+        for (auto &j : fixed) if (j.parent == parent) fj = &j;
+        if (!fj) break;
+        if (fj->rpy[0] != 0 || fj->rpy[1] != 0 || fj->rpy[2] != 0) { g_err = "rotated fixed joints are not supported"; return MPCMP_EINVAL; }
+        for (int d = 0; d < 3; d++) off[d] += fj->xyz[d];
+        const UrdfLink &L = links[fj->child];
+        nfix++;
+        mk[nfix] = L.mass;
+        for (int d = 0; d < 3; d++) ck[nfix][d] = off[d] + L.com[d];
+        std::memcpy(Ik[nfix], L.I, sizeof L.I);
+        if (nfix == 1) std::memcpy(m->link8, off, sizeof off);
+        std::memcpy(m->tool, off, sizeof off);
+        parent = fj->child;
+    }
+    lump_last_body(m, mk, ck, Ik);
+    m->gravity[2] = -9.81;
+    return MPCMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+template <typename T>
+static int dalloc(mpcmp_ctx *ctx, T **p, size_t count) {
+    void *q = nullptr;
+    HIPCHK(ctx, hipMalloc(&q, count * sizeof(T)));
+    ctx->allocs.push_back(q);
+    *p = (T *)q;
+    return MPCMP_OK;
+}
+
+static int validate(const mpcmp_config *c, std::string &err) {
+    if (c->num_seg != 1 && c->num_seg != 2 && c->num_seg != 4 && c->num_seg != 6) { err = "num_seg must be 1, 2, 4 or 6 on the HIP backend"; return MPCMP_EINVAL; }
+    if (c->sqp_iters < 1 || c->qp_iters < 1 || c->check_every < 1) { err = "iteration counts must be >= 1"; return MPCMP_EINVAL; }
+    if (c->ls_iters < 2 || c->ls_iters > 10) { err = "ls_iters must be in [2,10]"; return MPCMP_EINVAL; }
+    if (!(c->rho > 0) || !(c->sigma > 0) || !(c->alpha > 0 && c->alpha < 2)) { err = "rho, sigma > 0 and 0 < alpha < 2 required"; return MPCMP_EINVAL; }
+    return MPCMP_OK;
+}
+
+extern "C" const char *mpcmp_last_error(const mpcmp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+extern "C" int mpcmp_destroy(mpcmp_ctx *ctx) {
+    if (!ctx) return MPCMP_OK;
+    (void)hipSetDevice(ctx->device);
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    for (auto &e : ctx->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, int device, int max_batch, mpcmp_ctx **out) {
+    if (!cfg || !out || max_batch < 1) return MPCMP_EINVAL;
+    *out = nullptr;
+    if (int rc = validate(cfg, g_err)) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device >= ndev) {
+        g_err = "no HIP device available: the mpcmp product path has no CPU fallback";
+        return MPCMP_ENODEVICE;
+    }
+    mpcmp_ctx *ctx = new mpcmp_ctx();
+    ctx->cfg = *cfg; ctx->device = device; ctx->max_batch = max_batch; ctx->nseg = cfg->num_seg;
+    ctx->N = 3 * cfg->num_seg + 1; ctx->n = 21 * ctx->N + 1; ctx->meq = 14 * (ctx->N - 1);
+    ctx->m = ctx->meq + 8 * ctx->N; ctx->mn = ctx->m + ctx->n;
+    auto fail = [&](int rc) { g_err = ctx->err; mpcmp_destroy(ctx); return rc; };
+#define TRY(x) do { int rc_ = (x); if (rc_) return fail(rc_); } while (0)
+#define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return fail(MPCMP_ERUNTIME); } } while (0)
+    HIPTRY(hipSetDevice(device));
+    HIPTRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    mpcmp_model mdl;
+    if (model) mdl = *model; else mpcmp_default_model(&mdl);
+    TRY(dalloc(ctx, &ctx->d_model, 1));
+    HIPTRY(hipMemcpy(ctx->d_model, &mdl, sizeof mdl, hipMemcpyHostToDevice));
+    StructureTables tab;
+    if (!build_tables(cfg->num_seg, tab)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
+    TRY(dalloc(ctx, &ctx->d_ext_of_int, tab.ext_of_int.size()));
+    TRY(dalloc(ctx, &ctx->d_entry_ptr, tab.entry_ptr.size()));
+    TRY(dalloc(ctx, &ctx->d_terms, tab.terms.size()));
+    HIPTRY(hipMemcpy(ctx->d_ext_of_int, tab.ext_of_int.data(), tab.ext_of_int.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(ctx->d_entry_ptr, tab.entry_ptr.data(), tab.entry_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(ctx->d_terms, tab.terms.data(), tab.terms.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const size_t B = max_batch, N = ctx->N, n = ctx->n, mn = ctx->mn;
+    WS &w = ctx->ws;
+    w.model = ctx->d_model; w.ext_of_int = ctx->d_ext_of_int; w.entry_ptr = ctx->d_entry_ptr; w.terms = ctx->d_terms;
+    TRY(dalloc(ctx, &w.z, B * n)); TRY(dalloc(ctx, &w.lam, B * mn)); TRY(dalloc(ctx, &w.ceq, B * ctx->meq));
+    TRY(dalloc(ctx, &w.g, B * 8 * N)); TRY(dalloc(ctx, &w.Gk, B * N * 176)); TRY(dalloc(ctx, &w.p, B * n));
+    TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.qp_total, B));
+    TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B));
+    TRY(dalloc(ctx, &ctx->d_x0, B * 14)); TRY(dalloc(ctx, &ctx->d_xf, B * 14));
+    TRY(dalloc(ctx, &ctx->d_wx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_wu, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
+    TRY(dalloc(ctx, &ctx->d_sx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_su, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_sT, B));
+    TRY(dalloc(ctx, &ctx->d_info, B));
+#undef TRY
+#undef HIPTRY
+    *out = ctx;
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_set_config(mpcmp_ctx *ctx, const mpcmp_config *cfg) {
+    if (!ctx || !cfg) return MPCMP_EINVAL;
+    if (cfg->num_seg != ctx->nseg) { ctx->err = "num_seg cannot change after mpcmp_create"; return MPCMP_EINVAL; }
+    if (int rc = validate(cfg, ctx->err)) return rc;
+    ctx->cfg = *cfg;
+    return MPCMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+template <typename K>
+static int set_lds(mpcmp_ctx *ctx, K kern, size_t bytes) {
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MPCMP_OK;
+}
+
+static hipEvent_t *next_events(mpcmp_ctx *ctx) {
+    if (ctx->ev_used == ctx->ev.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+        ctx->ev.emplace_back(a, b);
+    }
+    return &ctx->ev[ctx->ev_used++].first;
+}
+
+template <int NSEG>
+static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_wx,
+                      const double *d_wu, const double *d_wT, double *d_sx, double *d_su, double *d_sT,
+                      mpcmp_info *d_info, hipStream_t st, int only_qp) {
+    using D = Dim<NSEG>;
+    WS w = ctx->ws;
+    w.x0 = d_x0; w.xf = d_xf;
+    const size_t l_init = InitLds<NSEG>::size * sizeof(double), l_qp = QpLds<NSEG>::size * sizeof(double),
+                 l_step = StepLds<NSEG>::size * sizeof(double);
+    if (int rc = set_lds(ctx, k_init<NSEG>, l_init)) return rc;
+    if (int rc = set_lds(ctx, k_qp<NSEG>, l_qp)) return rc;
+    if (int rc = set_lds(ctx, k_step<NSEG>, l_step)) return rc;
+    hipLaunchKernelGGL(k_init<NSEG>, dim3(B), dim3(D::NT), l_init, st, ctx->cfg, w, d_wx, d_wu, d_wT);
+    const int iters = only_qp ? 1 : ctx->cfg.sqp_iters;
+    for (int it = 0; it < iters; it++) {
+        hipEvent_t *ev = ctx->timing ? next_events(ctx) : nullptr;
+        if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
+        hipLaunchKernelGGL(k_qp<NSEG>, dim3(B), dim3(D::NT), l_qp, st, ctx->cfg, w);
+        if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
+        if (only_qp) break;
+        hipLaunchKernelGGL(k_step<NSEG>, dim3(B), dim3(D::NT), l_step, st, ctx->cfg, w, it == iters - 1 ? 1 : 0, it,
+                           d_sx, d_su, d_sT, d_info);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return MPCMP_OK;
+}
+
+static int solve_dispatch(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_wx,
+                          const double *d_wu, const double *d_wT, double *d_sx, double *d_su, double *d_sT,
+                          mpcmp_info *d_info, hipStream_t st, int only_qp) {
+    if (!ctx) return MPCMP_EINVAL;
+    if (B < 1) return MPCMP_EINVAL;
+    if (B > ctx->max_batch) { ctx->err = "batch exceeds the context capacity"; return MPCMP_ETOOBIG; }
+    if (!d_x0 || !d_xf) return MPCMP_EINVAL;
+    if ((d_wx != nullptr) != (d_wu != nullptr) || (d_wx != nullptr) != (d_wT != nullptr)) { ctx->err = "warm_x, warm_u, warm_T must be all given or all NULL"; return MPCMP_EINVAL; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    switch (ctx->nseg) {
+        case 1: return solve_impl<1>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp);
+        case 2: return solve_impl<2>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp);
+        case 4: return solve_impl<4>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp);
+        case 6: return solve_impl<6>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp);
+    }
+    return MPCMP_EINVAL;
+}
+
+extern "C" int mpcmp_solve_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf,
+                                        const double *d_wx, const double *d_wu, const double *d_wT, double *d_sx,
+                                        double *d_su, double *d_sT, mpcmp_info *d_info, void *hip_stream) {
+    if (!d_sx || !d_su || !d_sT) return MPCMP_EINVAL;
+    return solve_dispatch(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, (hipStream_t)hip_stream, 0);
+}
+
+extern "C" int mpcmp_solve_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *wx,
+                                 const double *wu, const double *wT, double *sx, double *su, double *sT, mpcmp_info *info) {
+    if (!ctx || !x0 || !xf || !sx || !su || !sT) return MPCMP_EINVAL;
+    if (B < 1) return MPCMP_EINVAL;
+    if (B > ctx->max_batch) { ctx->err = "batch exceeds the context capacity"; return MPCMP_ETOOBIG; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = ctx->N;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    const bool warm = wx && wu && wT;
+    if (warm) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_wx, wx, sizeof(double) * 14 * N * B, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_wu, wu, sizeof(double) * 7 * N * B, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_wT, wT, sizeof(double) * B, hipMemcpyHostToDevice, st));
+    } else if (wx || wu || wT) { ctx->err = "warm_x, warm_u, warm_T must be all given or all NULL"; return MPCMP_EINVAL; }
+    if (int rc = solve_dispatch(ctx, B, ctx->d_x0, ctx->d_xf, warm ? ctx->d_wx : nullptr, warm ? ctx->d_wu : nullptr,
+                                warm ? ctx->d_wT : nullptr, ctx->d_sx, ctx->d_su, ctx->d_sT, ctx->d_info, st, 0))
+        return rc;
+    HIPCHK(ctx, hipMemcpyAsync(sx, ctx->d_sx, sizeof(double) * 14 * N * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(su, ctx->d_su, sizeof(double) * 7 * N * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(sT, ctx->d_sT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    if (info) HIPCHK(ctx, hipMemcpyAsync(info, ctx->d_info, sizeof(mpcmp_info) * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, double *wx, double *wu, double *wT) {
+    if (!ctx || !x0 || !xf || !wx || !wu || !wT || B < 1) return MPCMP_EINVAL;
+    if (B > ctx->max_batch) return MPCMP_ETOOBIG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = ctx->N, n = ctx->n;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    // k_init alone: the built-in initialiser writes the iterate z = [xs|us|T]
+    mpcmp_config save = ctx->cfg;
+    WS w = ctx->ws; w.x0 = ctx->d_x0; w.xf = ctx->d_xf;
+    int rc = MPCMP_OK;
+#define LAUNCH_INIT(NS) { size_t l = InitLds<NS>::size * sizeof(double); rc = set_lds(ctx, k_init<NS>, l); \
+        if (!rc) hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }
+    switch (ctx->nseg) { case 1: LAUNCH_INIT(1) break; case 2: LAUNCH_INIT(2) break; case 4: LAUNCH_INIT(4) break; case 6: LAUNCH_INIT(6) break; }
+#undef LAUNCH_INIT
+    if (rc) return rc;
+    std::vector<double> z((size_t)B * n);
+    HIPCHK(ctx, hipMemcpyAsync(z.data(), ctx->ws.z, sizeof(double) * n * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    for (int b = 0; b < B; b++) {
+        std::memcpy(wx + (size_t)b * 14 * N, z.data() + (size_t)b * n, sizeof(double) * 14 * N);
+        std::memcpy(wu + (size_t)b * 7 * N, z.data() + (size_t)b * n + 14 * N, sizeof(double) * 7 * N);
+        wT[b] = z[(size_t)b * n + 21 * N];
+    }
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_qp_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *xs,
+                              const double *us, const double *T, double *p, double *y, int *iters) {
+    if (!ctx || !x0 || !xf || !xs || !us || !T || !p || !y || B < 1) return MPCMP_EINVAL;
+    if (B > ctx->max_batch) return MPCMP_ETOOBIG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = ctx->N;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_wx, xs, sizeof(double) * 14 * N * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_wu, us, sizeof(double) * 7 * N * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_wT, T, sizeof(double) * B, hipMemcpyHostToDevice, st));
+    if (int rc = solve_dispatch(ctx, B, ctx->d_x0, ctx->d_xf, ctx->d_wx, ctx->d_wu, ctx->d_wT, ctx->d_sx, ctx->d_su,
+                                ctx->d_sT, nullptr, st, 1))
+        return rc;
+    HIPCHK(ctx, hipMemcpyAsync(p, ctx->ws.p, sizeof(double) * ctx->n * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(y, ctx->ws.y, sizeof(double) * ctx->mn * B, hipMemcpyDeviceToHost, st));
+    if (iters) HIPCHK(ctx, hipMemcpyAsync(iters, ctx->ws.qpit, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// leaf kernels
+struct TmpBuf {
+    std::vector<void *> p;
+    ~TmpBuf() { for (void *q : p) (void)hipFree(q); }
+    template <typename T> T *get(size_t count) { void *q = nullptr; if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T *)q; }
+};
+
+extern "C" int mpcmp_rnea_batch(mpcmp_ctx *ctx, int n, const double *q, const double *qd, const double *qdd, double *tau) {
+    if (!ctx || n < 1 || !q || !qd || !qdd || !tau) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TmpBuf tb;
+    double *dq = tb.get<double>(7 * (size_t)n), *dv = tb.get<double>(7 * (size_t)n), *da = tb.get<double>(7 * (size_t)n), *dt = tb.get<double>(7 * (size_t)n);
+    if (!dq || !dv || !da || !dt) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dq, q, sizeof(double) * 7 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dv, qd, sizeof(double) * 7 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(da, qdd, sizeof(double) * 7 * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rnea_batch, dim3((n + 63) / 64), dim3(64), 0, st, ctx->d_model, n, dq, dv, da, dt);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(tau, dt, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_eval_constraints_batch(mpcmp_ctx *ctx, int n, const double *x, const double *u, double *g, double *G) {
+    if (!ctx || n < 1 || !x || !u || !g || !G) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TmpBuf tb;
+    double *dx = tb.get<double>(14 * (size_t)n), *du = tb.get<double>(7 * (size_t)n), *dg = tb.get<double>(8 * (size_t)n), *dG = tb.get<double>(176 * (size_t)n);
+    if (!dx || !du || !dg || !dG) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dx, x, sizeof(double) * 14 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(du, u, sizeof(double) * 7 * n, hipMemcpyHostToDevice, st));
+    constexpr int NS = 4;
+    const size_t l = EvalLds<NS>::size * sizeof(double);
+    if (int rc = set_lds(ctx, k_eval_constraints<NS>, l)) return rc;
+    const int N = Dim<NS>::N;
+    hipLaunchKernelGGL(k_eval_constraints<NS>, dim3((n + N - 1) / N), dim3(Dim<NS>::NT), l, st, ctx->cfg, ctx->d_model, n, dx, du, dg, dG);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(g, dg, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(G, dG, sizeof(double) * 176 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sx, const double *d_su, const double *d_sT,
+                                         int n_pts, double *d_out, void *hip_stream) {
+    if (!ctx || B < 1 || n_pts < 1 || !d_sx || !d_su || !d_sT || !d_out) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long total = (long)B * (n_pts + 1);
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)hip_stream, ctx->d_model,
+                       ctx->nseg, B, n_pts, d_sx, d_su, d_sT, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sx, const double *su, const double *sT, int n_pts, double *out) {
+    if (!ctx || B < 1 || n_pts < 1 || !sx || !su || !sT || !out) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = ctx->N, np = (size_t)B * (n_pts + 1) * 29;
+    TmpBuf tb;
+    double *dx = tb.get<double>(14 * N * B), *du = tb.get<double>(7 * N * B), *dT = tb.get<double>(B), *dout = tb.get<double>(np);
+    if (!dx || !du || !dT || !dout) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dx, sx, sizeof(double) * 14 * N * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(du, su, sizeof(double) * 7 * N * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dT, sT, sizeof(double) * B, hipMemcpyHostToDevice, st));
+    if (int rc = mpcmp_sample_batch_device(ctx, B, dx, du, dT, n_pts, dout, st)) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, dout, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name, double *ms_total, int *launches) {
+    if (!ctx) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // fold finished event pairs into the accumulators (caller has synchronised the stream)
+    for (size_t i = 0; i < ctx->ev_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[i].first, ctx->ev[i].second) == hipSuccess) { ctx->qp_ms += ms; ctx->qp_launches++; }
+    }
+    ctx->ev_used = 0;
+    if (name) *name = "k_qp";
+    if (ms_total) *ms_total = ctx->qp_ms;
+    if (launches) *launches = ctx->qp_launches;
+    if (reset) { ctx->qp_ms = 0.0; ctx->qp_launches = 0; }
+    return MPCMP_OK;
+}

@@ -1,0 +1,153 @@
+// rbd_device.hpp — rigid-body layer for gfx950: RNEA with forward-mode analytic derivatives, FK and the
+// tool-height Jacobian row for a 7-joint revolute-z chain.  Replaces the Pinocchio calls on the reference's
+// hot path (robot_ocp.hpp:87-91,118-122,145-155; motionPlanner.hpp:92,111,127,141).
+//
+// One thread evaluates one (collocation node, derivative direction) pair: the Newton-Euler recursion and
+// its tangent are fused in a single fully unrolled forward/backward sweep whose per-joint spatial
+// quantities (F,N and their tangents) stay in VGPRs; sin/cos of the joint angles are staged once per node in
+// LDS and shared by the 22 threads of the node.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/mpcmp.h"
+
+namespace mpcmp {
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// s * (z_hat x v)
+__device__ __forceinline__ V3 zcross(V3 v, double s) { return mk(-s * v.y, s * v.x, 0.0); }
+
+struct M3 {
+    double a[9];
+};
+__device__ __forceinline__ V3 mul(const M3 &R, V3 v) {
+    return mk(R.a[0] * v.x + R.a[1] * v.y + R.a[2] * v.z, R.a[3] * v.x + R.a[4] * v.y + R.a[5] * v.z,
+              R.a[6] * v.x + R.a[7] * v.y + R.a[8] * v.z);
+}
+__device__ __forceinline__ V3 mulT(const M3 &R, V3 v) {
+    return mk(R.a[0] * v.x + R.a[3] * v.y + R.a[6] * v.z, R.a[1] * v.x + R.a[4] * v.y + R.a[7] * v.z,
+              R.a[2] * v.x + R.a[5] * v.y + R.a[8] * v.z);
+}
+__device__ __forceinline__ V3 mulI(const double *I, V3 v) {
+    return mk(I[0] * v.x + I[1] * v.y + I[2] * v.z, I[3] * v.x + I[4] * v.y + I[5] * v.z,
+              I[6] * v.x + I[7] * v.y + I[8] * v.z);
+}
+// R_i(q) = R0_i * Rz(q), with (s,c) = (sin q, cos q)
+__device__ __forceinline__ M3 joint_rot(const double *A, double s, double c) {
+    M3 R;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        R.a[3 * r + 0] = A[3 * r + 0] * c + A[3 * r + 1] * s;
+        R.a[3 * r + 1] = -A[3 * r + 0] * s + A[3 * r + 1] * c;
+        R.a[3 * r + 2] = A[3 * r + 2];
+    }
+    return R;
+}
+
+// tau = RNEA(q,v,a); if TANGENT also dtau = d tau / d theta with theta = (q|v|a)_j  (type 0|1|2).
+// sc: [7][2] = sin, cos of the joint angles.
+template <bool TANGENT>
+__device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, const double *sc, const double *v,
+                                         const double *a, int type, int j, double *tau, double *dtau) {
+    V3 F[7], N[7], dF[7], dN[7];
+    V3 w = mk(0, 0, 0), wd = mk(0, 0, 0), al = mk(-M->gravity[0], -M->gravity[1], -M->gravity[2]);
+    V3 dw = mk(0, 0, 0), dwd = mk(0, 0, 0), dal = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const M3 R = joint_rot(M->R0[i], sc[2 * i], sc[2 * i + 1]);
+        const V3 p = ld3(M->p[i]), c = ld3(M->com[i]);
+        const double vi = v[i], ai = a[i];
+        const V3 u = mulT(R, w), ud = mulT(R, wd);
+        const V3 b = al + cross(wd, p) + cross(w, cross(w, p));
+        const V3 wn = mk(u.x, u.y, u.z + vi);
+        const V3 wdn = mk(ud.x + u.y * vi, ud.y - u.x * vi, ud.z + ai);
+        const V3 aln = mulT(R, b);
+        const V3 wxc = cross(wn, c);
+        const V3 ac = aln + cross(wdn, c) + cross(wn, wxc);
+        const V3 Iw = mulI(M->I[i], wn);
+        F[i] = M->mass[i] * ac;
+        N[i] = mulI(M->I[i], wdn) + cross(wn, Iw);
+        if (TANGENT) {
+            const double dq = (type == 0 && i == j) ? 1.0 : 0.0;
+            const double dv = (type == 1 && i == j) ? 1.0 : 0.0;
+            const double da = (type == 2 && i == j) ? 1.0 : 0.0;
+            const V3 du = mulT(R, dw) - zcross(u, dq);
+            const V3 dud = mulT(R, dwd) - zcross(ud, dq);
+            const V3 db = dal + cross(dwd, p) + cross(dw, cross(w, p)) + cross(w, cross(dw, p));
+            const V3 dwn = mk(du.x, du.y, du.z + dv);
+            const V3 dwdn = mk(dud.x + du.y * vi + u.y * dv, dud.y - du.x * vi - u.x * dv, dud.z + da);
+            const V3 daln = mulT(R, db) - zcross(aln, dq);
+            const V3 dac = daln + cross(dwdn, c) + cross(dwn, wxc) + cross(wn, cross(dwn, c));
+            dF[i] = M->mass[i] * dac;
+            dN[i] = mulI(M->I[i], dwdn) + cross(dwn, Iw) + cross(wn, mulI(M->I[i], dwn));
+            dw = dwn; dwd = dwdn; dal = daln;
+        }
+        w = wn; wd = wdn; al = aln;
+    }
+    V3 f = mk(0, 0, 0), n = mk(0, 0, 0), df = mk(0, 0, 0), dn = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 6; i >= 0; i--) {
+        const V3 c = ld3(M->com[i]);
+        V3 fi = F[i], ni = N[i] + cross(c, F[i]);
+        V3 dfi = mk(0, 0, 0), dni = mk(0, 0, 0);
+        if (TANGENT) { dfi = dF[i]; dni = dN[i] + cross(c, dF[i]); }
+        if (i < 6) {
+            const M3 R = joint_rot(M->R0[i + 1], sc[2 * (i + 1)], sc[2 * (i + 1) + 1]);
+            const V3 p = ld3(M->p[i + 1]);
+            const V3 gf = mul(R, f), gn = mul(R, n);
+            fi = fi + gf; ni = ni + gn + cross(p, gf);
+            if (TANGENT) {
+                const double dq = (type == 0 && i + 1 == j) ? 1.0 : 0.0;
+                const V3 dgf = mul(R, df + zcross(f, dq)), dgn = mul(R, dn + zcross(n, dq));
+                dfi = dfi + dgf; dni = dni + dgn + cross(p, dgf);
+            }
+        }
+        f = fi; n = ni; df = dfi; dn = dni;
+        tau[i] = n.z;
+        if (TANGENT) dtau[i] = dn.z;
+    }
+}
+
+// Forward kinematics of the chain: tool position and the z-row of the world-aligned tool Jacobian
+// (robot_ocp.hpp:145-160: J = blockdiag(R,R) * J_local, row 2).  Also returns joint-7 origin height
+// (MotionPlanner::sample_random_state rejects on oMi[7].z, motionPlanner.cpp:111) and link8 position.
+__device__ __forceinline__ void fk_tool(const mpcmp_model *__restrict__ M, const double *sc, V3 *p_tool, double *Jz,
+                                        V3 *p_joint7, V3 *p_link8) {
+    M3 Rw; V3 pw = mk(0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rw.a[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    V3 zax[7], org[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const M3 R = joint_rot(M->R0[i], sc[2 * i], sc[2 * i + 1]);
+        pw = pw + mul(Rw, ld3(M->p[i]));
+        M3 Rn;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                Rn.a[3 * r + c] = Rw.a[3 * r + 0] * R.a[0 + c] + Rw.a[3 * r + 1] * R.a[3 + c] + Rw.a[3 * r + 2] * R.a[6 + c];
+        Rw = Rn;
+        zax[i] = mk(Rw.a[2], Rw.a[5], Rw.a[8]);
+        org[i] = pw;
+    }
+    const V3 pt = pw + mul(Rw, ld3(M->tool));
+    *p_tool = pt;
+    if (p_joint7) *p_joint7 = pw;
+    if (p_link8) *p_link8 = pw + mul(Rw, ld3(M->link8));
+    if (Jz) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) Jz[i] = cross(zax[i], pt - org[i]).z;
+    }
+}
+
+}  // namespace mpcmp

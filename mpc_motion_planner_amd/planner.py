@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference's planner façade for the batched HIP path.
+
+`Solver` is the raw context (one per GPU); `BatchMotionPlanner` keeps the member names and argument meaning
+of `MotionPlanner` (mpc_solver/motionPlanner.hpp:16-176, motionPlanner.cpp) with a leading batch dimension.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, dp, f64, lib
+
+
+class Solver:
+    """mpcmp_ctx wrapper. Host-buffer calls take numpy arrays; *_device calls take raw device pointers."""
+
+    def __init__(self, cfg, max_batch, device=0, model=None):
+        self.cfg = cfg
+        self.N = 3 * cfg.num_seg + 1
+        self.n = 21 * self.N + 1
+        self.m = 14 * (self.N - 1) + 8 * self.N
+        self.max_batch = int(max_batch)
+        self._ctx = C.c_void_p()
+        rc = lib().mpcmp_create(C.byref(cfg), C.byref(model) if model is not None else None, int(device),
+                                int(max_batch), C.byref(self._ctx))
+        check(rc)
+
+    def close(self):
+        if self._ctx:
+            lib().mpcmp_destroy(self._ctx); self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_config(self, cfg):
+        check(lib().mpcmp_set_config(self._ctx, C.byref(cfg)), self._ctx); self.cfg = cfg
+
+    # -- hot path, host buffers
+    def solve(self, x0, xf, warm=None):
+        x0, xf = f64(x0), f64(xf); B = x0.shape[0]
+        wx = wu = wT = None
+        if warm is not None:
+            wx, wu, wT = f64(warm[0]), f64(warm[1]), f64(warm[2])
+        sx, su, sT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
+        info = np.zeros(B, dtype=capi.INFO_DTYPE)
+        check(lib().mpcmp_solve_batch(self._ctx, B, dp(x0), dp(xf), dp(wx), dp(wu), dp(wT), dp(sx), dp(su), dp(sT),
+                                      info.ctypes.data_as(C.c_void_p)), self._ctx)
+        return sx, su, sT, info
+
+    # -- hot path, device-resident buffers (raw pointers, e.g. torch tensors' data_ptr())
+    def solve_device(self, B, x0, xf, sol_x, sol_u, sol_T, info=0, warm=(0, 0, 0), stream=0):
+        vp = C.c_void_p
+        check(lib().mpcmp_solve_batch_device(self._ctx, int(B), vp(x0), vp(xf), vp(warm[0] or None), vp(warm[1] or None),
+                                             vp(warm[2] or None), vp(sol_x), vp(sol_u), vp(sol_T), vp(info or None),
+                                             vp(stream or None)), self._ctx)
+
+    def warm_start(self, x0, xf):
+        x0, xf = f64(x0), f64(xf); B = x0.shape[0]
+        wx, wu, wT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
+        check(lib().mpcmp_warm_start_batch(self._ctx, B, dp(x0), dp(xf), dp(wx), dp(wu), dp(wT)), self._ctx)
+        return wx, wu, wT
+
+    def rnea(self, q, qd, qdd):
+        q, qd, qdd = f64(q), f64(qd), f64(qdd); tau = np.zeros_like(q)
+        check(lib().mpcmp_rnea_batch(self._ctx, q.shape[0], dp(q), dp(qd), dp(qdd), dp(tau)), self._ctx)
+        return tau
+
+    def eval_constraints(self, x, u):
+        x, u = f64(x), f64(u); nn = x.shape[0]
+        g, G = np.zeros((nn, 8)), np.zeros((nn, 8, 22))
+        check(lib().mpcmp_eval_constraints_batch(self._ctx, nn, dp(x), dp(u), dp(g), dp(G)), self._ctx)
+        return g, G
+
+    def qp(self, x0, xf, xs, us, T):
+        x0, xf, xs, us, T = f64(x0), f64(xf), f64(xs), f64(us), f64(T); B = x0.shape[0]
+        p, y = np.zeros((B, self.n)), np.zeros((B, self.m + self.n)); it = np.zeros(B, dtype=np.int32)
+        check(lib().mpcmp_qp_batch(self._ctx, B, dp(x0), dp(xf), dp(xs), dp(us), dp(T), dp(p), dp(y),
+                                   it.ctypes.data_as(C.c_void_p)), self._ctx)
+        return p, y, it
+
+    def sample(self, sx, su, sT, n_pts=200):
+        sx, su, sT = f64(sx), f64(su), f64(sT); B = sx.shape[0]
+        out = np.zeros((B, n_pts + 1, 29))
+        check(lib().mpcmp_sample_batch(self._ctx, B, dp(sx), dp(su), dp(sT), int(n_pts), dp(out)), self._ctx)
+        return out
+
+    def sample_device(self, B, sol_x, sol_u, sol_T, n_pts, out, stream=0):
+        vp = C.c_void_p
+        check(lib().mpcmp_sample_batch_device(self._ctx, int(B), vp(sol_x), vp(sol_u), vp(sol_T), int(n_pts), vp(out),
+                                              vp(stream or None)), self._ctx)
+
+    def kernel_timing(self, reset=False):
+        name = C.c_char_p(); ms = C.c_double(); nl = C.c_int()
+        check(lib().mpcmp_kernel_timing(self._ctx, int(reset), C.byref(name), C.byref(ms), C.byref(nl)), self._ctx)
+        return name.value.decode(), ms.value, nl.value
+
+
+class BatchMotionPlanner:
+    """Batched `MotionPlanner`: same member names / argument meaning, arrays carry a leading batch axis.
+
+    Reference call sequence (examples/benchmark.cpp:6-53): MotionPlanner(urdf); set_constraint_margins(...);
+    per problem set_current_state / set_target_state; solve_trajectory(true); get_MPC_trajectory<200>.
+    """
+
+    eps = 1e-2  # motionPlanner.hpp:44
+
+    def __init__(self, urdf_path=None, max_batch=1024, num_seg=4, sqp_iters=20, device=0):
+        self.model = capi.model_from_urdf(urdf_path) if urdf_path else capi.default_model()
+        self.limits = capi.default_limits()
+        self.cfg = capi.default_config(num_seg, sqp_iters)         # motionPlanner.cpp:15-24
+        self._solver = Solver(self.cfg, max_batch, device, self.model)
+        mid = 0.5 * (self.limits["qmin"] + self.limits["qmax"])    # motionPlanner.cpp:5-8
+        self.current_state = np.concatenate([mid, np.zeros(7)])[None, :]
+        self.target_state = self.current_state.copy()
+        self.margin_position_ = self.margin_velocity_ = self.margin_acceleration_ = 1.0
+        self.margin_torque_ = self.margin_jerk_ = 1.0
+        self._warm = None
+        self._sol = None
+
+    # motionPlanner.cpp:56-90
+    def set_constraint_margins(self, margin_position, margin_velocity, margin_acceleration, margin_torque, margin_jerk):
+        self.margin_position_, self.margin_velocity_ = margin_position, margin_velocity
+        self.margin_acceleration_, self.margin_torque_, self.margin_jerk_ = margin_acceleration, margin_torque, margin_jerk
+        check(lib().mpcmp_set_margins(C.byref(self.cfg), C.c_double(margin_position), C.c_double(margin_velocity),
+                                      C.c_double(margin_acceleration), C.c_double(margin_torque)))
+        self._solver.set_config(self.cfg)
+
+    # motionPlanner.cpp:92-100
+    def set_min_height(self, min_height):
+        check(lib().mpcmp_set_min_height(C.byref(self.cfg), C.c_double(min_height)))
+        self._solver.set_config(self.cfg)
+
+    # motionPlanner.cpp:27-39 / 41-54
+    def set_target_state(self, target_position, target_velocity):
+        self.target_state = np.concatenate([f64(target_position), f64(target_velocity)], axis=-1).reshape(-1, 14)
+
+    def set_current_state(self, current_position, current_velocity):
+        self.current_state = np.concatenate([f64(current_position), f64(current_velocity)], axis=-1).reshape(-1, 14)
+
+    # motionPlanner.cpp:116-144
+    def check_state_in_bounds(self, position, velocity, acceleration=None):
+        position, velocity = f64(position), f64(velocity)
+        L = self.limits
+        s = (1 - self.margin_position_) * (L["qmax"] - L["qmin"]) / 2
+        pc = np.any(position > L["qmax"] - s, axis=-1) | np.any(position < L["qmin"] + s, axis=-1)
+        vc = np.any(np.abs(velocity) > self.margin_velocity_ * L["vmax"], axis=-1)
+        flag = np.where(pc & ~vc, 1, 0) + np.where(~pc & vc, 2, 0) + np.where(pc & vc, 3, 0)
+        if acceleration is not None:
+            flag = flag + 10 * np.any(np.abs(f64(acceleration)) > self.margin_acceleration_ * L["amax"], axis=-1)
+        return flag
+
+    # motionPlanner.hpp:145-172 (generic warm start from a regularly time-spaced trajectory [B, nPoint, 7])
+    def warm_start(self, final_time, position_trajectory, velocity_trajectory, acceleration_trajectory):
+        q, v, a = f64(position_trajectory), f64(velocity_trajectory), f64(acceleration_trajectory)
+        nP = q.shape[1]
+        idx = np.round(capi.time_nodes(self.cfg.num_seg) * (nP - 1)).astype(int)     # motionPlanner.hpp:157
+        self._warm = (np.concatenate([q[:, idx], v[:, idx]], axis=-1), a[:, idx], f64(final_time).reshape(-1))
+
+    # motionPlanner.cpp:177-208
+    def solve_trajectory(self, use_builtin_warm_start=True):
+        B = max(self.current_state.shape[0], self.target_state.shape[0])
+        x0 = np.broadcast_to(self.current_state, (B, 14)); xf = np.broadcast_to(self.target_state, (B, 14))
+        warm = None if use_builtin_warm_start else self._warm
+        sx, su, sT, info = self._solver.solve(x0, xf, warm)
+        self._sol = (sx, su, sT)
+        # re-guess with exact end states (motionPlanner.cpp:199-207)
+        gx = sx.copy(); gx[:, 0] = x0; gx[:, -1] = xf
+        self._warm = (gx, su.copy(), sT.copy())
+        self.info = info
+        return info
+
+    def solution(self):
+        return self._sol
+
+    # motionPlanner.hpp:99-116
+    def get_MPC_trajectory(self, n_pts=200):
+        out = self._solver.sample(*self._sol, n_pts=n_pts)
+        return out[..., 0], out[..., 1:8], out[..., 8:15], out[..., 15:22], out[..., 22:29]
