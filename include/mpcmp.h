@@ -143,6 +143,10 @@ int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sol_x, cons
  * last reset; launches = number of launches accumulated. */
 int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name, double *ms_total, int *launches);
 
+/* diagnostics: per-problem phase cycle stamps of the last k_qp launch, [B][16]; zeros unless the library was
+ * built with -DMPCMP_STAMPS (tools/stamps.py). */
+int mpcmp_debug_stamps(mpcmp_ctx *ctx, int B, unsigned long long *out);
+
 #ifdef __cplusplus
 }
 #endif

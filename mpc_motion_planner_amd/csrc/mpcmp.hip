@@ -353,7 +353,7 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
     TRY(dalloc(ctx, &w.z, B * n)); TRY(dalloc(ctx, &w.lam, B * mn)); TRY(dalloc(ctx, &w.ceq, B * ctx->meq));
     TRY(dalloc(ctx, &w.g, B * 8 * N)); TRY(dalloc(ctx, &w.Gk, B * N * 176)); TRY(dalloc(ctx, &w.p, B * n));
     TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.qp_total, B));
-    TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B));
+    TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, B * 16));
     TRY(dalloc(ctx, &ctx->d_x0, B * 14)); TRY(dalloc(ctx, &ctx->d_xf, B * 14));
     TRY(dalloc(ctx, &ctx->d_wx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_wu, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
     TRY(dalloc(ctx, &ctx->d_sx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_su, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_sT, B));
@@ -589,6 +589,15 @@ extern "C" int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sx, const
     if (int rc = mpcmp_sample_batch_device(ctx, B, dx, du, dT, n_pts, dout, st)) return rc;
     HIPCHK(ctx, hipMemcpyAsync(out, dout, sizeof(double) * np, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+// diagnostics: raw phase stamps of the last k_qp launch (all zero unless built with -DMPCMP_STAMPS)
+extern "C" int mpcmp_debug_stamps(mpcmp_ctx *ctx, int B, unsigned long long *out) {
+    if (!ctx || !out || B < 1 || B > ctx->max_batch) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out, ctx->ws.dbg, sizeof(unsigned long long) * 16 * B, hipMemcpyDeviceToHost));
     return MPCMP_OK;
 }
 

@@ -38,7 +38,14 @@ struct WS {
     int *qp_total;            // [B]
     int *status;              // [B]
     double *alpha;            // [B]
+    unsigned long long *dbg;  // [B][16] phase cycle stamps (diagnostic builds with -DMPCMP_STAMPS only)
 };
+
+#ifdef MPCMP_STAMPS
+#define STAMP(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
 
 template <int NW, int K, bool MAX>
 __device__ __forceinline__ void block_reduce(double (&v)[K], double *red, int tid) {
@@ -252,14 +259,16 @@ struct InitLds { static constexpr int size = Dim<NSEG>::n + LinLds<NSEG>::size; 
 template <int NSEG>
 struct QpLds {
     using D = Dim<NSEG>;
-    static constexpr bool GK_LDS = (NSEG <= 4);
+    static constexpr bool Z_LDS = (NSEG <= 4);
+    static constexpr int GS = 23;                      // padded row stride of the path Jacobians in LDS
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int oE = 0;                       // E_s = G_s K_JC,s        [NSEG][49][29]
     static constexpr int oS = oE + NSEG * D::JC;       // packed -(S^-1)
-    static constexpr int oU = oS + D::SP;
+    static constexpr int oGk = oS + D::SP;             // path Jacobians [N][8][GS]
+    static constexpr int oU = oGk + D::N * 8 * GS;
     // factorisation view of the union region
-    static constexpr int fKJJ = oU, fKJC = fKJJ + D::JP, fZ = fKJC + D::JC, fGk = fZ + D::n;
-    static constexpr int fEnd = fGk + (GK_LDS ? D::N * 176 : 0);
+    static constexpr int fKJJ = oU, fKJC = fKJJ + D::JP, fZ = fKJC + D::JC;
+    static constexpr int fEnd = fZ + (Z_LDS ? D::n : 0);
     // ADMM view
     static constexpr int aRhs = oU, aXt = aRhs + D::n, aXI = aXt + D::n, aRI = aXI + D::nI,
                          aPart = aRI + D::nI, aWg = aPart + NSEG * 29, aYs = aWg + D::m, aEnd = aYs + D::m;
@@ -282,16 +291,18 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
     const double T = zg_[n - 1];
     const double tsT = ts * T;
     int status = 0;
+#ifdef MPCMP_STAMPS
+    unsigned long long stamp_acc[16] = {0}, stamp_t = clock64();
+#endif
 
     // ---------------- per-thread static roles ----------------
     const bool isVar = tid < n, isRow = tid < m;
     // variable role
     double lb = 0, ub = 0, rb = rho_in, hd = 0, ha = 0, qv = 0, cf = 0;
-    double dA[3] = {0, 0, 0}, dB[3] = {0, 0, 0}, gkcol[8];
-    int rA = 0, rB = 0, rf = 0, pb = meq, ipos = 0;
+    double dA[3] = {0, 0, 0}, dB[3] = {0, 0, 0};
+    int rA = 0, rB = 0, rf = 0, pb = meq, ipos = 0, gcol = 0;
+    bool hasG = false;
     const bool isT = (tid == n - 1);
-#pragma unroll
-    for (int q = 0; q < 8; q++) gkcol[q] = 0.0;
     if (isVar) {
         const int v = tid;
         ipos = int_of_ext(NSEG, v);
@@ -321,14 +332,12 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
                 }
             }
             if (c >= 7 && k <= N - 2) { rf = 14 * k + (c - 7); cf = -tsT; ha = -ts * ws.lam[(size_t)b * D::mn + rf]; }
-#pragma unroll
-            for (int q = 0; q < 8; q++) gkcol[q] = Gkg[(k * 8 + q) * 22 + c];
+            gcol = k * 8 * L::GS + c; hasG = true;
         } else if (v < 21 * N) {
             const int k = (v - 14 * N) / 7, c = (v - 14 * N) % 7;
             pb = meq + 8 * k;
             if (k <= N - 2) { rf = 14 * k + 7 + c; cf = -tsT; ha = -ts * ws.lam[(size_t)b * D::mn + rf]; }
-#pragma unroll
-            for (int q = 0; q < 8; q++) gkcol[q] = Gkg[(k * 8 + q) * 22 + 14 + c];
+            gcol = k * 8 * L::GS + 14 + c; hasG = true;
         } else {
             qv = 1.0;   // cost gradient e_T (robot_ocp.hpp:201-213)
         }
@@ -340,11 +349,11 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
         if (isT) { hd = sv[0] + cfg.hess_reg; ha = 0.0; }
     }
     // row role
-    double rcoef[22], lg = 0, ug = 0, rr_ = rho_in, coefT = 0;
-    int ix0 = 0, ixf = 0, bx = 0, bu = 0;
+    double rcoef[6], lg = 0, ug = 0, rr_ = rho_in, coefT = 0;
+    int ix0 = 0, ixf = 0, bx = 0, bu = 0, grow_off = 0;
     const bool isDyn = tid < meq;
 #pragma unroll
-    for (int c = 0; c < 22; c++) rcoef[c] = 0.0;
+    for (int c = 0; c < 6; c++) rcoef[c] = 0.0;
     if (isRow) {
         const int r = tid;
         if (isDyn) {
@@ -362,25 +371,26 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
         } else {
             const int k = (r - meq) / 8, q = (r - meq) % 8;
             bx = 14 * k; bu = 14 * N + 7 * k;
-#pragma unroll
-            for (int c = 0; c < 22; c++) rcoef[c] = Gkg[(k * 8 + q) * 22 + c];
-            coefT = rcoef[21];
+            grow_off = (k * 8 + q) * L::GS;
+            coefT = Gkg[(k * 8 + q) * 22 + 21];
             const double gv = ws.g[(size_t)b * 8 * N + 8 * k + q];
             lg = cfg.lbg[q] - gv; ug = cfg.ubg[q] - gv;
             rr_ = (ug - lg < 1e-4) ? rho_eq : rho_in;
         }
     }
+    double *gkl = lds + L::oGk;
     auto row_dot = [&](const double *xe) -> double {
         double s;
         if (isDyn) {
             s = rcoef[0] * xe[ix0] + rcoef[1] * xe[ix0 + 14] + rcoef[2] * xe[ix0 + 28] + rcoef[3] * xe[ix0 + 42] +
                 rcoef[4] * xe[ixf] + rcoef[5] * xe[n - 1];
         } else {
-            s = rcoef[21] * xe[n - 1];
+            const double *gr = gkl + grow_off;
+            s = gr[21] * xe[n - 1];
 #pragma unroll
-            for (int c = 0; c < 14; c++) s += rcoef[c] * xe[bx + c];
+            for (int c = 0; c < 14; c++) s += gr[c] * xe[bx + c];
 #pragma unroll
-            for (int c = 0; c < 7; c++) s += rcoef[14 + c] * xe[bu + c];
+            for (int c = 0; c < 7; c++) s += gr[14 + c] * xe[bu + c];
         }
         return s;
     };
@@ -390,21 +400,25 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
         for (int i = 0; i < 3; i++) s += dA[i] * w[rA + 14 * i];
 #pragma unroll
         for (int i = 0; i < 3; i++) s += dB[i] * w[rB + 14 * i];
+        if (hasG) {
+            const double *gc = gkl + gcol;
 #pragma unroll
-        for (int q = 0; q < 8; q++) s += gkcol[q] * w[pb + q];
+            for (int q = 0; q < 8; q++) s += gc[q * L::GS] * w[pb + q];
+        }
         return s;
     };
 
+    STAMP(0);
     // ---------------- assembly + factorisation ----------------
     double *E = lds + L::oE, *S = lds + L::oS;
-    double *KJJ = lds + L::fKJJ, *KJC = lds + L::fKJC, *zl = lds + L::fZ;
-    const double *gk = Gkg;
-    if (L::GK_LDS) {
-        double *gkl = lds + L::fGk;
-        for (int i = tid; i < N * 176; i += NT) gkl[i] = Gkg[i];
-        gk = gkl;
+    double *KJJ = lds + L::fKJJ, *KJC = lds + L::fKJC;
+    for (int i = tid; i < N * 176; i += NT) gkl[(i / 22) * L::GS + (i % 22)] = Gkg[i];
+    const double *zl = zg_;
+    if (L::Z_LDS) {
+        double *zz = lds + L::fZ;
+        for (int v = tid; v < n; v += NT) zz[v] = zg_[v];
+        zl = zz;
     }
-    for (int v = tid; v < n; v += NT) zl[v] = zg_[v];
     __syncthreads();
     auto term_val = [&](uint32_t t) -> double {
         const int r = t >> 16, a = (t >> 8) & 255, c = t & 255;
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
             vb = c < 4 ? c_D[4 * i + c] : (c == 4 ? -tsT : cT);
             rho = rho_eq;
         } else {
-            const double *row = gk + (r - meq) * 22;
+            const double *row = gkl + (r - meq) * L::GS;
             va = row[a]; vb = row[c];
             rho = rho_in;
         }
@@ -501,7 +515,9 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
         }
         __syncthreads();
     }
+    STAMP(1);
     sweep(S, nI, D::SP);
+    STAMP(2);
 
     // ---------------- ADMM (OSQP form on [A; I], reduced KKT) ----------------
     double *rhs = lds + L::aRhs, *xt = lds + L::aXt, *xI = lds + L::aXI, *rI = lds + L::aRI, *part = lds + L::aPart,
@@ -521,12 +537,23 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
             rhs[ipos] = r;
         }
         __syncthreads();
+        STAMP(3);
         // P1: t = G_s b_Js ; partial = E_s^T b_Js
         double tloc = 0.0;
         if (tid < nJ) {
             const double *bj = rhs + 49 * my_s;
+            double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < 49; j++) tloc += grow[j] * bj[j];
+            for (int jc = 0; jc < 49; jc += 7) {
+                // chunks of 7 keep the LDS reads in flight without hoisting all 49 (VGPR pressure)
+                double bv[7];
+#pragma unroll
+                for (int j = 0; j < 7; j++) bv[j] = bj[jc + j];
+#pragma unroll
+                for (int j = 0; j < 7; j++) { if (j & 1) t1 += grow[jc + j] * bv[j]; else t0 += grow[jc + j] * bv[j]; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tloc = t0 + t1;
         } else if (tid < nJ + 29 * NSEG) {
             const int s = (tid - nJ) / 29, c = (tid - nJ) % 29;
             const double *bj = rhs + 49 * s, *Es = E + s * D::JC + c;
@@ -536,6 +563,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
             part[s * 29 + c] = acc;
         }
         __syncthreads();
+        STAMP(4);
         // P2a: r_I = b_I - sum_s E_s^T b_Js
         if (tid < nI) {
             const int a = tid;
@@ -551,6 +579,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
             rI[a] = r;
         }
         __syncthreads();
+        STAMP(5);
         // P2b: x_I = S^-1 r_I   (S holds -(S^-1); 4 lanes per row)
         if ((tid >> 2) < nI) {
             const int a = tid >> 2, pt = tid & 3;
@@ -561,6 +590,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
             if (pt == 0) { xI[a] = -acc; xt[ext_if] = -acc; }
         }
         __syncthreads();
+        STAMP(6);
         // P3: x_J = t - E_s x_C(s)
         if (tid < nJ) {
             const double *Er = E + (my_s * 49 + my_i) * 29, *xc = xI + 14 * my_s;
@@ -570,6 +600,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
             xt[ext_my] = acc;
         }
         __syncthreads();
+        STAMP(7);
         // E: z~ = A x~, relaxation, projection, dual update
         double tp = 0.0;
         if (isRow) {
@@ -629,6 +660,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
             const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);
             if (mx[0] <= ep && mx[3] <= ed) { done = 1; }
         }
+        STAMP(8);
         if (done) break;
     }
     if (it > cfg.qp_iters) it = cfg.qp_iters;
@@ -638,6 +670,9 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
         ws.y[(size_t)b * D::mn + m + tid] = yb;
     }
     if (isRow) ws.y[(size_t)b * D::mn + tid] = yg;
+#ifdef MPCMP_STAMPS
+    if (tid == 0) { for (int k = 0; k < 16; k++) ws.dbg[(size_t)b * 16 + k] = stamp_acc[k]; ws.dbg[(size_t)b * 16 + 15] = it; }
+#endif
     {
         int any = __syncthreads_or(status);
         if (tid == 0) {

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic: build the library with -DMPCMP_STAMPS and print where k_qp's cycles go (per ADMM iteration).
+Not part of the product path; stamps cost a few % (see MI355X_MICROARCH.md, s_memtime)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+so = os.path.join(ROOT, "gpurun_out", "libmpcmp_stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMPCMP_STAMPS",
+                       "-o", so, os.path.join(ROOT, "mpc_motion_planner_amd", "csrc", "mpcmp.hip")])
+import mpc_motion_planner_amd.capi as capi
+capi._SO = so
+import mpc_motion_planner_amd as M
+from mpc_motion_planner_amd import scenarios
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+nseg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+cfg = M.default_config(nseg, 1, margins=(0.9, 0.9, 0.5, 0.9))
+s = M.Solver(cfg, B)
+x0, xf = scenarios.make_batch(B)
+wx, wu, wT = s.warm_start(x0, xf)
+p, y, it = s.qp(x0, xf, wx, wu, wT)
+st = np.zeros((B, 16), dtype=np.uint64)
+capi.check(capi.lib().mpcmp_debug_stamps(s._ctx, B, st.ctypes.data_as(C.c_void_p)))
+st = st.astype(np.float64)
+its = st[:, 15]
+names = ["setup", "assemble+KJJ/E/S", "sweep S", "A(rhs)", "P1", "P2a", "P2b", "P3", "E"]
+print("B=%d nseg=%d  mean ADMM iterations %.1f" % (B, nseg, its.mean()))
+for k, nm in enumerate(names):
+    if k < 3:
+        print("%-18s %10.0f cycles (once)" % (nm, st[:, k].mean()))
+    else:
+        print("%-18s %10.1f cycles / iteration" % (nm, (st[:, k] / its).mean()))
+print("loop total %10.1f cycles / iteration" % ((st[:, 3:9].sum(axis=1) / its).mean()))
