@@ -1,0 +1,302 @@
+// mpcmp_motion_planner.hpp — header-only C++ mirror of the reference's planner façade over the mpcmp C ABI.
+//
+// Same class name, member names, argument meaning and error behaviour as `MotionPlanner`
+// (mpc_solver/motionPlanner.hpp:16-176, mpc_solver/motionPlanner.cpp) and the limits table of `PandaWrapper`
+// (robot_utils/pandaWrapper.hpp:28-40), so that examples/offline_trajectory.cpp / examples/benchmark.cpp keep
+// their call sequence; the solve runs on the GPU through libmpcmp.so.  Additions: `solve_batch` (B problems in
+// one call — what examples/benchmark.cpp:16 loops over) and the text writers of the two result formats.
+//
+// With Eigen on the include path the vector/matrix arguments are Eigen types exactly as in the reference;
+// without it (this image has no Eigen) a minimal column-major fixed-size matrix with the same element access
+// stands in.  Differences that cannot be hidden: Ruckig is replaced by the built-in initialiser
+// (get_ruckig_trajectory returns that initial guess), `mpc` (the polympc object) does not exist.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mpcmp.h"
+
+#if defined(MPCMP_USE_EIGEN) || (defined(__has_include) && __has_include(<Eigen/Dense>))
+#include <Eigen/Dense>
+namespace mpcmp_shim {
+template <int R, int C> using Mat = Eigen::Matrix<double, R, C>;
+}
+#else
+namespace mpcmp_shim {
+template <int R, int C>
+struct Mat {                                  // column-major like Eigen's default
+    std::array<double, (size_t)R * C> d{};
+    double &operator()(int i, int j) { return d[(size_t)j * R + i]; }
+    double operator()(int i, int j) const { return d[(size_t)j * R + i]; }
+    double &operator()(int i) { return d[i]; }
+    double operator()(int i) const { return d[i]; }
+    double &operator[](int i) { return d[i]; }
+    double operator[](int i) const { return d[i]; }
+    double *data() { return d.data(); }
+    const double *data() const { return d.data(); }
+    static Mat Zero() { return Mat(); }
+    static constexpr int rows() { return R; }
+    static constexpr int cols() { return C; }
+};
+}  // namespace mpcmp_shim
+#endif
+
+#define NDOF 7   // robot_utils/pandaWrapper.hpp:10
+
+// limits table + model of robot_utils/pandaWrapper.hpp (Pinocchio members replaced by mpcmp_model)
+class PandaWrapper {
+  public:
+    using Vec7 = mpcmp_shim::Mat<NDOF, 1>;
+    mpcmp_model model;
+    Vec7 min_position, max_position, max_velocity, max_acceleration, max_jerk, max_torque;
+    double max_torqueDot{1000};
+    double max_linear_velocity{1.7};
+    double max_angular_velocity{2.5};
+    double min_height{0.05};
+    explicit PandaWrapper(const std::string &urdf_path) {
+        const int rc = urdf_path.empty() ? mpcmp_default_model(&model) : mpcmp_model_from_urdf(urdf_path.c_str(), &model);
+        if (rc) throw std::runtime_error(std::string("PandaWrapper: ") + mpcmp_last_error(nullptr));
+        mpcmp_default_limits(min_position.data(), max_position.data(), max_velocity.data(), max_acceleration.data(),
+                             max_jerk.data(), max_torque.data());
+    }
+    // world position of the joint-7 origin (oMi[7]) and of the tool frame
+    void forward_kinematics(const double *q, double *p_joint7, double *p_tool) const {
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+        for (int i = 0; i < 7; i++) {
+            for (int r = 0; r < 3; r++) p[r] += R[3 * r] * model.p[i][0] + R[3 * r + 1] * model.p[i][1] + R[3 * r + 2] * model.p[i][2];
+            const double c = std::cos(q[i]), s = std::sin(q[i]);
+            double J[9], Rn[9];
+            for (int r = 0; r < 3; r++) {
+                J[3 * r] = model.R0[i][3 * r] * c + model.R0[i][3 * r + 1] * s;
+                J[3 * r + 1] = -model.R0[i][3 * r] * s + model.R0[i][3 * r + 1] * c;
+                J[3 * r + 2] = model.R0[i][3 * r + 2];
+            }
+            for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++)
+                Rn[3 * r + k] = R[3 * r] * J[k] + R[3 * r + 1] * J[3 + k] + R[3 * r + 2] * J[6 + k];
+            for (int k = 0; k < 9; k++) R[k] = Rn[k];
+        }
+        if (p_joint7) for (int r = 0; r < 3; r++) p_joint7[r] = p[r];
+        if (p_tool) for (int r = 0; r < 3; r++)
+            p_tool[r] = p[r] + R[3 * r] * model.tool[0] + R[3 * r + 1] * model.tool[1] + R[3 * r + 2] * model.tool[2];
+    }
+};
+
+class MotionPlanner {
+  public:
+    using Vec7 = mpcmp_shim::Mat<NDOF, 1>;
+    using Vec14 = mpcmp_shim::Mat<2 * NDOF, 1>;
+
+    PandaWrapper robot;
+    Vec14 current_state, target_state;
+    const double eps = 1e-2;                                            // motionPlanner.hpp:44
+    const double inf = std::numeric_limits<double>::infinity();
+    double margin_position_, margin_velocity_, margin_acceleration_, margin_torque_, margin_jerk_;
+    mpcmp_config config;                                                 // stands in for mpc.settings()/qp_settings()
+    mpcmp_info last_info{};
+
+    // num_seg / sqp_iters default to the reference as shipped (robot_ocp.hpp:32, motionPlanner.cpp:15)
+    explicit MotionPlanner(std::string urdf_path, int num_seg = 6, int sqp_iters = 2, int max_batch = 1024, int device = 0)
+        : robot(urdf_path), max_batch_(max_batch) {
+        mpcmp_default_config(&config, num_seg, sqp_iters);               // motionPlanner.cpp:15-20
+        N_ = mpcmp_num_nodes(num_seg);
+        const int rc = mpcmp_create(&config, &robot.model, device, max_batch, &ctx_);
+        if (rc) throw std::runtime_error(std::string("MotionPlanner: ") + mpcmp_last_error(nullptr));
+        Vec7 mid, zero = Vec7::Zero();
+        for (int j = 0; j < 7; j++) mid(j) = 0.5 * (robot.max_position(j) + robot.min_position(j));  // motionPlanner.cpp:5
+        set_target_state(mid, zero);
+        set_current_state(mid, zero);
+        set_constraint_margins(1.0, 1.0, 1.0, 1.0, 1.0);                 // motionPlanner.cpp:24
+        sol_x_.assign((size_t)14 * N_, 0.0); sol_u_.assign((size_t)7 * N_, 0.0);
+    }
+    ~MotionPlanner() { mpcmp_destroy(ctx_); }
+    MotionPlanner(const MotionPlanner &) = delete;
+    MotionPlanner &operator=(const MotionPlanner &) = delete;
+
+    void set_target_state(Vec7 target_position, Vec7 target_velocity, Vec7 = Vec7::Zero()) {     // motionPlanner.cpp:27-39
+        for (int j = 0; j < 7; j++) { target_state(j) = target_position(j); target_state(7 + j) = target_velocity(j); }
+    }
+    void set_current_state(Vec7 current_position, Vec7 current_velocity, Vec7 = Vec7::Zero()) {  // motionPlanner.cpp:41-54
+        for (int j = 0; j < 7; j++) { current_state(j) = current_position(j); current_state(7 + j) = current_velocity(j); }
+    }
+    void set_constraint_margins(double margin_position, double margin_velocity, double margin_acceleration,
+                                double margin_torque, double margin_jerk) {                          // motionPlanner.cpp:56-90
+        margin_position_ = margin_position; margin_velocity_ = margin_velocity; margin_acceleration_ = margin_acceleration;
+        margin_torque_ = margin_torque; margin_jerk_ = margin_jerk;
+        mpcmp_set_margins(&config, margin_position, margin_velocity, margin_acceleration, margin_torque);
+        mpcmp_set_min_height(&config, robot.min_height);
+        push_config();
+    }
+    void set_min_height(double min_height) { mpcmp_set_min_height(&config, min_height); push_config(); }  // :92-100
+
+    // motionPlanner.cpp:102-114 (Eigen::Random replaced by a SplitMix64 stream owned by the planner)
+    void sample_random_state(Vec7 &random_position, Vec7 &random_velocity) {
+        double p7[3];
+        do {
+            for (int j = 0; j < 7; j++) {
+                const double s = (1 - margin_position_) * (robot.max_position(j) - robot.min_position(j)) / 2;
+                random_position(j) = 0.5 * (uniform() * (robot.max_position(j) - robot.min_position(j) - 2 * s) +
+                                            (robot.max_position(j) + robot.min_position(j)));
+            }
+            robot.forward_kinematics(random_position.data(), p7, nullptr);
+        } while (p7[2] < robot.min_height);
+        for (int j = 0; j < 7; j++) random_velocity(j) = margin_velocity_ * uniform() * robot.max_velocity(j);
+    }
+    void seed(uint64_t s) { rng_ = s; }
+
+    // motionPlanner.cpp:116-144
+    int check_state_in_bounds(Vec7 &position, Vec7 &velocity, Vec7 acceleration = Vec7::Zero()) {
+        bool pc = false, vc = false, ac = false;
+        for (int j = 0; j < 7; j++) {
+            const double s = (1 - margin_position_) * (robot.max_position(j) - robot.min_position(j)) / 2;
+            pc |= position(j) > robot.max_position(j) - s || position(j) < robot.min_position(j) + s;
+            vc |= std::fabs(velocity(j)) > margin_velocity_ * robot.max_velocity(j);
+            ac |= std::fabs(acceleration(j)) > margin_acceleration_ * robot.max_acceleration(j);
+        }
+        int flag = 0;
+        if (pc && !vc) flag = 1;
+        if (!pc && vc) flag = 2;
+        if (pc && vc) flag = 3;
+        if (ac) flag += 10;
+        return flag;
+    }
+
+    // motionPlanner.hpp:145-172: regularly time-spaced trajectory, nearest-sample pick round(t*(nPoint-1))
+    void warm_start(double final_time, const std::vector<double> &position_trajectory /*7 x nPoint col-major*/,
+                    const std::vector<double> &velocity_trajectory, const std::vector<double> &acceleration_trajectory) {
+        const int nPoint = (int)(position_trajectory.size() / 7);
+        std::vector<double> tau(N_);
+        mpcmp_time_nodes(config.num_seg, tau.data());
+        warm_x_.assign((size_t)14 * N_, 0.0); warm_u_.assign((size_t)7 * N_, 0.0);
+        for (int i = 0; i < N_; i++) {
+            const int idx = (int)std::lround(tau[i] * (nPoint - 1));
+            for (int j = 0; j < 7; j++) {
+                warm_x_[14 * i + j] = position_trajectory[7 * idx + j];
+                warm_x_[14 * i + 7 + j] = velocity_trajectory[7 * idx + j];
+                warm_u_[7 * i + j] = acceleration_trajectory[7 * idx + j];
+            }
+        }
+        warm_T_ = final_time; have_warm_ = true;
+    }
+
+    // motionPlanner.cpp:177-208.  true: built-in initialiser (stand-in for Ruckig); false: previous solution /
+    // warm_start() guess
+    void solve_trajectory(bool use_ruckig_as_warm_start) {
+        const bool use_guess = !use_ruckig_as_warm_start && have_warm_;
+        if (!use_guess) {
+            guess_x_.assign((size_t)14 * N_, 0.0); guess_u_.assign((size_t)7 * N_, 0.0);
+            chk(mpcmp_warm_start_batch(ctx_, 1, current_state.data(), target_state.data(), guess_x_.data(), guess_u_.data(), &guess_T_));
+        } else { guess_x_ = warm_x_; guess_u_ = warm_u_; guess_T_ = warm_T_; }
+        chk(mpcmp_solve_batch(ctx_, 1, current_state.data(), target_state.data(), guess_x_.data(), guess_u_.data(), &guess_T_,
+                              sol_x_.data(), sol_u_.data(), &sol_T_, &last_info));
+        // "Fix initial and final point at correct place" (motionPlanner.cpp:199-207)
+        warm_x_ = sol_x_; warm_u_ = sol_u_; warm_T_ = sol_T_; have_warm_ = true;
+        for (int r = 0; r < 14; r++) { warm_x_[r] = current_state(r); warm_x_[(size_t)14 * (N_ - 1) + r] = target_state(r); }
+    }
+
+    // B independent problems in one call (the loop of examples/benchmark.cpp:16). x0/xf: [B][14]
+    void solve_batch(int B, const double *x0, const double *xf, double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info) {
+        chk(mpcmp_solve_batch(ctx_, B, x0, xf, nullptr, nullptr, nullptr, sol_x, sol_u, sol_T, info));
+    }
+
+    // motionPlanner.hpp:99-116
+    template <const int NP>
+    void get_MPC_trajectory(mpcmp_shim::Mat<1, NP + 1> &time, mpcmp_shim::Mat<7, NP + 1> &position_trajectory,
+                            mpcmp_shim::Mat<7, NP + 1> &velocity_trajectory, mpcmp_shim::Mat<7, NP + 1> &acceleration_trajectory,
+                            mpcmp_shim::Mat<7, NP + 1> &torque_trajectory) {
+        std::vector<double> out((size_t)(NP + 1) * 29);
+        chk(mpcmp_sample_batch(ctx_, 1, sol_x_.data(), sol_u_.data(), &sol_T_, NP, out.data()));
+        unpack<NP>(out, time, position_trajectory, velocity_trajectory, acceleration_trajectory, torque_trajectory);
+    }
+    // motionPlanner.hpp:73-96 — the initial guess handed to the solver, resampled like the Ruckig trajectory
+    template <const int NP>
+    void get_ruckig_trajectory(mpcmp_shim::Mat<1, NP + 1> &time, mpcmp_shim::Mat<7, NP + 1> &position_trajectory,
+                               mpcmp_shim::Mat<7, NP + 1> &velocity_trajectory, mpcmp_shim::Mat<7, NP + 1> &acceleration_trajectory,
+                               mpcmp_shim::Mat<7, NP + 1> &torque_trajectory) {
+        std::vector<double> out((size_t)(NP + 1) * 29);
+        chk(mpcmp_sample_batch(ctx_, 1, guess_x_.data(), guess_u_.data(), &guess_T_, NP, out.data()));
+        unpack<NP>(out, time, position_trajectory, velocity_trajectory, acceleration_trajectory, torque_trajectory);
+    }
+    // motionPlanner.hpp:118-128, including its clamp: for time >= T the normalised time is set to T (not 1)
+    void get_MPC_point(double time, Vec7 &position, Vec7 &velocity, Vec7 &acceleration, Vec7 &torque) {
+        if (time < sol_T_) time /= sol_T_;
+        else time = sol_T_;
+        interpolate(time, position, velocity, acceleration);
+        chk(mpcmp_rnea_batch(ctx_, 1, position.data(), velocity.data(), acceleration.data(), torque.data()));
+    }
+    double solution_T() const { return sol_T_; }
+    const std::vector<double> &solution_x() const { return sol_x_; }
+    const std::vector<double> &solution_u() const { return sol_u_; }
+    int num_nodes() const { return N_; }
+    mpcmp_ctx *context() { return ctx_; }
+
+    // analysis/optimal_solution.txt: row 0 target, rows 1..NP+1 initial guess ("Ruckig"), then MPC; 29 columns
+    // (examples/offline_trajectory.cpp:69-105)
+    template <const int NP>
+    void write_optimal_solution(const std::string &path) {
+        mpcmp_shim::Mat<1, NP + 1> t; mpcmp_shim::Mat<7, NP + 1> q, v, a, tau;
+        FILE *f = std::fopen(path.c_str(), "w");
+        if (!f) throw std::runtime_error("cannot open " + path);
+        std::fprintf(f, "0");
+        for (int j = 0; j < 14; j++) std::fprintf(f, " %.6g", target_state(j));
+        for (int j = 0; j < 14; j++) std::fprintf(f, " 0");
+        std::fprintf(f, "\n");
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 0) get_ruckig_trajectory<NP>(t, q, v, a, tau); else get_MPC_trajectory<NP>(t, q, v, a, tau);
+            for (int i = 0; i <= NP; i++) {
+                std::fprintf(f, "%.6g", t(0, i));
+                for (int j = 0; j < 7; j++) std::fprintf(f, " %.6g", q(j, i));
+                for (int j = 0; j < 7; j++) std::fprintf(f, " %.6g", v(j, i));
+                for (int j = 0; j < 7; j++) std::fprintf(f, " %.6g", a(j, i));
+                for (int j = 0; j < 7; j++) std::fprintf(f, " %.6g", tau(j, i));
+                std::fprintf(f, "\n");
+            }
+        }
+        std::fclose(f);
+    }
+
+  private:
+    mpcmp_ctx *ctx_ = nullptr;
+    int N_ = 0, max_batch_ = 0;
+    std::vector<double> sol_x_, sol_u_, warm_x_, warm_u_, guess_x_, guess_u_;
+    double sol_T_ = 0, warm_T_ = 0, guess_T_ = 0;
+    bool have_warm_ = false;
+    uint64_t rng_ = 20240001ull;
+
+    void chk(int rc) { if (rc) throw std::runtime_error(std::string("mpcmp: ") + mpcmp_last_error(ctx_)); }
+    void push_config() { if (ctx_) chk(mpcmp_set_config(ctx_, &config)); }
+    double uniform() {   // [-1,1), SplitMix64
+        uint64_t z = (rng_ += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    }
+    void interpolate(double t, Vec7 &q, Vec7 &v, Vec7 &a) const {   // mpc.solution_x_at / solution_u_at
+        static const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+        const int ns = config.num_seg;
+        int s = (int)std::floor(t * ns); if (s >= ns) s = ns - 1; if (s < 0) s = 0;
+        const double x = 2.0 * (t * ns - s) - 1.0;
+        double L[4];
+        for (int j = 0; j < 4; j++) { double w = 1; for (int k = 0; k < 4; k++) if (k != j) w *= (x - xi[k]) / (xi[j] - xi[k]); L[j] = w; }
+        for (int r = 0; r < 7; r++) {
+            q(r) = v(r) = a(r) = 0;
+            for (int j = 0; j < 4; j++) {
+                q(r) += L[j] * sol_x_[(size_t)14 * (3 * s + j) + r]; v(r) += L[j] * sol_x_[(size_t)14 * (3 * s + j) + 7 + r];
+                a(r) += L[j] * sol_u_[(size_t)7 * (3 * s + j) + r];
+            }
+        }
+    }
+    template <const int NP>
+    static void unpack(const std::vector<double> &out, mpcmp_shim::Mat<1, NP + 1> &time, mpcmp_shim::Mat<7, NP + 1> &q,
+                       mpcmp_shim::Mat<7, NP + 1> &v, mpcmp_shim::Mat<7, NP + 1> &a, mpcmp_shim::Mat<7, NP + 1> &tau) {
+        for (int i = 0; i <= NP; i++) {
+            const double *o = out.data() + (size_t)i * 29;
+            time(0, i) = o[0];
+            for (int j = 0; j < 7; j++) { q(j, i) = o[1 + j]; v(j, i) = o[8 + j]; a(j, i) = o[15 + j]; tau(j, i) = o[22 + j]; }
+        }
+    }
+};

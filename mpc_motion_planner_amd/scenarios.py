@@ -53,6 +53,9 @@ def sample_states(B, margins, seed=SEED, stream_offset=0, min_height=0.05, model
     base = (int(seed) * 0x100000001B3 + int(salt)) & _M64
     with np.errstate(over="ignore"):
         state = np.uint64(base) + np.arange(stream_offset, stream_offset + B, dtype=np.uint64) * np.uint64(2)
+    # velocity first, so that a stream's draws never depend on how many rejection rounds OTHER streams need
+    state, u = _uniform(state, 7)
+    v = mv * u * L["vmax"]                                                                # motionPlanner.cpp:113
     q = np.zeros((B, 7)); todo = np.ones(B, dtype=bool)
     for _ in range(200):
         state, u = _uniform(state, 7)
@@ -61,8 +64,6 @@ def sample_states(B, margins, seed=SEED, stream_offset=0, min_height=0.05, model
         todo = joint7_height(model, q) < min_height                                       # motionPlanner.cpp:111
         if not todo.any():
             break
-    state, u = _uniform(state, 7)
-    v = mv * u * L["vmax"]                                                                # motionPlanner.cpp:113
     return np.concatenate([q, v], axis=1)
 
 
