@@ -57,7 +57,7 @@ def library_path():
 def build_library(force=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "rbd_device.hpp", "structure.hpp")]
+    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "qp_kernel_v2.hpp", "rbd_device.hpp", "structure.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "mpcmp.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         subprocess.check_call(["make", "-C", src, "-B"], stdout=subprocess.DEVNULL)

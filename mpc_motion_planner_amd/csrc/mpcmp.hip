@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -13,6 +14,7 @@
 
 #include "../../include/mpcmp.h"
 #include "solver_kernels.hpp"
+#include "qp_kernel_v2.hpp"
 
 using namespace mpcmp;
 
@@ -399,14 +401,20 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     const size_t l_init = InitLds<NSEG>::size * sizeof(double), l_qp = QpLds<NSEG>::size * sizeof(double),
                  l_step = StepLds<NSEG>::size * sizeof(double);
     if (int rc = set_lds(ctx, k_init<NSEG>, l_init)) return rc;
-    if (int rc = set_lds(ctx, k_qp<NSEG>, l_qp)) return rc;
+    static const bool force_v1 = std::getenv("MPCMP_FORCE_V1") != nullptr;   // diagnostics: generic kernel everywhere
+    constexpr bool V2C = (NSEG == 2 || NSEG == 4);      // role-specialised 1024-thread QP kernel
+    const bool V2 = V2C && !force_v1;
+    const size_t l_qp2 = Qp2<V2C ? NSEG : 4>::size * sizeof(double);
+    if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
+    else if (int rc = set_lds(ctx, k_qp<NSEG>, l_qp)) return rc;
     if (int rc = set_lds(ctx, k_step<NSEG>, l_step)) return rc;
     hipLaunchKernelGGL(k_init<NSEG>, dim3(B), dim3(D::NT), l_init, st, ctx->cfg, w, d_wx, d_wu, d_wT);
     const int iters = only_qp ? 1 : ctx->cfg.sqp_iters;
     for (int it = 0; it < iters; it++) {
         hipEvent_t *ev = ctx->timing ? next_events(ctx) : nullptr;
         if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(k_qp<NSEG>, dim3(B), dim3(D::NT), l_qp, st, ctx->cfg, w);
+        if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(B), dim3(1024), l_qp2, st, ctx->cfg, w);
+        else hipLaunchKernelGGL(k_qp<NSEG>, dim3(B), dim3(D::NT), l_qp, st, ctx->cfg, w);
         if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
         if (only_qp) break;
         hipLaunchKernelGGL(k_step<NSEG>, dim3(B), dim3(D::NT), l_step, st, ctx->cfg, w, it == iters - 1 ? 1 : 0, it,
@@ -610,7 +618,7 @@ extern "C" int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name,
         if (hipEventElapsedTime(&ms, ctx->ev[i].first, ctx->ev[i].second) == hipSuccess) { ctx->qp_ms += ms; ctx->qp_launches++; }
     }
     ctx->ev_used = 0;
-    if (name) *name = "k_qp";
+    if (name) *name = (ctx->nseg == 2 || ctx->nseg == 4) ? "k_qp2" : "k_qp";
     if (ms_total) *ms_total = ctx->qp_ms;
     if (launches) *launches = ctx->qp_launches;
     if (reset) { ctx->qp_ms = 0.0; ctx->qp_launches = 0; }
