@@ -7,8 +7,8 @@
 //     over the 1024 threads); LDS carries only the exchanged vectors and the (padded) path Jacobians;
 //   * each thread owns a 2-row x k-column register block, so one LDS operand read feeds two FMAs; the
 //     k-way partial sums are combined with DPP (quad_perm / row_half_mirror), not through LDS;
-//   * waves are role-specialised (group A = segment quads for the interior solves + path rows, group B =
-//     interface solve, dynamics rows, variables), 5 workgroup barriers per ADMM iteration.
+//   * waves are role-specialised (group A = segment quads for the interior solves + all general rows, group B =
+//     interface solve + variables), 5 workgroup barriers per ADMM iteration.
 // Factorisation: segment blocks are processed two at a time in LDS (symmetric sweep), then loaded by their
 // owner threads, so the LDS footprint stays at ~125 KB.
 #pragma once
@@ -32,46 +32,95 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
+template <bool MAX>
+__device__ __forceinline__ double red_op(double a, double b) { return MAX ? fmax(a, b) : a + b; }
+template <bool MAX>
+__device__ __forceinline__ double reduce16(double x) {      // all 16 lanes of a DPP row end up with the result
+    x = red_op<MAX>(x, dpp_mov<0xB1>(x)); x = red_op<MAX>(x, dpp_mov<0x4E>(x));
+    x = red_op<MAX>(x, dpp_mov<0x141>(x)); x = red_op<MAX>(x, dpp_mov<0x140>(x));
+    return x;
+}
+// Workgroup reduction of K <= 8 values for 16 waves with a small register footprint: per-wave DPP reduction,
+// one LDS slot per (wave, k), then wave 0 combines the 16 partials of each k inside one DPP row. 3 barriers.
+// red: >= 16*K + K doubles.
+template <int K, bool MAX>
+__device__ __forceinline__ void block_reduce16(double (&v)[K], double *red, int tid) {
+    static_assert(K <= 8, "K");
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double x = reduce16<MAX>(v[k]);
+        x = red_op<MAX>(x, __shfl_xor(x, 16));
+        x = red_op<MAX>(x, __shfl_xor(x, 32));
+        if ((tid & 63) == 0) red[(tid >> 6) * K + k] = x;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int w = tid & 15, k0 = tid >> 4;
+        double a = (k0 < K) ? red[w * K + k0] : 0.0;
+        double b = (k0 + 4 < K) ? red[w * K + k0 + 4] : 0.0;
+        a = reduce16<MAX>(a); b = reduce16<MAX>(b);
+        if (w == 0) {
+            if (k0 < K) red[16 * K + k0] = a;
+            if (k0 + 4 < K) red[16 * K + k0 + 4] = b;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = red[16 * K + k];
+    __syncthreads();
+}
+
 template <int NSEG>
 struct Qp2 {
     using D = Dim<NSEG>;
     static constexpr int NT = 1024, NW = 16;
-    static constexpr int QPS = 40;                 // quads per segment: 25 G row-pairs + 15 E^T row-pairs
-    static constexpr int NA = 4 * QPS * NSEG;      // group A threads (640 at NSEG=4)
-    static constexpr int NB = NT - NA;             // group B threads
-    static constexpr int NPR = (D::nI + 1) / 2;    // interface row pairs (39)
-    static constexpr int GS = 23;                  // padded row stride of the path Jacobians in LDS
-    static constexpr int XS = 24;                  // node-major x~ stride: [x_k(14) u_k(7) T pad pad]
-    static constexpr int HS = 2;                   // segments factorised concurrently
-    static_assert(NA % 64 == 0 && 8 * NPR <= NB && D::m - D::meq <= 8 * D::N && D::n <= NB && D::meq <= NB, "mapping");
-    static_assert(8 * D::N <= 60 * NSEG, "path-row lanes must fit the E^T quads");
+    static constexpr int NGQ = 25 * NSEG, NEQ = 15 * NSEG;          // G row-pair quads, E^T row-pair quads
+    static constexpr int NA1 = (4 * NGQ + 63) / 64 * 64;           // role A1 threads (448 at NSEG=4)
+    static constexpr int NA2 = (4 * NEQ + 63) / 64 * 64;           // role A2 threads (256)
+    static constexpr int NB = NT - NA1 - NA2;                      // role B threads  (320)
+    static constexpr int NPR = (D::nI + 1) / 2;                    // interface row pairs (39)
+    static constexpr int GS = 23;                                  // padded row stride of the path Jacobians in LDS
+    static constexpr int XS = 24;                                  // node-major x~ stride: [x_k(14) u_k(7) T pad pad]
+    static constexpr int HS = 2;                                   // segments factorised concurrently
+    static constexpr int FAC = NSEG * (D::JP + D::JC);             // per-problem factor scratch in HBM (doubles)
+    static_assert(8 * NPR <= NB && D::n <= NB, "role B mapping");
+    static_assert(8 * D::N <= 4 * NEQ && D::meq <= 4 * NEQ, "row lanes must fit the E^T quads");
     // LDS (doubles)
     static constexpr int oGk = 0;                              // [N][8][GS]
     static constexpr int oRhsJ = oGk + D::N * 8 * GS;          // [NSEG][56]   rhs, interior part (zero padded)
     static constexpr int oRhsI = oRhsJ + NSEG * 56;            // [80]         rhs, interface part
-    static constexpr int oPart = oRhsI + 80;                   // [NSEG][32]   E_s^T b_Js
+    static constexpr int oPart = oRhsI + 2 * ((D::nI + 2) / 2);// [NSEG][32]   E_s^T b_Js
     static constexpr int oXC = oPart + NSEG * 32;              // [NSEG][32]   x_I restricted to C_s
     static constexpr int oXn = oXC + NSEG * 32;                // [N][XS]      x~ node-major
     static constexpr int oXx = oXn + D::N * XS;                // [N][XS]      x  node-major (termination tests)
     static constexpr int oWg = oXx + D::N * XS;                // [m]          w = rho z - y   (general rows)
     static constexpr int oYs = oWg + D::m;                     // [m]          y (termination tests)
     static constexpr int oTp = oYs + D::m;                     // [m]          coefT_r * w_r
-    static constexpr int oMisc = oTp + D::m;                   // [8]          0: zero slot, 1: T-variable base
+    static constexpr int oMisc = oTp + D::m;                   // [8]  0: zero slot, 1: T base, 2: T column sum, 3: sum|ha|
     static constexpr int oRed = oMisc + 8;                     // [NW*8]
-    static constexpr int oS = oRed + NW * 8;                   // packed S (factorisation)
+    static constexpr int oS = oRed + NW * 8;                   // packed S (factorisation), then -(S^-1)
     static constexpr int oKJJ = oS + D::SP;                    // [HS][JP]
     static constexpr int oKJC = oKJJ + HS * D::JP;             // [HS][JC]
     static constexpr int oEh = oKJC + HS * D::JC;              // [HS][JC]
     static constexpr int oZ = oEh + HS * D::JC;                // [n]
-    static constexpr int size = oZ + D::n;
+    // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
+    static constexpr int oE3 = oS;                             // [16][4*NGQ] E_s blocks of role A1 (lane-transposed)
+    static constexpr int oRc = oE3 + 16 * 4 * NGQ;             // [6][NA2]   dynamics-row coefficients
+    static constexpr int oPc = oRc + 6 * NA2;                  // [4][NA2]   path-row lg, ug, rho, coefT
+    static constexpr int oVc = oPc + 4 * NA2;                  // [10][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv
+    static constexpr int oS2 = oVc + 10 * NB;                  // [10][NB]   second row of each S^-1 block (role B)
+    static constexpr int oEndA = oS2 + 10 * NB;
+    static_assert(oEndA * 8 <= 160 * 1024 && (oZ + D::n) * 8 <= 160 * 1024, "LDS budget");
+    static constexpr int size = (oZ + D::n > oEndA) ? oZ + D::n : oEndA;
 };
 
-// shared context of the two role groups
+// shared context of the role groups
 template <int NSEG>
 struct Qp2Ctx {
     const mpcmp_config *cfg;
     WS ws;
     double *lds;
+    const double *fac;      // this problem's factor scratch: per segment [-G packed (JP) | E (49x29)]
     int tid, b;
     double ts, tsT, rho_in, rho_eq, sigma, alpha;
 };
@@ -82,57 +131,71 @@ struct Qp2Ctx {
 #define STAMP2(slot) do { } while (0)
 #endif
 
-// ---- group A: segment quads — interior solves (P1, P3) and path rows ------------------------------------
+// termination test shared by all roles (every thread contributes its maxima; result is workgroup-uniform)
 template <int NSEG>
-__device__ __forceinline__ void qp2_group_a(const Qp2Ctx<NSEG> &c, const double (&m1)[2][14], const double (&e3)[2][8],
-                                            unsigned long long *stamp_acc_out) {
+__device__ __forceinline__ int qp2_converged(const mpcmp_config &cfg, double (&mx)[6], double *red, int tid) {
+    block_reduce16<6, true>(mx, red, tid);
+    const double ep = cfg.eps_abs + cfg.eps_rel * fmax(mx[1], mx[2]);
+    const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);
+    return (mx[0] <= ep && mx[3] <= ed) ? 1 : 0;
+}
+
+// ---- role A1: G row-pair quads — t = G_s b_J (P1) and x_J = t - E_s x_C (P3); wave 0 also sums the T column ----
+template <int NSEG>
+__device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     using D = Dim<NSEG>;
     using L = Qp2<NSEG>;
-    constexpr int N = D::N, n = D::n, meq = D::meq, m = D::m, GS = L::GS, XS = L::XS;
+    constexpr int N = D::N, m = D::m, XS = L::XS;
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
-    const int tid = c.tid, b = c.b;
-    double *red = lds + L::oRed, *gkl = lds + L::oGk;
-    double *rhsJ = lds + L::oRhsJ, *partl = lds + L::oPart, *xC = lds + L::oXC, *xn = lds + L::oXn, *xx = lds + L::oXx,
-           *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *misc = lds + L::oMisc;
+    const int tid = c.tid;
+    double *red = lds + L::oRed;
+    double *rhsJ = lds + L::oRhsJ, *xC = lds + L::oXC, *xn = lds + L::oXn, *tpl = lds + L::oTp, *misc = lds + L::oMisc;
 #ifdef MPCMP_STAMPS
     unsigned long long stamp_acc[16] = {0}, stamp_t = clock64();
 #endif
-    const int Q = tid >> 2, part = tid & 3, seg = Q / L::QPS, lp = Q % L::QPS;
-    const bool isG = lp < 25;
-    const int et = (seg * 15 + (lp - 25)) * 4 + part;
-    const bool isPath = !isG && et < 8 * N;
-    const int pk = et >> 3, prp = (et & 7) >> 1, phalf = et & 1;
-    // path row owned by this lane (ADMM state), and the 2x11 coefficient block it helps to evaluate
-    double lg = 0, ug = 0, rr_ = c.rho_in, coefT = 0, zg = 0, yg = 0;
-    int myrow = 0;
-    if (isPath) {
-        const int q = 2 * prp + phalf;
-        myrow = meq + 8 * pk + q;
-        coefT = c.ws.Gk[((size_t)b * N + pk) * 176 + q * 22 + 21];
-        const double gv = c.ws.g[(size_t)b * 8 * N + 8 * pk + q];
-        lg = cfg.lbg[q] - gv; ug = cfg.ubg[q] - gv;
-        rr_ = (ug - lg < 1e-4) ? c.rho_eq : c.rho_in;
+    const int Q = tid >> 2, part = tid & 3;
+    const bool act = Q < L::NGQ;
+    const int seg = act ? Q / 25 : 0, lp = act ? Q % 25 : 0;
+    // rows (2lp, 2lp+1) of G_s x columns part*14..+13 in registers; of E_s x columns part*8..+7 in LDS
+    // (lane-transposed: element q of lane t at e3l[q*NA1 + t], conflict-free)
+    double m1[2][14];
+    constexpr int E3S = 4 * L::NGQ;
+    double *e3l = lds + L::oE3 + (act ? tid : 0);
+    {
+        const double *Gn = c.fac + seg * (D::JP + D::JC), *Es = Gn + D::JP;
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int row = 2 * lp + a;
+#pragma unroll
+            for (int j = 0; j < 14; j++) {
+                const int col = part * 14 + j;
+                m1[a][j] = (act && row < 49 && col < 49) ? -Gn[packed(row, col)] : 0.0;
+                if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);     // one-time loads: keep address temporaries few
+            }
+        }
+        __syncthreads();      // every owner has picked up its blocks from the staging area (S is read by role B)
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int row = 2 * lp + a;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int col = part * 8 + j;
+                if (act) e3l[(a * 8 + j) * E3S] = (row < 49 && col < 29) ? Es[row * 29 + col] : 0.0;
+            }
+        }
+        __syncthreads();      // LDS-resident constants published
     }
-    const int groff = isPath ? (pk * 8 + 2 * prp) * GS + phalf * 11 : 0;
-    const int xnoff = isPath ? pk * XS + phalf * 11 : 0;
-    int jdst = -1;      // G quads: where row 2lp+part of x_J goes in the node-major x~
-    if (isG && part < 2 && 2 * lp + part < 49) {
+    int jdst = -1;      // where row 2lp+part of x_J goes in the node-major x~
+    if (act && part < 2 && 2 * lp + part < 49) {
         const int v = c.ws.ext_of_int[49 * seg + 2 * lp + part];
         jdst = v < 14 * N ? (v / 14) * XS + v % 14 : ((v - 14 * N) / 7) * XS + 14 + (v - 14 * N) % 7;
     }
-    auto row_dot_path = [&](const double *xe) -> double {
-        const double *g0 = gkl + groff, *g1 = g0 + GS, *xv = xe + xnoff;
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 11; cc++) { const double xc = xv[cc]; a0 += g0[cc] * xc; a1 += g1[cc] * xc; }
-        a0 = sum2(a0); a1 = sum2(a1);
-        return phalf ? a1 : a0;
-    };
-    const double alpha = c.alpha;
+    const double *bj = rhsJ + 56 * seg + 14 * part;
+    const double *xc = xC + 32 * seg + 8 * part;
     int it = 0, done = 0;
     for (it = 1; it <= cfg.qp_iters; it++) {
-        // ---- A (group A part): wave 0 sums the T column of A^T w ----
+        // ---- A: wave 0 sums the T column of A^T w ----
         if (tid < 64) {
             double sacc = 0.0;
             for (int r = tid; r < m; r += 64) sacc += tpl[r];
@@ -141,76 +204,203 @@ __device__ __forceinline__ void qp2_group_a(const Qp2Ctx<NSEG> &c, const double 
         }
         __syncthreads();
         STAMP2(3);
-        // ---- P1: [t ; E^T b] = [G ; E^T] b_J ----
+        // ---- P1 ----
         double t0, t1;
         {
-            const double *bj = rhsJ + 56 * seg + 14 * part;
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < 14; j++) { const double bv = bj[j]; a0 += m1[0][j] * bv; a1 += m1[1][j] * bv; }
-            t0 = sum4(a0); t1 = sum4(a1);
-            if (!isG && part < 2) {
-                const int cc = 2 * (lp - 25) + part;
-                if (cc < 29) partl[seg * 32 + cc] = part ? t1 : t0;
+            for (int jc = 0; jc < 14; jc += 7) {          // two chunks: bounds the LDS reads in flight (VGPR pressure)
+#pragma unroll
+                for (int j = jc; j < jc + 7; j++) { const double bv = bj[j]; a0 += m1[0][j] * bv; a1 += m1[1][j] * bv; }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            t0 = sum4(a0); t1 = sum4(a1);
         }
         __syncthreads();
         STAMP2(4);
-        // ---- P2: (group B) ----
+        // ---- P2 (role B) ----
         __syncthreads();
         STAMP2(5);
-        // ---- P3: x_J = t - E_s x_C(s) ----
-        if (isG) {
-            const double *xc = xC + 32 * seg + 8 * part;
+        // ---- P3 ----
+        {
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) { const double xv = xc[j]; a0 += e3[0][j] * xv; a1 += e3[1][j] * xv; }
+            for (int jc = 0; jc < 8; jc += 4) {
+#pragma unroll
+                for (int j = jc; j < jc + 4; j++) { const double xv = xc[j]; a0 += e3l[j * E3S] * xv; a1 += e3l[(8 + j) * E3S] * xv; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             a0 = sum4(a0); a1 = sum4(a1);
             if (jdst >= 0) xn[jdst] = part ? (t1 - a1) : (t0 - a0);
         }
         __syncthreads();
         STAMP2(6);
-        // ---- E: path rows ----
-        const bool check = (it % cfg.check_every == 0);
-        if (isPath) {
-            const double zt = row_dot_path(xn);
-            const double zr = alpha * zt + (1.0 - alpha) * zg;
-            const double zn = clip(zr + yg / rr_, lg, ug);
-            yg += rr_ * (zr - zn);
-            zg = zn;
-            const double w = rr_ * zg - yg;
-            wg[myrow] = w;
-            tpl[myrow] = coefT * w;
-            if (check) ys[myrow] = yg;
-        }
+        // ---- E (roles A2, B) ----
         __syncthreads();
         STAMP2(7);
-        if (check) {
-            double sums[2] = {isPath ? coefT * yg : 0.0, 0.0};
-            block_reduce<L::NW, 2, false>(sums, red, tid);
+        if (it % cfg.check_every == 0) {
+            double sums[2] = {0.0, 0.0};
+            block_reduce16<2, false>(sums, red, tid);
             double mx[6] = {0, 0, 0, 0, 0, 0};
-            if (isPath) {
-                const double ax = row_dot_path(xx);
-                mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg);
-            }
-            block_reduce<L::NW, 6, true>(mx, red, tid);
-            const double ep = cfg.eps_abs + cfg.eps_rel * fmax(mx[1], mx[2]);
-            const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);
-            if (mx[0] <= ep && mx[3] <= ed) done = 1;
+            done = qp2_converged<NSEG>(cfg, mx, red, tid);
         }
         STAMP2(8);
         if (done) break;
     }
     if (it > cfg.qp_iters) it = cfg.qp_iters;
-    if (isPath) c.ws.y[(size_t)b * D::mn + myrow] = yg;
-    if (tid == 0) { c.ws.qpit[b] = it; c.ws.qp_total[b] += it; }
+    if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; }
 #ifdef MPCMP_STAMPS
-    if (tid == 0) { for (int k = 3; k < 16; k++) stamp_acc_out[k] = stamp_acc[k]; stamp_acc_out[15] = it; }
+    if (tid == 0) { unsigned long long *o = c.ws.dbg + (size_t)c.b * 16; for (int k = 3; k < 15; k++) o[k] = stamp_acc[k]; o[15] = it; }
 #endif
-    (void)n; (void)stamp_acc_out;
 }
 
-// ---- group B: interface solve (P2), dynamics rows, variables ---------------------------------------------
+// ---- role A2: E^T row-pair quads — E_s^T b_J (P1) — and every general row (z~ = A x~, projection, duals) ----
+template <int NSEG>
+__device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
+    using D = Dim<NSEG>;
+    using L = Qp2<NSEG>;
+    constexpr int N = D::N, n = D::n, meq = D::meq, GS = L::GS, XS = L::XS;
+    double *lds = c.lds;
+    const mpcmp_config &cfg = *c.cfg;
+    const int tid = c.tid, b = c.b;
+    double *red = lds + L::oRed, *gkl = lds + L::oGk;
+    double *rhsJ = lds + L::oRhsJ, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx, *wg = lds + L::oWg,
+           *ys = lds + L::oYs, *tpl = lds + L::oTp;
+    const int et = tid - L::NA1, Q = et >> 2, part = et & 3;
+    const bool act = Q < L::NEQ;
+    const int seg = act ? Q / 15 : 0, le = act ? Q % 15 : 0;
+    // register block: rows (2le, 2le+1) of E_s^T x columns part*14..+13
+    double m1[2][14];
+    {
+        const double *Es = c.fac + seg * (D::JP + D::JC) + D::JP;
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int cc = 2 * le + a;
+#pragma unroll
+            for (int j = 0; j < 14; j++) {
+                const int i = part * 14 + j;
+                m1[a][j] = (act && cc < 29 && i < 49) ? Es[i * 29 + cc] : 0.0;
+                if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();          // (matches role A1/B: register blocks picked up)
+    const int pdst = (act && part < 2 && 2 * le + part < 29) ? seg * 32 + 2 * le + part : -1;
+    // path row owned by this lane (ADMM state) and the 2x11 coefficient block it helps to evaluate; the row
+    // constants live in LDS (lane-transposed), only the ADMM state (z, y) stays in registers
+    const bool isPath = et < 8 * N;
+    const int pk = et >> 3, prp = (et & 7) >> 1, phalf = et & 1;
+    double *pcl = lds + L::oPc + et, *rcl = lds + L::oRc + et;
+    double zg = 0, yg = 0;
+    int myrow = 0;
+    if (isPath) {
+        const int q = 2 * prp + phalf;
+        myrow = meq + 8 * pk + q;
+        const double gv = c.ws.g[(size_t)b * 8 * N + 8 * pk + q];
+        const double lg = cfg.lbg[q] - gv, ug = cfg.ubg[q] - gv;
+        pcl[0] = lg; pcl[L::NA2] = ug;
+        pcl[2 * L::NA2] = (ug - lg < 1e-4) ? c.rho_eq : c.rho_in;
+        pcl[3 * L::NA2] = c.ws.Gk[((size_t)b * N + pk) * 176 + q * 22 + 21];
+    }
+    const int groff = isPath ? (pk * 8 + 2 * prp) * GS + phalf * 11 : 0;
+    const int xnoff = isPath ? pk * XS + phalf * 11 : 0;
+    // dynamics row owned by this lane
+    const bool isDyn = et < meq;
+    double lgd = 0, zgd = 0, ygd = 0;
+    int ix0 = 0, ixf = 0, ixT = 21;
+    if (isDyn) {
+        const int r = et, k = r / 14, rr = r % 14, s = k / 3, i = k % 3;
+        ix0 = 3 * s * XS + rr;
+        ixf = k * XS + ((rr < 7) ? 7 + rr : 14 + rr - 7);
+        ixT = k * XS + 21;
+#pragma unroll
+        for (int j = 0; j < 4; j++) rcl[j * L::NA2] = c_D[4 * i + j];
+        rcl[4 * L::NA2] = -c.tsT;
+        rcl[5 * L::NA2] = -c.ts * c.ws.z[(size_t)b * n + ((rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7)];
+        lgd = -c.ws.ceq[(size_t)b * meq + r];
+    }
+    auto row_dot_dyn = [&](const double *xe) -> double {
+        return rcl[0] * xe[ix0] + rcl[L::NA2] * xe[ix0 + XS] + rcl[2 * L::NA2] * xe[ix0 + 2 * XS] +
+               rcl[3 * L::NA2] * xe[ix0 + 3 * XS] + rcl[4 * L::NA2] * xe[ixf] + rcl[5 * L::NA2] * xe[ixT];
+    };
+    auto row_dot_path = [&](const double *xe) -> double {
+        const double *g0 = gkl + groff, *g1 = g0 + GS, *xv = xe + xnoff;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 11; cc++) { const double xc = xv[cc]; a0 += g0[cc] * xc; a1 += g1[cc] * xc; }
+        a0 = sum2(a0); a1 = sum2(a1);
+        return phalf ? a1 : a0;
+    };
+    __syncthreads();          // constants published (matches the barrier of the other roles)
+    const double alpha = c.alpha, rho_eq = c.rho_eq;
+    const double *bj = rhsJ + 56 * seg + 14 * part;
+    int it = 0, done = 0;
+    for (it = 1; it <= cfg.qp_iters; it++) {
+        // ---- A (role B) ----
+        __syncthreads();
+        // ---- P1 ----
+        {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int jc = 0; jc < 14; jc += 7) {
+#pragma unroll
+                for (int j = jc; j < jc + 7; j++) { const double bv = bj[j]; a0 += m1[0][j] * bv; a1 += m1[1][j] * bv; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            a0 = sum4(a0); a1 = sum4(a1);
+            if (pdst >= 0) partl[pdst] = part ? a1 : a0;
+        }
+        __syncthreads();
+        // ---- P2 (role B) ----
+        __syncthreads();
+        // ---- P3 (role A1) ----
+        __syncthreads();
+        // ---- E: z~ = A x~, relaxation, projection, dual update ----
+        const bool check = (it % cfg.check_every == 0);
+        if (isPath) {
+            const double zt = row_dot_path(xn);
+            const double rr_ = pcl[2 * L::NA2];
+            const double zr = alpha * zt + (1.0 - alpha) * zg;
+            const double zn = clip(zr + yg / rr_, pcl[0], pcl[L::NA2]);
+            yg += rr_ * (zr - zn);
+            zg = zn;
+            const double w = rr_ * zg - yg;
+            wg[myrow] = w;
+            tpl[myrow] = pcl[3 * L::NA2] * w;
+            if (check) ys[myrow] = yg;
+        }
+        if (isDyn) {
+            const double zt = row_dot_dyn(xn);
+            const double zr = alpha * zt + (1.0 - alpha) * zgd;
+            const double zn = clip(zr + ygd / rho_eq, lgd, lgd);
+            ygd += rho_eq * (zr - zn);
+            zgd = zn;
+            const double w = rho_eq * zgd - ygd;
+            wg[et] = w;
+            tpl[et] = rcl[5 * L::NA2] * w;
+            if (check) ys[et] = ygd;
+        }
+        __syncthreads();
+        if (check) {
+            double sums[2] = {(isPath ? pcl[3 * L::NA2] * yg : 0.0) + (isDyn ? rcl[5 * L::NA2] * ygd : 0.0), 0.0};
+            block_reduce16<2, false>(sums, red, tid);
+            double mx[6] = {0, 0, 0, 0, 0, 0};
+            if (isPath) {
+                const double ax = row_dot_path(xx);
+                mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg);
+            }
+            if (isDyn) {
+                const double ax = row_dot_dyn(xx);
+                mx[0] = fmax(mx[0], fabs(ax - zgd)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zgd));
+            }
+            done = qp2_converged<NSEG>(cfg, mx, red, tid);
+        }
+        if (done) break;
+    }
+    if (isPath) c.ws.y[(size_t)b * D::mn + myrow] = yg;
+    if (isDyn) c.ws.y[(size_t)b * D::mn + et] = ygd;
+}
+
 struct VarRole {
     double lb, ub, rb, hd, ha, qv, cf, dA[3], dB[3];
     int rA, rB, rf, pb, gcol, xpos, rpos;
@@ -273,37 +463,66 @@ __device__ __forceinline__ VarRole make_var_role(const mpcmp_config &cfg, const 
 }
 
 template <int NSEG>
-__device__ __forceinline__ void qp2_group_b(const Qp2Ctx<NSEG> &c, const double (&s2)[2][10], const int (&rof)[10]) {
+__device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     using D = Dim<NSEG>;
     using L = Qp2<NSEG>;
     constexpr int N = D::N, n = D::n, meq = D::meq, m = D::m, nI = D::nI, GS = L::GS, XS = L::XS;
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
-    const int tid = c.tid, b = c.b, u = tid - L::NA;
+    const int tid = c.tid, b = c.b, u = tid - L::NA1 - L::NA2;
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
     double *rhsI = lds + L::oRhsI, *partl = lds + L::oPart, *xC = lds + L::oXC, *xn = lds + L::oXn, *xx = lds + L::oXx,
            *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *misc = lds + L::oMisc;
     const bool isP2 = (u >> 3) < L::NPR;
     const int rp2 = u >> 3, part2 = u & 7;
-    const bool isDyn = u < meq, isVar = u < n, isT = u == n - 1;
-    const double *zg_ = c.ws.z + (size_t)b * n;
-    VarRole vr = make_var_role<NSEG>(cfg, c.ws, b, u, isVar, c.ts, c.tsT, c.rho_in, c.rho_eq);
-    if (isT) { vr.hd = lds[L::oMisc + 3] + cfg.hess_reg; vr.ha = 0.0; }
-    // dynamics row role
-    double rcoef[6] = {0, 0, 0, 0, 0, 0}, lg = 0, ug = 0, zg = 0, yg = 0;
-    int ix0 = 0, ixf = 0, ixT = 21;
-    if (isDyn) {
-        const int r = u, k = r / 14, rr = r % 14, s = k / 3, i = k % 3;
-        ix0 = 3 * s * XS + rr;
-        ixf = k * XS + ((rr < 7) ? 7 + rr : 14 + rr - 7);
-        ixT = k * XS + 21;
+    const bool isVar = u < n, isT = u == n - 1;
+    const double sum_ha = lds[L::oMisc + 3];
+    // register block: rows (2rp2, 2rp2+1) of S^-1 x columns part2*10..+9; per column the LDS slots of the E^T b terms
+    // (row 2rp2 in registers, row 2rp2+1 in LDS lane-transposed: role B is the register-tightest role)
+    double s2[10], s2b[10];
+    int rof[10];
+    {
+        const double *S = lds + L::oS;
 #pragma unroll
-        for (int j = 0; j < 4; j++) rcoef[j] = c_D[4 * i + j];
-        rcoef[4] = -c.tsT;
-        rcoef[5] = -c.ts * zg_[(rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7];
-        lg = ug = -c.ws.ceq[(size_t)b * meq + r];
+        for (int j = 0; j < 10; j++) {
+            const int col = part2 * 10 + j;
+            // (the T column, col == nI-1, is applied separately: its right-hand side has NSEG+2 terms)
+            s2[j] = (isP2 && 2 * rp2 < nI && col < nI - 1) ? -S[packed(2 * rp2, col)] : 0.0;
+            s2b[j] = (isP2 && 2 * rp2 + 1 < nI && col < nI - 1) ? -S[packed(2 * rp2 + 1, col)] : 0.0;
+            int o1 = L::oMisc, o2 = L::oMisc;           // zero slot
+            if (col < 14 * (NSEG + 1)) {
+                const int sb = col / 14, cc = col % 14;
+                if (sb < NSEG) o1 = L::oPart + sb * 32 + cc;
+                if (sb > 0) o2 = L::oPart + (sb - 1) * 32 + 14 + cc;
+            }
+            rof[j] = (o1 << 16) | o2;
+        }
     }
-    const double rr_ = c.rho_eq, coefT = rcoef[5];
+    const bool hasT = isP2 && part2 == (nI - 1) / 10;      // the lane of each group that owns column T
+    const double sT0 = (hasT && 2 * rp2 < nI) ? -lds[L::oS + packed(2 * rp2, nI - 1)] : 0.0;
+    const double sT1 = (hasT && 2 * rp2 + 1 < nI) ? -lds[L::oS + packed(2 * rp2 + 1, nI - 1)] : 0.0;
+    __syncthreads();          // S consumed; the staging area may now be overwritten
+    double *s2l = lds + L::oS2 + u;
+#pragma unroll
+    for (int j = 0; j < 10; j++) s2l[j * L::NB] = s2b[j];
+    // variable role: the per-iteration state (x, z_b, y_b) and the box stay in registers, the gather coefficients
+    // and Hessian entries live in LDS (lane-transposed)
+    double *vcl = lds + L::oVc + u;
+    double v_lb, v_ub, v_rb, v_qv;
+    int v_rA, v_rB, v_rf, v_pb, v_gcol, v_xpos, v_rpos;
+    bool v_hasG;
+    {
+        VarRole vr = make_var_role<NSEG>(cfg, c.ws, b, u, isVar, c.ts, c.tsT, c.rho_in, c.rho_eq);
+        if (isT) { vr.hd = sum_ha + cfg.hess_reg; vr.ha = 0.0; }
+        vcl[0] = vr.cf;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { vcl[(1 + i) * L::NB] = vr.dA[i]; vcl[(4 + i) * L::NB] = vr.dB[i]; }
+        vcl[7 * L::NB] = vr.hd; vcl[8 * L::NB] = vr.ha; vcl[9 * L::NB] = vr.qv;
+        v_lb = vr.lb; v_ub = vr.ub; v_rb = vr.rb; v_qv = vr.qv;
+        v_rA = vr.rA; v_rB = vr.rB; v_rf = vr.rf; v_pb = vr.pb; v_gcol = vr.gcol; v_xpos = vr.xpos; v_rpos = vr.rpos;
+        v_hasG = vr.hasG;
+    }
+    __syncthreads();          // LDS-resident constants published
     // interface solve output: where x_I[row] goes
     int xdst = -1, cdst1 = -1, cdst2 = -1, myIrow = -1;
     if (isP2 && part2 < 2) {
@@ -320,20 +539,20 @@ __device__ __forceinline__ void qp2_group_b(const Qp2Ctx<NSEG> &c, const double 
             }
         }
     }
-    auto row_dot_dyn = [&](const double *xe) -> double {
-        return rcoef[0] * xe[ix0] + rcoef[1] * xe[ix0 + XS] + rcoef[2] * xe[ix0 + 2 * XS] + rcoef[3] * xe[ix0 + 3 * XS] +
-               rcoef[4] * xe[ixf] + rcoef[5] * xe[ixT];
-    };
     auto col_gather = [&](const double *w) -> double {
-        double s = vr.cf * w[vr.rf];
+        double s = vcl[0] * w[v_rf];
 #pragma unroll
-        for (int i = 0; i < 3; i++) s += vr.dA[i] * w[vr.rA + 14 * i];
+        for (int i = 0; i < 3; i++) s += vcl[(1 + i) * L::NB] * w[v_rA + 14 * i];
 #pragma unroll
-        for (int i = 0; i < 3; i++) s += vr.dB[i] * w[vr.rB + 14 * i];
-        if (vr.hasG) {
-            const double *gc = gkl + vr.gcol;
+        for (int i = 0; i < 3; i++) s += vcl[(4 + i) * L::NB] * w[v_rB + 14 * i];
+        __builtin_amdgcn_sched_barrier(0);          // two batches of LDS reads (VGPR pressure of role B)
+        if (v_hasG) {
+            const double *gc = gkl + v_gcol;
 #pragma unroll
-            for (int q = 0; q < 8; q++) s += gc[q * GS] * w[vr.pb + q];
+            for (int q = 0; q < 4; q++) s += gc[q * GS] * w[v_pb + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 4; q < 8; q++) s += gc[q * GS] * w[v_pb + q];
         }
         return s;
     };
@@ -343,9 +562,9 @@ __device__ __forceinline__ void qp2_group_b(const Qp2Ctx<NSEG> &c, const double 
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: rhs = sigma x - q + rho_b zb - yb + A^T w ----
         if (isVar) {
-            const double base = sigma * x - vr.qv + (vr.rb * zb - yb);
+            const double base = sigma * x - v_qv + (v_rb * zb - yb);
             if (isT) misc[1] = base;
-            else lds[vr.rpos] = base + col_gather(wg);
+            else lds[v_rpos] = base + col_gather(wg);
         }
         __syncthreads();
         // ---- P1: (group A) ----
@@ -355,14 +574,19 @@ __device__ __forceinline__ void qp2_group_b(const Qp2Ctx<NSEG> &c, const double 
             double a0 = 0.0, a1 = 0.0;
             const double *bi = rhsI + part2 * 10;
 #pragma unroll
-            for (int j = 0; j < 10; j++) {
-                double r = bi[j] - lds[rof[j] >> 16] - lds[rof[j] & 0xffff];
-                if (part2 * 10 + j == nI - 1) {       // column T: b_T assembled here
-                    r = misc[1] + misc[2];
+            for (int jc = 0; jc < 10; jc += 5) {
 #pragma unroll
-                    for (int s = 0; s < NSEG; s++) r -= partl[s * 32 + 28];
+                for (int j = jc; j < jc + 5; j++) {
+                    const double r = bi[j] - lds[rof[j] >> 16] - lds[rof[j] & 0xffff];
+                    a0 += s2[j] * r; a1 += s2l[j * L::NB] * r;
                 }
-                a0 += s2[0][j] * r; a1 += s2[1][j] * r;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (hasT) {       // column T: b_T = (sigma x_T - q_T + box terms) + sum_r coefT_r w_r - sum_s (E_s^T b_Js)_T
+                double r = misc[1] + misc[2];
+#pragma unroll
+                for (int sg = 0; sg < NSEG; sg++) r -= partl[sg * 32 + 28];
+                a0 += sT0 * r; a1 += sT1 * r;
             }
             a0 = sum8(a0); a1 = sum8(a1);
             if (myIrow >= 0) {
@@ -382,51 +606,34 @@ __device__ __forceinline__ void qp2_group_b(const Qp2Ctx<NSEG> &c, const double 
         __syncthreads();
         // ---- P3: (group A) ----
         __syncthreads();
-        // ---- E: dynamics rows and variables ----
+        // ---- E: variables ----
         const bool check = (it % cfg.check_every == 0);
-        if (isDyn) {
-            const double zt = row_dot_dyn(xn);
-            const double zr = alpha * zt + (1.0 - alpha) * zg;
-            const double zn = clip(zr + yg / rr_, lg, ug);
-            yg += rr_ * (zr - zn);
-            zg = zn;
-            const double w = rr_ * zg - yg;
-            wg[u] = w;
-            tpl[u] = coefT * w;
-            if (check) ys[u] = yg;
-        }
         if (isVar) {
-            const double xtv = xn[vr.xpos];
+            const double xtv = xn[v_xpos];
             x = alpha * xtv + (1.0 - alpha) * x;
             const double zr = alpha * xtv + (1.0 - alpha) * zb;
-            const double zn = clip(zr + yb / vr.rb, vr.lb, vr.ub);
-            yb += vr.rb * (zr - zn);
+            const double zn = clip(zr + yb / v_rb, v_lb, v_ub);
+            yb += v_rb * (zr - zn);
             zb = zn;
             if (check) {
                 if (isT) { for (int k = 0; k < N; k++) xx[k * XS + 21] = x; }
-                else xx[vr.xpos] = x;
+                else xx[v_xpos] = x;
             }
         }
         __syncthreads();
         if (check) {
-            double sums[2] = {isDyn ? coefT * yg : 0.0, (isVar && !isT) ? vr.ha * x : 0.0};
-            block_reduce<L::NW, 2, false>(sums, red, tid);
+            double sums[2] = {0.0, (isVar && !isT) ? vcl[8 * L::NB] * x : 0.0};
+            block_reduce16<2, false>(sums, red, tid);
             double mx[6] = {0, 0, 0, 0, 0, 0};
-            if (isDyn) {
-                const double ax = row_dot_dyn(xx);
-                mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg);
-            }
             if (isVar) {
                 mx[0] = fmax(mx[0], fabs(x - zb)); mx[1] = fmax(mx[1], fabs(x)); mx[2] = fmax(mx[2], fabs(zb));
                 double hx, aty;
-                if (isT) { hx = vr.hd * x + sums[1]; aty = sums[0] + yb; }
-                else { hx = vr.hd * x + vr.ha * xx[21]; aty = col_gather(ys) + yb; }
-                mx[3] = fabs(hx + aty + vr.qv); mx[4] = fabs(hx); mx[5] = fabs(aty);
+                const double hdv = vcl[7 * L::NB];
+                if (isT) { hx = hdv * x + sums[1]; aty = sums[0] + yb; }
+                else { hx = hdv * x + vcl[8 * L::NB] * xx[21]; aty = col_gather(ys) + yb; }
+                mx[3] = fabs(hx + aty + v_qv); mx[4] = fabs(hx); mx[5] = fabs(aty);
             }
-            block_reduce<L::NW, 6, true>(mx, red, tid);
-            const double ep = cfg.eps_abs + cfg.eps_rel * fmax(mx[1], mx[2]);
-            const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);
-            if (mx[0] <= ep && mx[3] <= ed) done = 1;
+            done = qp2_converged<NSEG>(cfg, mx, red, tid);
         }
         if (done) break;
     }
@@ -434,20 +641,20 @@ __device__ __forceinline__ void qp2_group_b(const Qp2Ctx<NSEG> &c, const double 
         c.ws.p[(size_t)b * n + u] = x;
         c.ws.y[(size_t)b * D::mn + m + u] = yb;
     }
-    if (isDyn) c.ws.y[(size_t)b * D::mn + u] = yg;
 }
 
 template <int NSEG>
-__global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws) {
+__global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *fac_all) {
     using D = Dim<NSEG>;
     using L = Qp2<NSEG>;
     constexpr int N = D::N, n = D::n, meq = D::meq, nJ = D::nJ, nI = D::nI, NT = L::NT;
-    constexpr int GS = L::GS, XS = L::XS;
+    constexpr int GS = L::GS;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
+    double *fac = fac_all + (size_t)b * L::FAC;
     Qp2Ctx<NSEG> c;
-    c.cfg = &cfg; c.ws = ws; c.lds = lds; c.tid = tid; c.b = b;
+    c.cfg = &cfg; c.ws = ws; c.lds = lds; c.fac = fac; c.tid = tid; c.b = b;
     c.ts = 1.0 / (2.0 * NSEG);
     c.rho_in = cfg.rho; c.rho_eq = cfg.rho * cfg.rho_eq_scale; c.sigma = cfg.sigma; c.alpha = cfg.alpha;
     const double ts = c.ts, rho_in = c.rho_in, rho_eq = c.rho_eq, sigma = c.sigma;
@@ -460,20 +667,18 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws) {
 #ifdef MPCMP_STAMPS
     unsigned long long stamp_acc[16] = {0}, stamp_t = clock64();
 #endif
-    const bool grpA = tid < L::NA;
-    const int u = tid - L::NA;
-    const bool isVar = !grpA && u < n, isT = !grpA && u == n - 1;
+    const int u = tid - L::NA1 - L::NA2;
+    const bool isVar = u >= 0 && u < n, isT = u == n - 1;
 
     for (int i = tid; i < L::oRed - L::oRhsJ; i += NT) lds[L::oRhsJ + i] = 0.0;     // exchanged vectors and their pads
     __syncthreads();
-    // ---- variable role (group B): only the Hessian/rho entries needed by the assembly are kept live here;
-    //      the full role is rebuilt inside qp2_group_b (keeps the factorisation's register footprint small) ----
+    // ---- variable role (role B): only the Hessian/rho entries needed by the assembly are kept live here ----
     double v_diag = 0.0, v_ha = 0.0;
     int ipos = 0;
     {
         VarRole vr = make_var_role<NSEG>(cfg, ws, b, u, isVar, ts, tsT, rho_in, rho_eq);
         double sv[1] = {isVar && !isT ? fabs(vr.ha) : 0.0};
-        block_reduce<L::NW, 1, false>(sv, red, tid);
+        block_reduce16<1, false>(sv, red, tid);
         if (isT) { vr.hd = sv[0] + cfg.hess_reg; vr.ha = 0.0; }
         if (tid == 0) lds[L::oMisc + 3] = sv[0];
         v_diag = vr.hd + sigma + vr.rb; v_ha = vr.ha;
@@ -564,18 +769,6 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws) {
         if (!isT) S[packed(nI - 1, a)] += v_ha;
     }
     __syncthreads();
-    // register-resident factor blocks of group A
-    const int Q = tid >> 2, part = tid & 3, seg = Q / L::QPS, lp = Q % L::QPS;
-    const bool isG = grpA && lp < 25;
-    double m1[2][14];   // rows (2lp, 2lp+1) of [G_s ; E_s^T], columns part*14 .. +13 (of 49, zero padded)
-    double e3[2][8];    // G quads: rows (2lp, 2lp+1) of E_s, columns part*8 .. +7 (of 29)
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-#pragma unroll
-        for (int j = 0; j < 14; j++) m1[a][j] = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) e3[a][j] = 0.0;
-    }
     for (int s0 = 0; s0 < NSEG; s0 += L::HS) {
         const int nh = (NSEG - s0 < L::HS) ? NSEG - s0 : L::HS;
         for (int h = 0; h < nh; h++) {
@@ -610,35 +803,14 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws) {
                 const int ia = ca < 28 ? 14 * s + ca : nI - 1, ib = cb < 28 ? 14 * s + cb : nI - 1;
                 S[packed(ia, ib)] -= acc;
             }
-            __syncthreads();
+            __syncthreads();      // consecutive segments update overlapping entries of S (shared node, T)
         }
-        // owners load their register blocks
-        if (grpA && seg >= s0 && seg < s0 + nh) {
-            const int h = seg - s0;
-            const double *Gn = KJJ + h * D::JP, *Es = Eh + h * D::JC;
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                if (isG) {
-                    const int row = 2 * lp + a;
-#pragma unroll
-                    for (int j = 0; j < 14; j++) {
-                        const int col = part * 14 + j;
-                        m1[a][j] = (row < 49 && col < 49) ? -Gn[packed(row, col)] : 0.0;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int col = part * 8 + j;
-                        e3[a][j] = (row < 49 && col < 29) ? Es[row * 29 + col] : 0.0;
-                    }
-                } else {
-                    const int cc = 2 * (lp - 25) + a;       // row cc of E_s^T
-#pragma unroll
-                    for (int j = 0; j < 14; j++) {
-                        const int i = part * 14 + j;
-                        m1[a][j] = (cc < 29 && i < 49) ? Es[i * 29 + cc] : 0.0;
-                    }
-                }
-            }
+        // park -G and E of this group in the per-problem HBM scratch; the role threads load their register blocks
+        // from there once the whole factorisation is done (keeps the factorisation's register footprint small)
+        for (int h = 0; h < nh; h++) {
+            double *dst = fac + (s0 + h) * (D::JP + D::JC);
+            for (int e = tid; e < D::JP; e += NT) dst[e] = KJJ[h * D::JP + e];
+            for (int e = tid; e < D::JC; e += NT) dst[D::JP + e] = Eh[h * D::JC + e];
         }
         __syncthreads();
     }
@@ -650,36 +822,11 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws) {
         if (tid == 0 && any) ws.status[b] |= any;
     }
 #ifdef MPCMP_STAMPS
-    unsigned long long *dbg = ws.dbg + (size_t)b * 16;
-    if (tid == 0) { for (int k = 0; k < 3; k++) dbg[k] = stamp_acc[k]; }
-#else
-    unsigned long long *dbg = nullptr;
+    if (tid == 0) { unsigned long long *dbg = ws.dbg + (size_t)b * 16; for (int k = 0; k < 3; k++) dbg[k] = stamp_acc[k]; }
 #endif
-    if (grpA) {
-        qp2_group_a<NSEG>(c, m1, e3, dbg);
-    } else {
-        // rows (2rp2, 2rp2+1) of S^-1, columns part2*10 .. +9; per column the LDS slots of the E^T b contributions
-        double s2[2][10];
-        int rof[10];
-        const int rp2 = u >> 3, part2 = u & 7;
-#pragma unroll
-        for (int j = 0; j < 10; j++) {
-            const int col = part2 * 10 + j;
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const int row = 2 * rp2 + a;
-                s2[a][j] = (row < nI && col < nI) ? -S[packed(row, col)] : 0.0;
-            }
-            int o1 = L::oMisc, o2 = L::oMisc;           // zero slot
-            if (col < 14 * (NSEG + 1)) {
-                const int sb = col / 14, cc = col % 14;
-                if (sb < NSEG) o1 = L::oPart + sb * 32 + cc;
-                if (sb > 0) o2 = L::oPart + (sb - 1) * 32 + 14 + cc;
-            }
-            rof[j] = (o1 << 16) | o2;
-        }
-        qp2_group_b<NSEG>(c, s2, rof);
-    }
+    if (tid < L::NA1) qp2_role_a1<NSEG>(c);
+    else if (tid < L::NA1 + L::NA2) qp2_role_a2<NSEG>(c);
+    else qp2_role_b<NSEG>(c);
 }
 
 }  // namespace mpcmp
