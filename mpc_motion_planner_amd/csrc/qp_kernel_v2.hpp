@@ -32,6 +32,10 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
+// 16-byte LDS read of two consecutive doubles (ds_read_b128: full LDS rate; ds_read2_b64 runs at half rate)
+struct alignas(16) D2 { double x, y; };
+__device__ __forceinline__ D2 lds2(const double *p) { return *reinterpret_cast<const D2 *>(__builtin_assume_aligned(p, 16)); }
+
 template <bool MAX>
 __device__ __forceinline__ double red_op(double a, double b) { return MAX ? fmax(a, b) : a + b; }
 template <bool MAX>
@@ -89,7 +93,8 @@ struct Qp2 {
     static constexpr int oGk = 0;                              // [N][8][GS]
     static constexpr int oRhsJ = oGk + D::N * 8 * GS;          // [NSEG][56]   rhs, interior part (zero padded)
     static constexpr int oRhsI = oRhsJ + NSEG * 56;            // [80]         rhs, interface part
-    static constexpr int oPart = oRhsI + 2 * ((D::nI + 2) / 2);// [NSEG][32]   E_s^T b_Js
+    static constexpr int oRI = oRhsI + 2 * ((D::nI + 2) / 2);  // [80]         r_I = b_I - sum_s E_s^T b_Js
+    static constexpr int oPart = oRI + 80;                     // [NSEG][32]   E_s^T b_Js
     static constexpr int oXC = oPart + NSEG * 32;              // [NSEG][32]   x_I restricted to C_s
     static constexpr int oXn = oXC + NSEG * 32;                // [N][XS]      x~ node-major
     static constexpr int oXx = oXn + D::N * XS;                // [N][XS]      x  node-major (termination tests)
@@ -106,11 +111,11 @@ struct Qp2 {
     // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
     static constexpr int oE3 = oS;                             // [16][4*NGQ] E_s blocks of role A1 (lane-transposed)
     static constexpr int oRc = oE3 + 16 * 4 * NGQ;             // [6][NA2]   dynamics-row coefficients
-    static constexpr int oPc = oRc + 6 * NA2;                  // [4][NA2]   path-row lg, ug, rho, coefT
-    static constexpr int oVc = oPc + 4 * NA2;                  // [10][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv
+    static constexpr int oPc = oRc + 6 * NA2;                  // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
+    static constexpr int oVc = oPc + 5 * NA2;                  // [10][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv
     static constexpr int oS2 = oVc + 10 * NB;                  // [10][NB]   second row of each S^-1 block (role B)
     static constexpr int oEndA = oS2 + 10 * NB;
-    static_assert(oEndA * 8 <= 160 * 1024 && (oZ + D::n) * 8 <= 160 * 1024, "LDS budget");
+    static_assert(oEndA * 8 <= 160 * 1024 - 512 && (oZ + D::n) * 8 <= 160 * 1024 - 512, "LDS budget (a 256-byte static block precedes the dynamic region)");
     static constexpr int size = (oZ + D::n > oEndA) ? oZ + D::n : oEndA;
 };
 
@@ -161,7 +166,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     // (lane-transposed: element q of lane t at e3l[q*NA1 + t], conflict-free)
     double m1[2][14];
     constexpr int E3S = 4 * L::NGQ;
-    double *e3l = lds + L::oE3 + (act ? tid : 0);
+    double *e3l = lds + L::oE3 + 2 * (act ? tid : 0);      // element q of this lane at e3l[(q/2)*2*E3S + (q&1)]
     {
         const double *Gn = c.fac + seg * (D::JP + D::JC), *Es = Gn + D::JP;
 #pragma unroll
@@ -181,7 +186,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int col = part * 8 + j;
-                if (act) e3l[(a * 8 + j) * E3S] = (row < 49 && col < 29) ? Es[row * 29 + col] : 0.0;
+                if (act) e3l[((a * 8 + j) / 2) * 2 * E3S + ((a * 8 + j) & 1)] = (row < 49 && col < 29) ? Es[row * 29 + col] : 0.0;
             }
         }
         __syncthreads();      // LDS-resident constants published
@@ -209,26 +214,27 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         {
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int jc = 0; jc < 14; jc += 7) {          // two chunks: bounds the LDS reads in flight (VGPR pressure)
-#pragma unroll
-                for (int j = jc; j < jc + 7; j++) { const double bv = bj[j]; a0 += m1[0][j] * bv; a1 += m1[1][j] * bv; }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 14; j += 2) {
+                const D2 bv = lds2(bj + j);
+                a0 += m1[0][j] * bv.x; a1 += m1[1][j] * bv.x;
+                a0 += m1[0][j + 1] * bv.y; a1 += m1[1][j + 1] * bv.y;
             }
             t0 = sum4(a0); t1 = sum4(a1);
         }
         __syncthreads();
         STAMP2(4);
-        // ---- P2 (role B) ----
+        // ---- P2a, P2b (role B) ----
+        __syncthreads();
         __syncthreads();
         STAMP2(5);
         // ---- P3 ----
         {
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int jc = 0; jc < 8; jc += 4) {
-#pragma unroll
-                for (int j = jc; j < jc + 4; j++) { const double xv = xc[j]; a0 += e3l[j * E3S] * xv; a1 += e3l[(8 + j) * E3S] * xv; }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 8; j += 2) {
+                const D2 xv = lds2(xc + j), e0 = lds2(e3l + j * E3S), e1 = lds2(e3l + (8 + j) * E3S);
+                a0 += e0.x * xv.x; a1 += e1.x * xv.x;
+                a0 += e0.y * xv.y; a1 += e1.y * xv.y;
             }
             a0 = sum4(a0); a1 = sum4(a1);
             if (jdst >= 0) xn[jdst] = part ? (t1 - a1) : (t0 - a0);
@@ -301,6 +307,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         pcl[0] = lg; pcl[L::NA2] = ug;
         pcl[2 * L::NA2] = (ug - lg < 1e-4) ? c.rho_eq : c.rho_in;
         pcl[3 * L::NA2] = c.ws.Gk[((size_t)b * N + pk) * 176 + q * 22 + 21];
+        pcl[4 * L::NA2] = 1.0 / pcl[2 * L::NA2];
     }
     const int groff = isPath ? (pk * 8 + 2 * prp) * GS + phalf * 11 : 0;
     const int xnoff = isPath ? pk * XS + phalf * 11 : 0;
@@ -332,7 +339,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         return phalf ? a1 : a0;
     };
     __syncthreads();          // constants published (matches the barrier of the other roles)
-    const double alpha = c.alpha, rho_eq = c.rho_eq;
+    const double alpha = c.alpha, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
     const double *bj = rhsJ + 56 * seg + 14 * part;
     int it = 0, done = 0;
     for (it = 1; it <= cfg.qp_iters; it++) {
@@ -342,16 +349,17 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         {
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int jc = 0; jc < 14; jc += 7) {
-#pragma unroll
-                for (int j = jc; j < jc + 7; j++) { const double bv = bj[j]; a0 += m1[0][j] * bv; a1 += m1[1][j] * bv; }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 14; j += 2) {
+                const D2 bv = lds2(bj + j);
+                a0 += m1[0][j] * bv.x; a1 += m1[1][j] * bv.x;
+                a0 += m1[0][j + 1] * bv.y; a1 += m1[1][j + 1] * bv.y;
             }
             a0 = sum4(a0); a1 = sum4(a1);
             if (pdst >= 0) partl[pdst] = part ? a1 : a0;
         }
         __syncthreads();
-        // ---- P2 (role B) ----
+        // ---- P2a, P2b (role B) ----
+        __syncthreads();
         __syncthreads();
         // ---- P3 (role A1) ----
         __syncthreads();
@@ -361,7 +369,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             const double zt = row_dot_path(xn);
             const double rr_ = pcl[2 * L::NA2];
             const double zr = alpha * zt + (1.0 - alpha) * zg;
-            const double zn = clip(zr + yg / rr_, pcl[0], pcl[L::NA2]);
+            const double zn = clip(zr + yg * pcl[4 * L::NA2], pcl[0], pcl[L::NA2]);
             yg += rr_ * (zr - zn);
             zg = zn;
             const double w = rr_ * zg - yg;
@@ -372,7 +380,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         if (isDyn) {
             const double zt = row_dot_dyn(xn);
             const double zr = alpha * zt + (1.0 - alpha) * zgd;
-            const double zn = clip(zr + ygd / rho_eq, lgd, lgd);
+            const double zn = clip(zr + ygd * inv_rho_eq, lgd, lgd);
             ygd += rho_eq * (zr - zn);
             zgd = zn;
             const double w = rho_eq * zgd - ygd;
@@ -472,43 +480,37 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     const int tid = c.tid, b = c.b, u = tid - L::NA1 - L::NA2;
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
     double *rhsI = lds + L::oRhsI, *partl = lds + L::oPart, *xC = lds + L::oXC, *xn = lds + L::oXn, *xx = lds + L::oXx,
-           *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *misc = lds + L::oMisc;
+           *wg = lds + L::oWg, *ys = lds + L::oYs, *misc = lds + L::oMisc, *rI = lds + L::oRI;
     const bool isP2 = (u >> 3) < L::NPR;
     const int rp2 = u >> 3, part2 = u & 7;
     const bool isVar = u < n, isT = u == n - 1;
     const double sum_ha = lds[L::oMisc + 3];
-    // register block: rows (2rp2, 2rp2+1) of S^-1 x columns part2*10..+9; per column the LDS slots of the E^T b terms
-    // (row 2rp2 in registers, row 2rp2+1 in LDS lane-transposed: role B is the register-tightest role)
+    // register block: row 2rp2 of S^-1 x columns part2*10..+9 in registers, row 2rp2+1 in LDS (lane-transposed pairs)
     double s2[10], s2b[10];
-    int rof[10];
     {
         const double *S = lds + L::oS;
 #pragma unroll
         for (int j = 0; j < 10; j++) {
             const int col = part2 * 10 + j;
-            // (the T column, col == nI-1, is applied separately: its right-hand side has NSEG+2 terms)
-            s2[j] = (isP2 && 2 * rp2 < nI && col < nI - 1) ? -S[packed(2 * rp2, col)] : 0.0;
-            s2b[j] = (isP2 && 2 * rp2 + 1 < nI && col < nI - 1) ? -S[packed(2 * rp2 + 1, col)] : 0.0;
-            int o1 = L::oMisc, o2 = L::oMisc;           // zero slot
-            if (col < 14 * (NSEG + 1)) {
-                const int sb = col / 14, cc = col % 14;
-                if (sb < NSEG) o1 = L::oPart + sb * 32 + cc;
-                if (sb > 0) o2 = L::oPart + (sb - 1) * 32 + 14 + cc;
-            }
-            rof[j] = (o1 << 16) | o2;
+            s2[j] = (isP2 && 2 * rp2 < nI && col < nI) ? -S[packed(2 * rp2, col)] : 0.0;
+            s2b[j] = (isP2 && 2 * rp2 + 1 < nI && col < nI) ? -S[packed(2 * rp2 + 1, col)] : 0.0;
         }
     }
-    const bool hasT = isP2 && part2 == (nI - 1) / 10;      // the lane of each group that owns column T
-    const double sT0 = (hasT && 2 * rp2 < nI) ? -lds[L::oS + packed(2 * rp2, nI - 1)] : 0.0;
-    const double sT1 = (hasT && 2 * rp2 + 1 < nI) ? -lds[L::oS + packed(2 * rp2 + 1, nI - 1)] : 0.0;
+    // P2a role (lanes u < nI): which E^T b terms enter r_I[u]
+    int o1 = L::oMisc, o2 = L::oMisc;                   // zero slot
+    if (u < 14 * (NSEG + 1)) {
+        const int sb = u / 14, cc = u % 14;
+        if (sb < NSEG) o1 = L::oPart + sb * 32 + cc;
+        if (sb > 0) o2 = L::oPart + (sb - 1) * 32 + 14 + cc;
+    }
     __syncthreads();          // S consumed; the staging area may now be overwritten
-    double *s2l = lds + L::oS2 + u;
+    double *s2l = lds + L::oS2 + 2 * u;     // element j at s2l[(j/2)*2*NB + (j&1)]: 16-byte reads, conflict-free
 #pragma unroll
-    for (int j = 0; j < 10; j++) s2l[j * L::NB] = s2b[j];
+    for (int j = 0; j < 10; j++) s2l[(j / 2) * 2 * L::NB + (j & 1)] = s2b[j];
     // variable role: the per-iteration state (x, z_b, y_b) and the box stay in registers, the gather coefficients
     // and Hessian entries live in LDS (lane-transposed)
     double *vcl = lds + L::oVc + u;
-    double v_lb, v_ub, v_rb, v_qv;
+    double v_lb, v_ub, v_rb, v_qv, v_rbi;
     int v_rA, v_rB, v_rf, v_pb, v_gcol, v_xpos, v_rpos;
     bool v_hasG;
     {
@@ -518,7 +520,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
 #pragma unroll
         for (int i = 0; i < 3; i++) { vcl[(1 + i) * L::NB] = vr.dA[i]; vcl[(4 + i) * L::NB] = vr.dB[i]; }
         vcl[7 * L::NB] = vr.hd; vcl[8 * L::NB] = vr.ha; vcl[9 * L::NB] = vr.qv;
-        v_lb = vr.lb; v_ub = vr.ub; v_rb = vr.rb; v_qv = vr.qv;
+        v_lb = vr.lb; v_ub = vr.ub; v_rb = vr.rb; v_qv = vr.qv; v_rbi = 1.0 / vr.rb;
         v_rA = vr.rA; v_rB = vr.rB; v_rf = vr.rf; v_pb = vr.pb; v_gcol = vr.gcol; v_xpos = vr.xpos; v_rpos = vr.rpos;
         v_hasG = vr.hasG;
     }
@@ -569,24 +571,28 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         __syncthreads();
         // ---- P1: (group A) ----
         __syncthreads();
-        // ---- P2: x_I = S^-1 (b_I - sum_s E_s^T b_Js) ----
-        if (isP2) {
-            double a0 = 0.0, a1 = 0.0;
-            const double *bi = rhsI + part2 * 10;
-#pragma unroll
-            for (int jc = 0; jc < 10; jc += 5) {
-#pragma unroll
-                for (int j = jc; j < jc + 5; j++) {
-                    const double r = bi[j] - lds[rof[j] >> 16] - lds[rof[j] & 0xffff];
-                    a0 += s2[j] * r; a1 += s2l[j * L::NB] * r;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (hasT) {       // column T: b_T = (sigma x_T - q_T + box terms) + sum_r coefT_r w_r - sum_s (E_s^T b_Js)_T
-                double r = misc[1] + misc[2];
+        // ---- P2a: r_I = b_I - sum_s E_s^T b_Js  (one lane per interface entry) ----
+        if (u < nI) {
+            double r;
+            if (u == nI - 1) {       // T: b_T = (sigma x_T - q_T + box terms) + sum_r coefT_r w_r
+                r = misc[1] + misc[2];
 #pragma unroll
                 for (int sg = 0; sg < NSEG; sg++) r -= partl[sg * 32 + 28];
-                a0 += sT0 * r; a1 += sT1 * r;
+            } else {
+                r = rhsI[u] - lds[o1] - lds[o2];
+            }
+            rI[u] = r;
+        }
+        __syncthreads();
+        // ---- P2b: x_I = S^-1 r_I  (2 rows x 10 columns per lane, 8-lane reduction) ----
+        if (isP2) {
+            double a0 = 0.0, a1 = 0.0;
+            const double *rv = rI + part2 * 10;
+#pragma unroll
+            for (int j = 0; j < 10; j += 2) {
+                const D2 r = lds2(rv + j), sb2 = lds2(s2l + j * L::NB);
+                a0 += s2[j] * r.x; a1 += sb2.x * r.x;
+                a0 += s2[j + 1] * r.y; a1 += sb2.y * r.y;
             }
             a0 = sum8(a0); a1 = sum8(a1);
             if (myIrow >= 0) {
@@ -612,7 +618,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             const double xtv = xn[v_xpos];
             x = alpha * xtv + (1.0 - alpha) * x;
             const double zr = alpha * xtv + (1.0 - alpha) * zb;
-            const double zn = clip(zr + yb / v_rb, v_lb, v_ub);
+            const double zn = clip(zr + yb * v_rbi, v_lb, v_ub);
             yb += v_rb * (zr - zn);
             zb = zn;
             if (check) {
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
     using L = Qp2<NSEG>;
     constexpr int N = D::N, n = D::n, meq = D::meq, nJ = D::nJ, nI = D::nI, NT = L::NT;
     constexpr int GS = L::GS;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
     double *fac = fac_all + (size_t)b * L::FAC;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, WS ws,
                                                         const double *warm_u, const double *warm_T) {
     using D = Dim<NSEG>;
     constexpr int N = D::N, n = D::n;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     double *zl = lds, *scr = lds + n;
     const int tid = threadIdx.x, b = blockIdx.x;
     const double *x0 = ws.x0 + 14 * b, *xf = ws.xf + 14 * b;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
     using D = Dim<NSEG>;
     using L = QpLds<NSEG>;
     constexpr int N = D::N, n = D::n, meq = D::meq, m = D::m, nJ = D::nJ, nI = D::nI, NT = D::NT;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     double *red = lds + L::oRed;
     const double ts = 1.0 / (2.0 * NSEG);
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, WS ws,
     using D = Dim<NSEG>;
     using L = StepLds<NSEG>;
     constexpr int N = D::N, n = D::n, meq = D::meq, m = D::m, NT = D::NT;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     double *zl = lds + L::oZ, *pl = lds + L::oP, *pv = lds + L::oPv, *scr = lds + L::oScr, *red = lds + L::oRed;
     const double *x0 = ws.x0 + 14 * b, *xf = ws.xf + 14 * b;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_eval_constraints(mpcmp_config
                                                                     double *G) {
     using D = Dim<NSEG>;
     constexpr int N = D::N;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     double *zl = lds, *scr = lds + D::n;
     const int tid = threadIdx.x, base = blockIdx.x * N;
     for (int t = tid; t < N * 21; t += D::NT) {
