@@ -90,7 +90,9 @@ struct Qp2 {
     static_assert(8 * NPR <= NB && D::n <= NB, "role B mapping");
     static_assert(8 * D::N <= 4 * NEQ && D::meq <= 4 * NEQ, "row lanes must fit the E^T quads");
     // LDS (doubles)
-    static constexpr int oGk = 0;                              // [N][8][GS]
+    static constexpr int RS = 7;                               // padded stride of the dynamics-row coefficients
+    static constexpr int oRv = 0;                              // [meq][RS]    dynamics rows: D_i0..D_i3, -ts*T, -ts*f  (V part 1)
+    static constexpr int oGk = oRv + D::meq * RS;              // [N][8][GS]   path Jacobians                           (V part 2)
     static constexpr int oRhsJ = oGk + D::N * 8 * GS;          // [NSEG][56]   rhs, interior part (zero padded)
     static constexpr int oRhsI = oRhsJ + NSEG * 56;            // [80]         rhs, interface part
     static constexpr int oRI = oRhsI + 2 * ((D::nI + 2) / 2);  // [80]         r_I = b_I - sum_s E_s^T b_Js
@@ -103,20 +105,23 @@ struct Qp2 {
     static constexpr int oTp = oYs + D::m;                     // [m]          coefT_r * w_r
     static constexpr int oMisc = oTp + D::m;                   // [8]  0: zero slot, 1: T base, 2: T column sum, 3: sum|ha|
     static constexpr int oRed = oMisc + 8;                     // [NW*8]
-    static constexpr int oS = oRed + NW * 8;                   // packed S (factorisation), then -(S^-1)
-    static constexpr int oKJJ = oS + D::SP;                    // [HS][JP]
-    static constexpr int oKJC = oKJJ + HS * D::JP;             // [HS][JC]
+    // factor area (must match build_streams): S | KJJ[NSEG] | KJC[HS] | Eh[HS] | scratch[32] | rdv[8]
+    static constexpr int oS = oRed + NW * 8;                   // packed S, then -(S^-1)
+    static constexpr int oKJJ = oS + D::SP;                    // [NSEG][JP]
+    static constexpr int oKJC = oKJJ + NSEG * D::JP;           // [HS][JC]
     static constexpr int oEh = oKJC + HS * D::JC;              // [HS][JC]
-    static constexpr int oZ = oEh + HS * D::JC;                // [n]
+    static constexpr int oScr = oEh + HS * D::JC;              // [32] partial sums of split entries
+    static constexpr int oRdv = oScr + 32;                     // [8]  pivot reciprocals of the running sweep
+    static constexpr int oEndF = oRdv + 8;
     // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
-    static constexpr int oE3 = oS;                             // [16][4*NGQ] E_s blocks of role A1 (lane-transposed)
-    static constexpr int oRc = oE3 + 16 * 4 * NGQ;             // [6][NA2]   dynamics-row coefficients
-    static constexpr int oPc = oRc + 6 * NA2;                  // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
+    static constexpr int oE3 = oS;                             // [16][4*NGQ] E_s blocks of role A1 (lane-transposed pairs)
+    static constexpr int oPc = oE3 + 16 * 4 * NGQ;             // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
     static constexpr int oVc = oPc + 5 * NA2;                  // [10][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv
     static constexpr int oS2 = oVc + 10 * NB;                  // [10][NB]   second row of each S^-1 block (role B)
     static constexpr int oEndA = oS2 + 10 * NB;
-    static_assert(oEndA * 8 <= 160 * 1024 - 512 && (oZ + D::n) * 8 <= 160 * 1024 - 512, "LDS budget (a 256-byte static block precedes the dynamic region)");
-    static constexpr int size = (oZ + D::n > oEndA) ? oZ + D::n : oEndA;
+    static constexpr int size = oEndF > oEndA ? oEndF : oEndA;
+    static_assert(size * 8 <= 160 * 1024 - 512, "LDS budget (a 256-byte static block precedes the dynamic region)");
+    static_assert(oGk + D::N * 8 * GS < (1 << 14), "assembly stream operand offsets are 14 bits");
 };
 
 // shared context of the role groups
@@ -256,7 +261,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     if (it > cfg.qp_iters) it = cfg.qp_iters;
     if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; }
 #ifdef MPCMP_STAMPS
-    if (tid == 0) { unsigned long long *o = c.ws.dbg + (size_t)c.b * 16; for (int k = 3; k < 15; k++) o[k] = stamp_acc[k]; o[15] = it; }
+    if (tid == 0) { unsigned long long *o = c.ws.dbg + (size_t)c.b * 16; for (int k = 3; k < 9; k++) o[k] = stamp_acc[k]; o[15] = it; }
 #endif
 }
 
@@ -296,7 +301,8 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     // constants live in LDS (lane-transposed), only the ADMM state (z, y) stays in registers
     const bool isPath = et < 8 * N;
     const int pk = et >> 3, prp = (et & 7) >> 1, phalf = et & 1;
-    double *pcl = lds + L::oPc + et, *rcl = lds + L::oRc + et;
+    double *pcl = lds + L::oPc + et;
+    const double *rcl = lds + L::oRv + (et < meq ? et : 0) * L::RS;    // dynamics-row coefficients (written by the prologue)
     double zg = 0, yg = 0;
     int myrow = 0;
     if (isPath) {
@@ -316,19 +322,15 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     double lgd = 0, zgd = 0, ygd = 0;
     int ix0 = 0, ixf = 0, ixT = 21;
     if (isDyn) {
-        const int r = et, k = r / 14, rr = r % 14, s = k / 3, i = k % 3;
+        const int r = et, k = r / 14, rr = r % 14, s = k / 3;
         ix0 = 3 * s * XS + rr;
         ixf = k * XS + ((rr < 7) ? 7 + rr : 14 + rr - 7);
         ixT = k * XS + 21;
-#pragma unroll
-        for (int j = 0; j < 4; j++) rcl[j * L::NA2] = c_D[4 * i + j];
-        rcl[4 * L::NA2] = -c.tsT;
-        rcl[5 * L::NA2] = -c.ts * c.ws.z[(size_t)b * n + ((rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7)];
         lgd = -c.ws.ceq[(size_t)b * meq + r];
     }
     auto row_dot_dyn = [&](const double *xe) -> double {
-        return rcl[0] * xe[ix0] + rcl[L::NA2] * xe[ix0 + XS] + rcl[2 * L::NA2] * xe[ix0 + 2 * XS] +
-               rcl[3 * L::NA2] * xe[ix0 + 3 * XS] + rcl[4 * L::NA2] * xe[ixf] + rcl[5 * L::NA2] * xe[ixT];
+        return rcl[0] * xe[ix0] + rcl[1] * xe[ix0 + XS] + rcl[2] * xe[ix0 + 2 * XS] + rcl[3] * xe[ix0 + 3 * XS] +
+               rcl[4] * xe[ixf] + rcl[5] * xe[ixT];
     };
     auto row_dot_path = [&](const double *xe) -> double {
         const double *g0 = gkl + groff, *g1 = g0 + GS, *xv = xe + xnoff;
@@ -385,12 +387,12 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             zgd = zn;
             const double w = rho_eq * zgd - ygd;
             wg[et] = w;
-            tpl[et] = rcl[5 * L::NA2] * w;
+            tpl[et] = rcl[5] * w;
             if (check) ys[et] = ygd;
         }
         __syncthreads();
         if (check) {
-            double sums[2] = {(isPath ? pcl[3 * L::NA2] * yg : 0.0) + (isDyn ? rcl[5 * L::NA2] * ygd : 0.0), 0.0};
+            double sums[2] = {(isPath ? pcl[3 * L::NA2] * yg : 0.0) + (isDyn ? rcl[5] * ygd : 0.0), 0.0};
             block_reduce16<2, false>(sums, red, tid);
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isPath) {
@@ -649,8 +651,16 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     }
 }
 
+// pass metadata of the assembly streams (structure.hpp: build_streams)
+struct Qp2Streams {
+    const uint32_t *words;
+    int npass;
+    int off[8], W[8];
+    int split_dst, split_scr, split_n;
+};
+
 template <int NSEG>
-__global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *fac_all) {
+__global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *fac_all, Qp2Streams st) {
     using D = Dim<NSEG>;
     using L = Qp2<NSEG>;
     constexpr int N = D::N, n = D::n, meq = D::meq, nJ = D::nJ, nI = D::nI, NT = L::NT;
@@ -677,6 +687,16 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
     const bool isVar = u >= 0 && u < n, isT = u == n - 1;
 
     for (int i = tid; i < L::oRed - L::oRhsJ; i += NT) lds[L::oRhsJ + i] = 0.0;     // exchanged vectors and their pads
+    // V = [dynamics-row coefficients | path Jacobians]: operands of the assembly, reused by the ADMM rows
+    for (int i = tid; i < N * 176; i += NT) gkl[(i / 22) * GS + (i % 22)] = Gkg[i];
+    for (int i = tid; i < meq * L::RS; i += NT) {
+        const int r = i / L::RS, a = i % L::RS, k = r / 14, rr = r % 14;
+        double v = 0.0;
+        if (a < 4) v = c_D[4 * (k % 3) + a];
+        else if (a == 4) v = -tsT;
+        else if (a == 5) v = -ts * zg_[(rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7];
+        lds[L::oRv + i] = v;
+    }
     __syncthreads();
     // ---- variable role (role B): only the Hessian/rho entries needed by the assembly are kept live here ----
     double v_diag = 0.0, v_ha = 0.0;
@@ -692,33 +712,22 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
     }
     STAMP(0);
     // ---------------- assembly + factorisation ----------------
-    double *S = lds + L::oS, *KJJ = lds + L::oKJJ, *KJC = lds + L::oKJC, *Eh = lds + L::oEh, *zl = lds + L::oZ;
-    for (int i = tid; i < N * 176; i += NT) gkl[(i / 22) * GS + (i % 22)] = Gkg[i];
-    for (int v = tid; v < n; v += NT) zl[v] = zg_[v];
-    __syncthreads();
-    auto term_val = [&](uint32_t t) -> double {
-        const int r = t >> 16, a = (t >> 8) & 255, cc = t & 255;
-        double va, vb, rho;
-        if (r < meq) {
-            const int k = r / 14, rr = r % 14, i = k % 3;
-            const int fc = (rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7;
-            const double cT = -ts * zl[fc];
-            va = a < 4 ? c_D[4 * i + a] : (a == 4 ? -tsT : cT);
-            vb = cc < 4 ? c_D[4 * i + cc] : (cc == 4 ? -tsT : cT);
-            rho = rho_eq;
-        } else {
-            const double *row = gkl + (r - meq) * GS;
-            va = row[a]; vb = row[cc];
-            rho = rho_in;
-        }
-        return rho * va * vb;
-    };
-    auto assemble = [&](int e0, int cnt, double *out) {
-        for (int e = tid; e < cnt; e += NT) {
-            double acc = 0.0;
-            const int t1 = ws.entry_ptr[e0 + e + 1];
-            for (int t = ws.entry_ptr[e0 + e]; t < t1; t++) acc += term_val(ws.terms[t]);
-            out[e] = acc;
+    double *F = lds + L::oS;                      // factor area: S | KJJ[NSEG] | KJC[HS] | Eh[HS] | scratch | rdv
+    double *S = F, *KJJ = lds + L::oKJJ, *KJC = lds + L::oKJC, *Eh = lds + L::oEh, *rdv = lds + L::oRdv;
+    const double *V = lds + L::oRv;
+    // one assembly pass: every thread interprets its own (load-balanced) word stream
+    auto run_pass = [&](int p) {
+        const uint32_t *wp = st.words + st.off[p] + tid;
+        const int W = st.W[p];
+        double acc = 0.0;
+        for (int w = 0; w < W; w++) {
+            const uint32_t x = wp[(size_t)w * NT];
+            if ((int)x >= 0) {
+                acc += ((x >> 28) & 1u ? rho_eq : rho_in) * V[x & 0x3fffu] * V[(x >> 14) & 0x3fffu];
+            } else if (x != 0xFFFFFFFFu) {
+                F[x & 0xFFFFFu] = acc;
+                acc = 0.0;
+            }
         }
     };
     auto tri_decode = [](int e, int &i, int &j) {
@@ -727,98 +736,123 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         while (i * (i + 1) / 2 > e) i--;
         j = e - i * (i + 1) / 2;
     };
-    // symmetric sweep of `nblk` packed nb x nb SPD blocks (stride bstride) in LDS: A <- -(A^-1);
-    // each thread owns up to EPT fixed entries (decoded once)
+    // symmetric sweep of `nblk` packed nb x nb SPD blocks (stride bstride) in LDS: A <- -(A^-1).
+    // Each thread owns up to EPT fixed entries (decoded once); the pivot reciprocal of the next step is produced in
+    // the second phase of the current one, so a step costs two barriers and no division on the critical path.
     auto sweep = [&](double *A, int nb, int cnt, int nblk, int bstride) {
-        constexpr int EPT = 4;
-        int ei[EPT], ej[EPT], eo[EPT], ek[EPT];
+        constexpr int EPT = 5;
+        int ei[EPT], ej[EPT], eo[EPT], eb[EPT];
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const int ge = tid + q * NT;
             if (ge < cnt * nblk) {
                 const int blk = ge / cnt, e = ge % cnt;
                 tri_decode(e, ei[q], ej[q]);
-                ek[q] = blk * bstride; eo[q] = blk * bstride + e;
-            } else { ei[q] = -1; ej[q] = 0; eo[q] = 0; ek[q] = 0; }
+                eb[q] = blk; eo[q] = blk * bstride + e;
+            } else { ei[q] = -1; ej[q] = 0; eo[q] = 0; eb[q] = 0; }
         }
         const int myblk = tid / nb, myi = tid % nb;
+        const bool colthread = tid < nb * nblk;
+        if (tid < nblk) {
+            const double d = A[tid * bstride];
+            if (!(d > 0.0)) status |= 2;
+            rdv[tid] = 1.0 / d;
+        }
+        __syncthreads();
         for (int k = 0; k < nb; k++) {
-            const int kk = packed(k, k);
-            double rdm = 0.0;
-            if (tid < nb * nblk) {
-                const double d = A[myblk * bstride + kk];
-                if (!(d > 0.0)) status |= 2;
-                rdm = 1.0 / d;
-            }
+            const int tk = k * (k + 1) / 2, kk = tk + k;
 #pragma unroll
             for (int q = 0; q < EPT; q++) {
-                if (ei[q] >= 0 && ei[q] != k && ej[q] != k) {
-                    const double rd = 1.0 / A[ek[q] + kk];
-                    A[eo[q]] -= A[ek[q] + packed(ei[q], k)] * (A[ek[q] + packed(ej[q], k)] * rd);
+                const int i = ei[q], j = ej[q];
+                if (i >= 0 && i != k && j != k) {
+                    const double *Ab = A + eb[q] * bstride;
+                    const int oi = i >= k ? i * (i + 1) / 2 + k : tk + i;
+                    const int oj = j >= k ? j * (j + 1) / 2 + k : tk + j;
+                    A[eo[q]] -= Ab[oi] * (Ab[oj] * rdv[eb[q]]);
                 }
             }
+            const double rdm = colthread ? rdv[myblk] : 0.0;
             __syncthreads();
-            if (tid < nb * nblk) {
+            if (colthread) {
                 double *Ab = A + myblk * bstride;
-                if (myi != k) Ab[packed(myi, k)] *= rdm;
+                if (myi != k) Ab[myi >= k ? myi * (myi + 1) / 2 + k : tk + myi] *= rdm;
                 else Ab[kk] = -rdm;
+                if (myi == k + 1) {             // pivot of the next step is final after the rank-1 update above
+                    const double d = Ab[(k + 1) * (k + 2) / 2 + k + 1];
+                    if (!(d > 0.0)) status |= 2;
+                    rdv[myblk] = 1.0 / d;
+                }
             }
             __syncthreads();
         }
     };
-    // interface block (base part)
-    assemble(NSEG * (D::JP + D::JC), D::SP, S);
+    // pass 0: interface block S and every interior diagonal block K_JJ,s
+    run_pass(0);
     __syncthreads();
-    if (isVar && ipos >= nJ) {
-        const int a = ipos - nJ;
-        S[packed(a, a)] += v_diag;
-        if (!isT) S[packed(nI - 1, a)] += v_ha;
+    if (isT && st.split_dst >= 0) {               // the T-T entry was accumulated in chunks
+        double acc = 0.0;
+        for (int q = 0; q < st.split_n; q++) acc += F[st.split_scr + q];
+        F[st.split_dst] = acc;
     }
     __syncthreads();
+    if (isVar) {
+        if (ipos >= nJ) {
+            const int a = ipos - nJ;
+            S[packed(a, a)] += v_diag;
+            if (!isT) S[packed(nI - 1, a)] += v_ha;
+        } else {
+            KJJ[(ipos / 49) * D::JP + packed(ipos % 49, ipos % 49)] += v_diag;
+        }
+    }
+    __syncthreads();
+    STAMP(9);
+    sweep(KJJ, 49, D::JP, NSEG, D::JP);            // K_JJ,s <- -G_s, all segments concurrently
+    STAMP(11);
     for (int s0 = 0; s0 < NSEG; s0 += L::HS) {
         const int nh = (NSEG - s0 < L::HS) ? NSEG - s0 : L::HS;
-        for (int h = 0; h < nh; h++) {
-            assemble((s0 + h) * (D::JP + D::JC), D::JP, KJJ + h * D::JP);
-            assemble((s0 + h) * (D::JP + D::JC) + D::JP, D::JC, KJC + h * D::JC);
-        }
+        run_pass(1 + s0 / L::HS);                  // coupling blocks K_JC of this segment group
         __syncthreads();
-        if (isVar && ipos < nJ && ipos / 49 >= s0 && ipos / 49 < s0 + nh) {
-            const int h = ipos / 49 - s0, li = ipos % 49;
-            KJJ[h * D::JP + packed(li, li)] += v_diag;
-            KJC[h * D::JC + li * 29 + 28] += v_ha;
-        }
+        if (isVar && ipos < nJ && ipos / 49 >= s0 && ipos / 49 < s0 + nh)
+            KJC[(ipos / 49 - s0) * D::JC + (ipos % 49) * 29 + 28] += v_ha;
         __syncthreads();
-        sweep(KJJ, 49, D::JP, nh, D::JP);           // KJJ <- -G
-        // E_h = G K_JC
+        STAMP(10);
+        // E_h = G K_JC  (one output per thread-iteration; row i of -G is walked along the packed triangle)
         for (int e = tid; e < nh * D::JC; e += NT) {
             const int h = e / D::JC, i = (e % D::JC) / 29, cc = e % 29;
-            const double *Gn = KJJ + h * D::JP, *Kc = KJC + h * D::JC + cc;
+            const double *Gn = KJJ + (s0 + h) * D::JP, *Kc = KJC + h * D::JC + cc;
             double acc = 0.0;
-            for (int j = 0; j < 49; j++) acc -= Gn[packed(i, j)] * Kc[j * 29];
+            const double *gi = Gn + i * (i + 1) / 2;
+            for (int j = 0; j <= i; j++) acc -= gi[j] * Kc[j * 29];
+            int o = (i + 1) * (i + 2) / 2 + i;
+            for (int j = i + 1; j < 49; j++) { acc -= Gn[o] * Kc[j * 29]; o += j + 1; }
             Eh[e] = acc;
         }
         __syncthreads();
+        STAMP(12);
         // S -= K_CJ E on the lower triangle of each 29x29 coupled block
         for (int h = 0; h < nh; h++) {
-            const int s = s0 + h;
+            const int sg = s0 + h;
             for (int e = tid; e < 29 * 30 / 2; e += NT) {
                 int ca, cb;
                 tri_decode(e, ca, cb);
+                const double *kc = KJC + h * D::JC + ca, *ec = Eh + h * D::JC + cb;
                 double acc = 0.0;
-                for (int i = 0; i < 49; i++) acc += KJC[h * D::JC + i * 29 + ca] * Eh[h * D::JC + i * 29 + cb];
-                const int ia = ca < 28 ? 14 * s + ca : nI - 1, ib = cb < 28 ? 14 * s + cb : nI - 1;
+                for (int i = 0; i < 49; i++) acc += kc[i * 29] * ec[i * 29];
+                const int ia = ca < 28 ? 14 * sg + ca : nI - 1, ib = cb < 28 ? 14 * sg + cb : nI - 1;
                 S[packed(ia, ib)] -= acc;
             }
             __syncthreads();      // consecutive segments update overlapping entries of S (shared node, T)
         }
+        STAMP(13);
         // park -G and E of this group in the per-problem HBM scratch; the role threads load their register blocks
         // from there once the whole factorisation is done (keeps the factorisation's register footprint small)
         for (int h = 0; h < nh; h++) {
             double *dst = fac + (s0 + h) * (D::JP + D::JC);
-            for (int e = tid; e < D::JP; e += NT) dst[e] = KJJ[h * D::JP + e];
+            for (int e = tid; e < D::JP; e += NT) dst[e] = KJJ[(s0 + h) * D::JP + e];
             for (int e = tid; e < D::JC; e += NT) dst[D::JP + e] = Eh[h * D::JC + e];
         }
         __syncthreads();
+        STAMP(14);
     }
     STAMP(1);
     sweep(S, nI, D::SP, 1, D::SP);                 // S <- -(S^-1)
@@ -828,7 +862,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         if (tid == 0 && any) ws.status[b] |= any;
     }
 #ifdef MPCMP_STAMPS
-    if (tid == 0) { unsigned long long *dbg = ws.dbg + (size_t)b * 16; for (int k = 0; k < 3; k++) dbg[k] = stamp_acc[k]; }
+    if (tid == 0) { unsigned long long *dbg = ws.dbg + (size_t)b * 16; for (int k = 0; k < 3; k++) dbg[k] = stamp_acc[k]; for (int k = 9; k < 15; k++) dbg[k] = stamp_acc[k]; }
 #endif
     if (tid < L::NA1) qp2_role_a1<NSEG>(c);
     else if (tid < L::NA1 + L::NA2) qp2_role_a2<NSEG>(c);

@@ -11,6 +11,7 @@
 //   interface I (nI)  = [x_0, x_3, .., x_3NSEG, u_{N-1}, T]
 //   interior s couples to the 29 interface entries C_s = [x_3s, x_3s+3, T].
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <vector>
 
@@ -141,6 +142,98 @@ inline bool build_tables(int nseg, StructureTables &T) {
         T.terms.insert(T.terms.end(), lists[e].begin(), lists[e].end());
     }
     T.entry_ptr[E] = (int)T.terms.size();
+    return true;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Load-balanced assembly streams for k_qp2.  The entries of one assembly pass are distributed over the NT threads
+// (longest-processing-time first) so that every thread evaluates about the same number of terms; thread t reads
+// word w at words[off + w*NT + t] (coalesced).  Word formats:
+//   term : bit31 = 0, bits 0-13 offA, bits 14-27 offB, bit 28 = equality row (rho_eq instead of rho)
+//          value = rho * V[offA] * V[offB], V = [dynamics-row coefficients (meq x RS) | path Jacobians (8N x GS)]
+//   store: bit31 = 1, bits 0-19 destination (doubles, relative to the factor area); flushes the accumulator
+//   nop  : 0xFFFFFFFF
+struct AsmStreams {
+    static constexpr int MAXPASS = 8;
+    int npass = 0;
+    int off[MAXPASS] = {0}, W[MAXPASS] = {0};
+    // entries with very many terms (the T-T diagonal: one term per general row) are split into chunks whose partial
+    // sums go to scratch slots; the owner adds them up in fixed order afterwards (deterministic)
+    int split_dst = -1, split_scr = 0, split_n = 0;
+    std::vector<uint32_t> words;
+};
+
+inline bool build_streams(int nseg, int NT, int HS, int GS, int RS, AsmStreams &A) {
+    const int N = 3 * nseg + 1, m = 14 * (N - 1) + 8 * N, meq = 14 * (N - 1);
+    const int nI = 14 * (nseg + 1) + 8, SP = nI * (nI + 1) / 2, JP = 1225, JC = 1421;
+    const int E = nseg * (JP + JC) + SP;
+    std::vector<std::vector<uint32_t>> lists(E);
+    std::vector<int> vars;
+    for (int r = 0; r < m; r++) {
+        row_vars(nseg, r, vars);
+        const int nz = (int)vars.size();
+        const int vbase = r < meq ? r * RS : meq * RS + (r - meq) * GS;
+        for (int a = 0; a < nz; a++)
+            for (int b = 0; b <= a; b++) {
+                const int e = entry_of(nseg, vars[a], vars[b]);
+                if (e < 0 || e >= E) return false;
+                const uint32_t oa = vbase + a, ob = vbase + b;
+                if (oa >= (1u << 14) || ob >= (1u << 14)) return false;
+                lists[e].push_back(oa | (ob << 14) | ((r < meq ? 1u : 0u) << 28));
+            }
+    }
+    // factor-area layout (doubles, relative): S | KJJ[nseg] | KJC[HS] | ...
+    const int oKJJ = SP, oKJC = SP + nseg * JP;
+    const int scr_base = SP + nseg * JP + 2 * HS * JC;      // scratch slots behind KJC[HS], Eh[HS]
+    struct Ent { int e; uint32_t dst; };
+    std::vector<std::vector<Ent>> passes;
+    {   // pass 0: interface block + every interior diagonal block
+        std::vector<Ent> p0;
+        for (int i = 0; i < SP; i++) p0.push_back({nseg * (JP + JC) + i, (uint32_t)i});
+        for (int s = 0; s < nseg; s++)
+            for (int i = 0; i < JP; i++) p0.push_back({s * (JP + JC) + i, (uint32_t)(oKJJ + s * JP + i)});
+        passes.push_back(p0);
+    }
+    for (int s0 = 0; s0 < nseg; s0 += HS) {   // one pass per segment group: coupling blocks
+        std::vector<Ent> pg;
+        for (int h = 0; h < HS && s0 + h < nseg; h++)
+            for (int i = 0; i < JC; i++) pg.push_back({(s0 + h) * (JP + JC) + JP + i, (uint32_t)(oKJC + h * JC + i)});
+        passes.push_back(pg);
+    }
+    if ((int)passes.size() > AsmStreams::MAXPASS) return false;
+    A.npass = (int)passes.size();
+    A.words.clear();
+    for (int p = 0; p < A.npass; p++) {
+        std::vector<Ent> ents = passes[p];
+        std::stable_sort(ents.begin(), ents.end(), [&](const Ent &x, const Ent &y) { return lists[x.e].size() > lists[y.e].size(); });
+        std::vector<std::vector<uint32_t>> th(NT);
+        // LPT: next entry goes to the currently shortest stream (ties: lowest thread id) — deterministic
+        auto shortest = [&]() { int best = 0; for (int t = 1; t < NT; t++) if (th[t].size() < th[best].size()) best = t; return best; };
+        for (const Ent &en : ents) {
+            const std::vector<uint32_t> &L = lists[en.e];
+            if (L.size() > 48) {            // split (only ever the T-T entry)
+                if (A.split_dst >= 0) return false;
+                const int chunk = 16, nc = ((int)L.size() + chunk - 1) / chunk;
+                A.split_dst = (int)en.dst; A.split_scr = scr_base; A.split_n = nc;
+                for (int c = 0; c < nc; c++) {
+                    const int t = shortest();
+                    for (int i = c * chunk; i < (c + 1) * chunk && i < (int)L.size(); i++) th[t].push_back(L[i]);
+                    th[t].push_back(0x80000000u | (uint32_t)(scr_base + c));
+                }
+                continue;
+            }
+            const int best = shortest();
+            for (uint32_t w : L) th[best].push_back(w);
+            th[best].push_back(0x80000000u | en.dst);
+        }
+        size_t W = 0;
+        for (int t = 0; t < NT; t++) W = std::max(W, th[t].size());
+        A.off[p] = (int)A.words.size(); A.W[p] = (int)W;
+        A.words.resize(A.words.size() + W * NT, 0xFFFFFFFFu);
+        for (int t = 0; t < NT; t++)
+            for (size_t w = 0; w < th[t].size(); w++) A.words[A.off[p] + w * NT + t] = th[t][w];
+    }
     return true;
 }
 

@@ -30,11 +30,13 @@ st = np.zeros((B, 16), dtype=np.uint64)
 capi.check(capi.lib().mpcmp_debug_stamps(s._ctx, B, st.ctypes.data_as(C.c_void_p)))
 st = st.astype(np.float64)
 its = st[:, 15]
-names = ["setup", "assemble+KJJ/E/S", "sweep S", "A(rhs)", "P1", "P2a", "P2b", "P3", "E"]
+names = ["setup", "factor J blocks (total)", "sweep S", "A(rhs)", "P1", "P2a+P2b", "P3", "E", "check/loop"]
 print("B=%d nseg=%d  mean ADMM iterations %.1f" % (B, nseg, its.mean()))
 for k, nm in enumerate(names):
     if k < 3:
-        print("%-18s %10.0f cycles (once)" % (nm, st[:, k].mean()))
+        print("%-26s %10.0f cycles (once)" % (nm, st[:, k].mean()))
     else:
-        print("%-18s %10.1f cycles / iteration" % (nm, (st[:, k] / its).mean()))
+        print("%-26s %10.1f cycles / iteration" % (nm, (st[:, k] / its).mean()))
 print("loop total %10.1f cycles / iteration" % ((st[:, 3:9].sum(axis=1) / its).mean()))
+for k, nm in zip(range(9, 15), ["  assemble K_JJ,K_JC", "  diag/arrow", "  sweep K_JJ", "  E = G K_JC", "  S -= K_CJ E", "  park to HBM"]):
+    print("%-26s %10.0f cycles (once, all segment groups)" % (nm, st[:, k].mean()))
