@@ -19,8 +19,10 @@ namespace mpcmp {
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    // every lane of the 16-lane row is a valid source for the permutations used here, so `old` is never selected:
+    // passing the source itself avoids a zero-initialising v_mov per half
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double sum2(double x) { return x + dpp_mov<0xB1>(x); }                  // lanes i, i^1
@@ -83,7 +85,7 @@ struct Qp2 {
     static constexpr int NA2 = (4 * NEQ + 63) / 64 * 64;           // role A2 threads (256)
     static constexpr int NB = NT - NA1 - NA2;                      // role B threads  (320)
     static constexpr int NPR = (D::nI + 1) / 2;                    // interface row pairs (39)
-    static constexpr int GS = 23;                                  // padded row stride of the path Jacobians in LDS
+    static constexpr int GS = 24;                                  // row stride of the path Jacobians in LDS (22 + 2 zero pads)
     static constexpr int XS = 24;                                  // node-major x~ stride: [x_k(14) u_k(7) T pad pad]
     static constexpr int HS = 2;                                   // segments factorised concurrently
     static constexpr int FAC = NSEG * (D::JP + D::JC);             // per-problem factor scratch in HBM (doubles)
@@ -218,11 +220,13 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         double t0, t1;
         {
             double a0 = 0.0, a1 = 0.0;
+            D2 bv[7];
 #pragma unroll
-            for (int j = 0; j < 14; j += 2) {
-                const D2 bv = lds2(bj + j);
-                a0 += m1[0][j] * bv.x; a1 += m1[1][j] * bv.x;
-                a0 += m1[0][j + 1] * bv.y; a1 += m1[1][j + 1] * bv.y;
+            for (int j = 0; j < 7; j++) bv[j] = lds2(bj + 2 * j);          // all operand reads in flight first
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
+                a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
             }
             t0 = sum4(a0); t1 = sum4(a1);
         }
@@ -235,11 +239,13 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         // ---- P3 ----
         {
             double a0 = 0.0, a1 = 0.0;
+            D2 xv[4], e0[4], e1[4];
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const D2 xv = lds2(xc + j), e0 = lds2(e3l + j * E3S), e1 = lds2(e3l + (8 + j) * E3S);
-                a0 += e0.x * xv.x; a1 += e1.x * xv.x;
-                a0 += e0.y * xv.y; a1 += e1.y * xv.y;
+            for (int j = 0; j < 4; j++) { xv[j] = lds2(xc + 2 * j); e0[j] = lds2(e3l + 2 * j * E3S); e1[j] = lds2(e3l + (8 + 2 * j) * E3S); }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                a0 += e0[j].x * xv[j].x; a1 += e1[j].x * xv[j].x;
+                a0 += e0[j].y * xv[j].y; a1 += e1[j].y * xv[j].y;
             }
             a0 = sum4(a0); a1 = sum4(a1);
             if (jdst >= 0) xn[jdst] = part ? (t1 - a1) : (t0 - a0);
@@ -315,8 +321,8 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         pcl[3 * L::NA2] = c.ws.Gk[((size_t)b * N + pk) * 176 + q * 22 + 21];
         pcl[4 * L::NA2] = 1.0 / pcl[2 * L::NA2];
     }
-    const int groff = isPath ? (pk * 8 + 2 * prp) * GS + phalf * 11 : 0;
-    const int xnoff = isPath ? pk * XS + phalf * 11 : 0;
+    const int groff = isPath ? (pk * 8 + 2 * prp) * GS + phalf * 12 : 0;     // columns 0..11 | 12..21 (+2 zero pads)
+    const int xnoff = isPath ? pk * XS + phalf * 12 : 0;
     // dynamics row owned by this lane
     const bool isDyn = et < meq;
     double lgd = 0, zgd = 0, ygd = 0;
@@ -336,7 +342,17 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         const double *g0 = gkl + groff, *g1 = g0 + GS, *xv = xe + xnoff;
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int cc = 0; cc < 11; cc++) { const double xc = xv[cc]; a0 += g0[cc] * xc; a1 += g1[cc] * xc; }
+        for (int h = 0; h < 3; h++) {                      // three batches of six 16-byte reads
+            D2 x2[2], p0[2], p1[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) { x2[j] = lds2(xv + 4 * h + 2 * j); p0[j] = lds2(g0 + 4 * h + 2 * j); p1[j] = lds2(g1 + 4 * h + 2 * j); }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                a0 += p0[j].x * x2[j].x; a1 += p1[j].x * x2[j].x;
+                a0 += p0[j].y * x2[j].y; a1 += p1[j].y * x2[j].y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         a0 = sum2(a0); a1 = sum2(a1);
         return phalf ? a1 : a0;
     };
@@ -350,11 +366,13 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         // ---- P1 ----
         {
             double a0 = 0.0, a1 = 0.0;
+            D2 bv[7];
 #pragma unroll
-            for (int j = 0; j < 14; j += 2) {
-                const D2 bv = lds2(bj + j);
-                a0 += m1[0][j] * bv.x; a1 += m1[1][j] * bv.x;
-                a0 += m1[0][j + 1] * bv.y; a1 += m1[1][j + 1] * bv.y;
+            for (int j = 0; j < 7; j++) bv[j] = lds2(bj + 2 * j);          // all operand reads in flight first
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
+                a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
             }
             a0 = sum4(a0); a1 = sum4(a1);
             if (pdst >= 0) partl[pdst] = part ? a1 : a0;
@@ -544,19 +562,28 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         }
     }
     auto col_gather = [&](const double *w) -> double {
-        double s = vcl[0] * w[v_rf];
-#pragma unroll
-        for (int i = 0; i < 3; i++) s += vcl[(1 + i) * L::NB] * w[v_rA + 14 * i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) s += vcl[(4 + i) * L::NB] * w[v_rB + 14 * i];
-        __builtin_amdgcn_sched_barrier(0);          // two batches of LDS reads (VGPR pressure of role B)
-        if (v_hasG) {
+        double s = 0.0;
+        if (v_hasG) {                                  // batch 1: path-row part (8 Jacobian entries, 4 x 16-byte w reads)
             const double *gc = gkl + v_gcol;
+            double gv[8];
+            D2 w2[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) s += gc[q * GS] * w[v_pb + q];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 8; q++) gv[q] = gc[q * GS];
 #pragma unroll
-            for (int q = 4; q < 8; q++) s += gc[q * GS] * w[v_pb + q];
+            for (int q = 0; q < 4; q++) w2[q] = lds2(w + v_pb + 2 * q);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { s += gv[2 * q] * w2[q].x; s += gv[2 * q + 1] * w2[q].y; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {                                              // batch 2: dynamics-row part
+            double cv[7], wv[7];
+            cv[0] = vcl[0]; wv[0] = w[v_rf];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { cv[1 + i] = vcl[(1 + i) * L::NB]; wv[1 + i] = w[v_rA + 14 * i]; }
+#pragma unroll
+            for (int i = 0; i < 3; i++) { cv[4 + i] = vcl[(4 + i) * L::NB]; wv[4 + i] = w[v_rB + 14 * i]; }
+#pragma unroll
+            for (int i = 0; i < 7; i++) s += cv[i] * wv[i];
         }
         return s;
     };
@@ -590,11 +617,13 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         if (isP2) {
             double a0 = 0.0, a1 = 0.0;
             const double *rv = rI + part2 * 10;
+            D2 r[5], sb2[5];
 #pragma unroll
-            for (int j = 0; j < 10; j += 2) {
-                const D2 r = lds2(rv + j), sb2 = lds2(s2l + j * L::NB);
-                a0 += s2[j] * r.x; a1 += sb2.x * r.x;
-                a0 += s2[j + 1] * r.y; a1 += sb2.y * r.y;
+            for (int j = 0; j < 5; j++) { r[j] = lds2(rv + 2 * j); sb2[j] = lds2(s2l + 2 * j * L::NB); }
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                a0 += s2[2 * j] * r[j].x; a1 += sb2[j].x * r[j].x;
+                a0 += s2[2 * j + 1] * r[j].y; a1 += sb2[j].y * r[j].y;
             }
             a0 = sum8(a0); a1 = sum8(a1);
             if (myIrow >= 0) {
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
 
     for (int i = tid; i < L::oRed - L::oRhsJ; i += NT) lds[L::oRhsJ + i] = 0.0;     // exchanged vectors and their pads
     // V = [dynamics-row coefficients | path Jacobians]: operands of the assembly, reused by the ADMM rows
-    for (int i = tid; i < N * 176; i += NT) gkl[(i / 22) * GS + (i % 22)] = Gkg[i];
+    for (int i = tid; i < N * 8 * GS; i += NT) gkl[i] = (i % GS < 22) ? Gkg[(i / GS) * 22 + i % GS] : 0.0;
     for (int i = tid; i < meq * L::RS; i += NT) {
         const int r = i / L::RS, a = i % L::RS, k = r / 14, rr = r % 14;
         double v = 0.0;
