@@ -113,8 +113,10 @@ struct Qp2 {
     static constexpr int oKJC = oKJJ + NSEG * D::JP;           // [HS][JC]
     static constexpr int oEh = oKJC + HS * D::JC;              // [HS][JC]
     static constexpr int oScr = oEh + HS * D::JC;              // [32] partial sums of split entries
-    static constexpr int oRdv = oScr + 32;                     // [8]  pivot reciprocals of the running sweep
-    static constexpr int oEndF = oRdv + 8;
+    static constexpr int oRdv = oScr + 32;                     // [2][4] pivot reciprocals of the running sweep (double buffered)
+    static constexpr int oCol = oRdv + 8;                      // [2][CB] current / next pivot column(s) of the sweep
+    static constexpr int CB = 4 * 64 > ((D::nI + 15) / 16 * 16) ? 4 * 64 : ((D::nI + 15) / 16 * 16);
+    static constexpr int oEndF = oCol + 2 * CB;
     // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
     static constexpr int oE3 = oS;                             // [16][4*NGQ] E_s blocks of role A1 (lane-transposed pairs)
     static constexpr int oPc = oE3 + 16 * 4 * NGQ;             // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
@@ -749,13 +751,19 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         const uint32_t *wp = st.words + st.off[p] + tid;
         const int W = st.W[p];
         double acc = 0.0;
-        for (int w = 0; w < W; w++) {
-            const uint32_t x = wp[(size_t)w * NT];
-            if ((int)x >= 0) {
-                acc += ((x >> 28) & 1u ? rho_eq : rho_in) * V[x & 0x3fffu] * V[(x >> 14) & 0x3fffu];
-            } else if (x != 0xFFFFFFFFu) {
-                F[x & 0xFFFFFu] = acc;
-                acc = 0.0;
+        for (int w0 = 0; w0 < W; w0 += 4) {
+            uint32_t xw[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) xw[q] = (w0 + q < W) ? wp[(size_t)(w0 + q) * NT] : 0xFFFFFFFFu;   // 4 loads in flight
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t x = xw[q];
+                if ((int)x >= 0) {
+                    acc += ((x >> 28) & 1u ? rho_eq : rho_in) * V[x & 0x3fffu] * V[(x >> 14) & 0x3fffu];
+                } else if (x != 0xFFFFFFFFu) {
+                    F[x & 0xFFFFFu] = acc;
+                    acc = 0.0;
+                }
             }
         }
     };
@@ -766,11 +774,15 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         j = e - i * (i + 1) / 2;
     };
     // symmetric sweep of `nblk` packed nb x nb SPD blocks (stride bstride) in LDS: A <- -(A^-1).
-    // Each thread owns up to EPT fixed entries (decoded once); the pivot reciprocal of the next step is produced in
-    // the second phase of the current one, so a step costs two barriers and no division on the critical path.
+    // Each thread keeps its (up to EPT) entries in registers for the whole sweep; per step only the pivot column and
+    // the pivot reciprocal travel through LDS (double buffered), so a step costs ONE barrier and no division outside
+    // the pivot owner:   a_ij -= a_ik a_jk / a_kk,   a_ik <- a_ik / a_kk,   a_kk <- -1 / a_kk.
     auto sweep = [&](double *A, int nb, int cnt, int nblk, int bstride) {
-        constexpr int EPT = 5;
-        int ei[EPT], ej[EPT], eo[EPT], eb[EPT];
+        constexpr int EPT = 5, CB = L::CB;
+        const int cst = nblk > 1 ? 64 : CB;          // column-buffer stride per block
+        double *colb = lds + L::oCol;
+        int ei[EPT], ej[EPT], eb[EPT], eo[EPT];
+        double val[EPT];
 #pragma unroll
         for (int q = 0; q < EPT; q++) {
             const int ge = tid + q * NT;
@@ -778,42 +790,43 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
                 const int blk = ge / cnt, e = ge % cnt;
                 tri_decode(e, ei[q], ej[q]);
                 eb[q] = blk; eo[q] = blk * bstride + e;
-            } else { ei[q] = -1; ej[q] = 0; eo[q] = 0; eb[q] = 0; }
-        }
-        const int myblk = tid / nb, myi = tid % nb;
-        const bool colthread = tid < nb * nblk;
-        if (tid < nblk) {
-            const double d = A[tid * bstride];
-            if (!(d > 0.0)) status |= 2;
-            rdv[tid] = 1.0 / d;
+                val[q] = A[eo[q]];
+                if (ej[q] == 0) {                    // column 0 (and its pivot reciprocal)
+                    colb[blk * cst + ei[q]] = val[q];
+                    if (ei[q] == 0) { if (!(val[q] > 0.0)) status |= 2; rdv[blk] = 1.0 / val[q]; }
+                }
+            } else { ei[q] = -1; ej[q] = 0; eo[q] = 0; eb[q] = 0; val[q] = 0.0; }
         }
         __syncthreads();
+        // invalid slots point at entry (0,0) of block 0 and never publish: the update below is branch-free
+        bool live[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; q++) { live[q] = ei[q] >= 0; if (!live[q]) ei[q] = 0; }
         for (int k = 0; k < nb; k++) {
-            const int tk = k * (k + 1) / 2, kk = tk + k;
+            const double *cur = colb + (k & 1) * CB, *rdc = rdv + (k & 1) * 4;
+            double *nxt = colb + ((k + 1) & 1) * CB, *rdn = rdv + ((k + 1) & 1) * 4;
+            double pv = 0.0;             // value of the next pivot if this thread owns it
+            int pblk = -1;
 #pragma unroll
             for (int q = 0; q < EPT; q++) {
                 const int i = ei[q], j = ej[q];
-                if (i >= 0 && i != k && j != k) {
-                    const double *Ab = A + eb[q] * bstride;
-                    const int oi = i >= k ? i * (i + 1) / 2 + k : tk + i;
-                    const int oj = j >= k ? j * (j + 1) / 2 + k : tk + j;
-                    A[eo[q]] -= Ab[oi] * (Ab[oj] * rdv[eb[q]]);
-                }
+                const double *cb = cur + eb[q] * cst;
+                const double rd = rdc[eb[q]], ci = cb[i], cj = cb[j];
+                const double upd = val[q] - ci * (cj * rd);
+                const double colv = (j == k ? ci : cj) * rd;
+                const bool ik = i == k, jk = j == k;
+                const double v = (ik && jk) ? -rd : ((ik || jk) ? colv : upd);
+                val[q] = v;
+                const bool pub = live[q] && (j == k + 1 || i == k + 1);
+                if (pub) nxt[eb[q] * cst + (j == k + 1 ? i : j)] = v;
+                if (pub && i == k + 1 && j == k + 1) { pv = v; pblk = eb[q]; }
             }
-            const double rdm = colthread ? rdv[myblk] : 0.0;
-            __syncthreads();
-            if (colthread) {
-                double *Ab = A + myblk * bstride;
-                if (myi != k) Ab[myi >= k ? myi * (myi + 1) / 2 + k : tk + myi] *= rdm;
-                else Ab[kk] = -rdm;
-                if (myi == k + 1) {             // pivot of the next step is final after the rank-1 update above
-                    const double d = Ab[(k + 1) * (k + 2) / 2 + k + 1];
-                    if (!(d > 0.0)) status |= 2;
-                    rdv[myblk] = 1.0 / d;
-                }
-            }
+            if (pblk >= 0) { if (!(pv > 0.0)) status |= 2; rdn[pblk] = 1.0 / pv; }
             __syncthreads();
         }
+#pragma unroll
+        for (int q = 0; q < EPT; q++) if (live[q]) A[eo[q]] = val[q];
+        __syncthreads();
     };
     // pass 0: interface block S and every interior diagonal block K_JJ,s
     run_pass(0);
@@ -845,16 +858,41 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
             KJC[(ipos / 49 - s0) * D::JC + (ipos % 49) * 29 + 28] += v_ha;
         __syncthreads();
         STAMP(10);
-        // E_h = G K_JC  (one output per thread-iteration; row i of -G is walked along the packed triangle)
-        for (int e = tid; e < nh * D::JC; e += NT) {
-            const int h = e / D::JC, i = (e % D::JC) / 29, cc = e % 29;
-            const double *Gn = KJJ + (s0 + h) * D::JP, *Kc = KJC + h * D::JC + cc;
-            double acc = 0.0;
-            const double *gi = Gn + i * (i + 1) / 2;
-            for (int j = 0; j <= i; j++) acc -= gi[j] * Kc[j * 29];
-            int o = (i + 1) * (i + 2) / 2 + i;
-            for (int j = i + 1; j < 49; j++) { acc -= Gn[o] * Kc[j * 29]; o += j + 1; }
-            Eh[e] = acc;
+        // E_h = G K_JC: a thread produces a 2 x 4 block (rows 2rp, 2rp+1; columns 4cq..4cq+3, cq < 7) so every LDS operand
+        // feeds two or four FMAs, or one entry of the T column (column 28); rows of -G are walked along the packed triangle
+        for (int t = tid; t < nh * (25 * 7 + 49); t += NT) {
+            const int h = t / (25 * 7 + 49), tt = t % (25 * 7 + 49);
+            const double *Gn = KJJ + (s0 + h) * D::JP, *Kc = KJC + h * D::JC;
+            double *Eo = Eh + h * D::JC;
+            if (tt < 25 * 7) {
+                const int rp = tt / 7, c0 = 4 * (tt % 7);
+                const int r0 = 2 * rp, r1 = (2 * rp + 1 < 49) ? 2 * rp + 1 : r0;
+                const int t0 = r0 * (r0 + 1) / 2, t1 = r1 * (r1 + 1) / 2;
+                double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+                int tj = 0;
+                for (int j = 0; j < 49; j++) {
+                    tj += j;                                   // j (j+1) / 2 - j ... running triangular base of row j
+                    const double g0 = Gn[j <= r0 ? t0 + j : tj + r0];
+                    const double g1 = Gn[j <= r1 ? t1 + j : tj + r1];
+                    const double *kr = Kc + j * 29 + c0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { a0[q] -= g0 * kr[q]; a1[q] -= g1 * kr[q]; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    Eo[r0 * 29 + c0 + q] = a0[q];
+                    if (r1 != r0) Eo[r1 * 29 + c0 + q] = a1[q];
+                }
+            } else {
+                const int r0 = tt - 25 * 7, t0 = r0 * (r0 + 1) / 2;
+                double acc = 0.0;
+                int tj = 0;
+                for (int j = 0; j < 49; j++) {
+                    tj += j;
+                    acc -= Gn[j <= r0 ? t0 + j : tj + r0] * Kc[j * 29 + 28];
+                }
+                Eo[r0 * 29 + 28] = acc;
+            }
         }
         __syncthreads();
         STAMP(12);
