@@ -135,6 +135,13 @@ def main():
         alg_bytes_launch = B * BYTES_PER_TRAJ / SQP_ITERS
         achieved_gbs = alg_bytes_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         qp_flops_launch = B * (flops_traj / SQP_ITERS)
+        traffic = None
+        try:    # HBM bytes per k_qp2 launch from the committed rocprofv3 PMC passes (see profiles/r01_traffic.json)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("kernel") == kname and B == 1024:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "trajectories/sec, 7-DoF Panda min-time OCP, 1k batch @ 1/2/4/8 GPU",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -145,7 +152,7 @@ def main():
                                    % (B, N, NUM_SEG, SQP_ITERS),
                        "batch_per_gpu": B, "seed": scenarios.SEED, "margins": list(MARGINS)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY.md 8d); see fp64"},

@@ -55,10 +55,13 @@ __device__ __forceinline__ M3 joint_rot(const double *A, double s, double c) {
 
 // tau = RNEA(q,v,a); if TANGENT also dtau = d tau / d theta with theta = (q|v|a)_j  (type 0|1|2).
 // sc: [7][2] = sin, cos of the joint angles.
-template <bool TANGENT>
+// tw (optional, TANGENT only): lane-private LDS area for the tangent wrenches dF, dN (42 doubles, element e of this
+// lane at tw[e * tws]); keeps the per-thread VGPR footprint below the spill threshold in the 320-thread kernels.
+template <bool TANGENT, bool TW_LDS = false>
 __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, const double *sc, const double *v,
-                                         const double *a, int type, int j, double *tau, double *dtau) {
-    V3 F[7], N[7], dF[7], dN[7];
+                                         const double *a, int type, int j, double *tau, double *dtau,
+                                         double *tw = nullptr, int tws = 0) {
+    V3 F[7], N[7], dF[TW_LDS ? 1 : 7], dN[TW_LDS ? 1 : 7];
     V3 w = mk(0, 0, 0), wd = mk(0, 0, 0), al = mk(-M->gravity[0], -M->gravity[1], -M->gravity[2]);
     V3 dw = mk(0, 0, 0), dwd = mk(0, 0, 0), dal = mk(0, 0, 0);
 #pragma unroll
@@ -87,8 +90,12 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
             const V3 dwdn = mk(dud.x + du.y * vi + u.y * dv, dud.y - du.x * vi - u.x * dv, dud.z + da);
             const V3 daln = mulT(R, db) - zcross(aln, dq);
             const V3 dac = daln + cross(dwdn, c) + cross(dwn, wxc) + cross(wn, cross(dwn, c));
-            dF[i] = M->mass[i] * dac;
-            dN[i] = mulI(M->I[i], dwdn) + cross(dwn, Iw) + cross(wn, mulI(M->I[i], dwn));
+            const V3 dFi = M->mass[i] * dac;
+            const V3 dNi = mulI(M->I[i], dwdn) + cross(dwn, Iw) + cross(wn, mulI(M->I[i], dwn));
+            if (TW_LDS) {
+                tw[(6 * i + 0) * tws] = dFi.x; tw[(6 * i + 1) * tws] = dFi.y; tw[(6 * i + 2) * tws] = dFi.z;
+                tw[(6 * i + 3) * tws] = dNi.x; tw[(6 * i + 4) * tws] = dNi.y; tw[(6 * i + 5) * tws] = dNi.z;
+            } else { dF[i] = dFi; dN[i] = dNi; }
             dw = dwn; dwd = dwdn; dal = daln;
         }
         w = wn; wd = wdn; al = aln;
@@ -99,7 +106,14 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
         const V3 c = ld3(M->com[i]);
         V3 fi = F[i], ni = N[i] + cross(c, F[i]);
         V3 dfi = mk(0, 0, 0), dni = mk(0, 0, 0);
-        if (TANGENT) { dfi = dF[i]; dni = dN[i] + cross(c, dF[i]); }
+        if (TANGENT) {
+            V3 dFi, dNi;
+            if (TW_LDS) {
+                dFi = mk(tw[(6 * i + 0) * tws], tw[(6 * i + 1) * tws], tw[(6 * i + 2) * tws]);
+                dNi = mk(tw[(6 * i + 3) * tws], tw[(6 * i + 4) * tws], tw[(6 * i + 5) * tws]);
+            } else { dFi = dF[i]; dNi = dN[i]; }
+            dfi = dFi; dni = dNi + cross(c, dFi);
+        }
         if (i < 6) {
             const M3 R = joint_rot(M->R0[i + 1], sc[2 * (i + 1)], sc[2 * (i + 1) + 1]);
             const V3 p = ld3(M->p[i + 1]);

@@ -105,6 +105,7 @@ __device__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__re
     constexpr int N = D::N;
     double *sc = scr;               // [N][14]
     double *raw = scr + N * 14;     // [N][7][21]
+    double *tw = raw + N * 147;     // [42][NT] tangent wrenches of rnea_dir (lane-transposed)
     for (int t = tid; t < N * 7; t += D::NT) {
         double s, c;
         sincos(zl[14 * (t / 7) + (t % 7)], &s, &c);
@@ -117,7 +118,7 @@ __device__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__re
         const double *v = zl + 14 * k + 7, *a = zl + 14 * N + 7 * k;
         if (d < 21) {
             double tau[7], dtau[7];
-            rnea_dir<true>(mdl, q_sc, v, a, d / 7, d % 7, tau, dtau);
+            rnea_dir<true, true>(mdl, q_sc, v, a, d / 7, d % 7, tau, dtau, tw + tid, D::NT);
 #pragma unroll
             for (int i = 0; i < 7; i++) raw[(k * 7 + i) * 21 + d] = dtau[i];
             if (d == 0) {
@@ -169,7 +170,7 @@ __device__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__re
 }
 
 template <int NSEG>
-struct LinLds { static constexpr int size = Dim<NSEG>::N * (14 + 147); };
+struct LinLds { static constexpr int size = Dim<NSEG>::N * (14 + 147) + 42 * Dim<NSEG>::NT; };
 
 // ------------------------------------------------------------------------------------------------
 // k_init
