@@ -138,6 +138,15 @@ int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double 
 int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sol_x, const double *d_sol_u,
                               const double *d_sol_T, int n_pts, double *d_out, void *hip_stream);
 
+/* ---- receding-horizon driver (BASELINE.json config #5) ---- */
+/* B instances; every step = re-solve warm-started from the previous solution with the reference's re-guess rule
+ * (head := current state, tail := target; motionPlanner.cpp:199-207), then the current state advances along the
+ * new solution by dt (MotionPlanner::get_MPC_point, motionPlanner.hpp:118-128).  The first step uses the built-in
+ * initialiser.  use_graph != 0 replays one hipGraph-captured step (fixed iteration counts: no host round trip). */
+int mpcmp_rh_init(mpcmp_ctx *ctx, int B, const double *x0, const double *xf);
+int mpcmp_rh_run(mpcmp_ctx *ctx, int steps, double dt, int use_graph);
+int mpcmp_rh_get(mpcmp_ctx *ctx, double *x0_now, double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info);
+
 /* ---- measurement hooks used by bench.py ---- */
 /* name and accumulated device time (ms, HIP events on the solve stream) of the dominant kernel since the
  * last reset; launches = number of launches accumulated. */

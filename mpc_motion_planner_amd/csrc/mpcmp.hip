@@ -43,6 +43,13 @@ struct mpcmp_ctx {
     double qp_ms = 0.0;
     int qp_launches = 0;
     bool timing = true;
+    bool capturing = false;
+    // receding-horizon state (mpcmp_rh_*)
+    int rh_B = 0;
+    bool rh_first = true;
+    hipGraph_t rh_graph = nullptr;
+    hipGraphExec_t rh_exec = nullptr;
+    double rh_dt = 0.0;
 };
 
 static thread_local std::string g_err;
@@ -315,6 +322,8 @@ extern "C" const char *mpcmp_last_error(const mpcmp_ctx *ctx) { return ctx ? ctx
 extern "C" int mpcmp_destroy(mpcmp_ctx *ctx) {
     if (!ctx) return MPCMP_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->rh_exec) (void)hipGraphExecDestroy(ctx->rh_exec);
+    if (ctx->rh_graph) (void)hipGraphDestroy(ctx->rh_graph);
     for (void *p : ctx->allocs) (void)hipFree(p);
     for (auto &e : ctx->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -408,7 +417,7 @@ static hipEvent_t *next_events(mpcmp_ctx *ctx) {
 template <int NSEG>
 static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_wx,
                       const double *d_wu, const double *d_wT, double *d_sx, double *d_su, double *d_sT,
-                      mpcmp_info *d_info, hipStream_t st, int only_qp) {
+                      mpcmp_info *d_info, hipStream_t st, int only_qp, int reguess = 0) {
     using D = Dim<NSEG>;
     WS w = ctx->ws;
     w.x0 = d_x0; w.xf = d_xf;
@@ -422,10 +431,10 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
     else if (int rc = set_lds(ctx, k_qp<NSEG>, l_qp)) return rc;
     if (int rc = set_lds(ctx, k_step<NSEG>, l_step)) return rc;
-    hipLaunchKernelGGL(k_init<NSEG>, dim3(B), dim3(D::NT), l_init, st, ctx->cfg, w, d_wx, d_wu, d_wT);
+    hipLaunchKernelGGL(k_init<NSEG>, dim3(B), dim3(D::NT), l_init, st, ctx->cfg, w, d_wx, d_wu, d_wT, reguess);
     const int iters = only_qp ? 1 : ctx->cfg.sqp_iters;
     for (int it = 0; it < iters; it++) {
-        hipEvent_t *ev = ctx->timing ? next_events(ctx) : nullptr;
+        hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
         if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
         if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(B), dim3(1024), l_qp2, st, ctx->cfg, w, ctx->d_fac, ctx->streams);
         else hipLaunchKernelGGL(k_qp<NSEG>, dim3(B), dim3(D::NT), l_qp, st, ctx->cfg, w);
@@ -440,7 +449,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
 
 static int solve_dispatch(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_wx,
                           const double *d_wu, const double *d_wT, double *d_sx, double *d_su, double *d_sT,
-                          mpcmp_info *d_info, hipStream_t st, int only_qp) {
+                          mpcmp_info *d_info, hipStream_t st, int only_qp, int reguess = 0) {
     if (!ctx) return MPCMP_EINVAL;
     if (B < 1) return MPCMP_EINVAL;
     if (B > ctx->max_batch) { ctx->err = "batch exceeds the context capacity"; return MPCMP_ETOOBIG; }
@@ -448,10 +457,10 @@ static int solve_dispatch(mpcmp_ctx *ctx, int B, const double *d_x0, const doubl
     if ((d_wx != nullptr) != (d_wu != nullptr) || (d_wx != nullptr) != (d_wT != nullptr)) { ctx->err = "warm_x, warm_u, warm_T must be all given or all NULL"; return MPCMP_EINVAL; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     switch (ctx->nseg) {
-        case 1: return solve_impl<1>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp);
-        case 2: return solve_impl<2>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp);
-        case 4: return solve_impl<4>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp);
-        case 6: return solve_impl<6>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp);
+        case 1: return solve_impl<1>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
+        case 2: return solve_impl<2>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
+        case 4: return solve_impl<4>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
+        case 6: return solve_impl<6>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
     }
     return MPCMP_EINVAL;
 }
@@ -503,7 +512,7 @@ extern "C" int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, c
     WS w = ctx->ws; w.x0 = ctx->d_x0; w.xf = ctx->d_xf;
     int rc = MPCMP_OK;
 #define LAUNCH_INIT(NS) { size_t l = InitLds<NS>::size * sizeof(double); rc = set_lds(ctx, k_init<NS>, l); \
-        if (!rc) hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr); }
+        if (!rc) hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); }
     switch (ctx->nseg) { case 1: LAUNCH_INIT(1) break; case 2: LAUNCH_INIT(2) break; case 4: LAUNCH_INIT(4) break; case 6: LAUNCH_INIT(6) break; }
 #undef LAUNCH_INIT
     if (rc) return rc;
@@ -610,6 +619,82 @@ extern "C" int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sx, const
     HIPCHK(ctx, hipMemcpyAsync(dT, sT, sizeof(double) * B, hipMemcpyHostToDevice, st));
     if (int rc = mpcmp_sample_batch_device(ctx, B, dx, du, dT, n_pts, dout, st)) return rc;
     HIPCHK(ctx, hipMemcpyAsync(out, dout, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// receding-horizon driver (BASELINE config #5): B instances, every step = warm-started re-solve from the previous
+// solution (re-guess rule of motionPlanner.cpp:199-207) + state advance along the new solution
+// (get_MPC_point, motionPlanner.hpp:118-128).  The fixed launch sequence of one step is captured in a hipGraph.
+extern "C" int mpcmp_rh_init(mpcmp_ctx *ctx, int B, const double *x0, const double *xf) {
+    if (!ctx || !x0 || !xf || B < 1) return MPCMP_EINVAL;
+    if (B > ctx->max_batch) return MPCMP_ETOOBIG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    ctx->rh_B = B; ctx->rh_first = true;
+    if (ctx->rh_exec) { (void)hipGraphExecDestroy(ctx->rh_exec); ctx->rh_exec = nullptr; }
+    if (ctx->rh_graph) { (void)hipGraphDestroy(ctx->rh_graph); ctx->rh_graph = nullptr; }
+    return MPCMP_OK;
+}
+
+static int rh_enqueue_step(mpcmp_ctx *ctx, double dt, bool first, hipStream_t st) {
+    const int B = ctx->rh_B;
+    const double *wx = first ? nullptr : ctx->d_sx, *wu = first ? nullptr : ctx->d_su, *wT = first ? nullptr : ctx->d_sT;
+    if (int rc = solve_dispatch(ctx, B, ctx->d_x0, ctx->d_xf, wx, wu, wT, ctx->d_sx, ctx->d_su, ctx->d_sT, ctx->d_info, st, 0,
+                                first ? 0 : 1))
+        return rc;
+    hipLaunchKernelGGL(k_advance, dim3((B * 14 + 255) / 256), dim3(256), 0, st, ctx->nseg, B, dt, ctx->d_sx, ctx->d_sT, ctx->d_x0);
+    HIPCHK(ctx, hipGetLastError());
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_rh_run(mpcmp_ctx *ctx, int steps, double dt, int use_graph) {
+    if (!ctx || steps < 1 || !(dt > 0.0) || ctx->rh_B < 1) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int done = 0;
+    if (ctx->rh_first) {                       // first solve: built-in initialiser, not part of the graph
+        if (int rc = rh_enqueue_step(ctx, dt, true, st)) return rc;
+        ctx->rh_first = false; done = 1;
+    }
+    if (use_graph && steps - done > 0) {
+        if (!ctx->rh_exec || ctx->rh_dt != dt) {
+            if (ctx->rh_exec) { (void)hipGraphExecDestroy(ctx->rh_exec); ctx->rh_exec = nullptr; }
+            if (ctx->rh_graph) { (void)hipGraphDestroy(ctx->rh_graph); ctx->rh_graph = nullptr; }
+            ctx->capturing = true;
+            HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = rh_enqueue_step(ctx, dt, false, st);
+            hipError_t e = hipStreamEndCapture(st, &ctx->rh_graph);
+            ctx->capturing = false;
+            if (rc) return rc;
+            HIPCHK(ctx, e);
+            HIPCHK(ctx, hipGraphInstantiate(&ctx->rh_exec, ctx->rh_graph, nullptr, nullptr, 0));
+            ctx->rh_dt = dt;
+        }
+        for (; done < steps; done++) HIPCHK(ctx, hipGraphLaunch(ctx->rh_exec, st));
+    } else {
+        for (; done < steps; done++)
+            if (int rc = rh_enqueue_step(ctx, dt, false, st)) return rc;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_rh_get(mpcmp_ctx *ctx, double *x0_now, double *sx, double *su, double *sT, mpcmp_info *info) {
+    if (!ctx || ctx->rh_B < 1) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t B = ctx->rh_B, N = ctx->N;
+    hipStream_t st = ctx->stream;
+    if (x0_now) HIPCHK(ctx, hipMemcpyAsync(x0_now, ctx->d_x0, sizeof(double) * 14 * B, hipMemcpyDeviceToHost, st));
+    if (sx) HIPCHK(ctx, hipMemcpyAsync(sx, ctx->d_sx, sizeof(double) * 14 * N * B, hipMemcpyDeviceToHost, st));
+    if (su) HIPCHK(ctx, hipMemcpyAsync(su, ctx->d_su, sizeof(double) * 7 * N * B, hipMemcpyDeviceToHost, st));
+    if (sT) HIPCHK(ctx, hipMemcpyAsync(sT, ctx->d_sT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    if (info) HIPCHK(ctx, hipMemcpyAsync(info, ctx->d_info, sizeof(mpcmp_info) * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return MPCMP_OK;
 }

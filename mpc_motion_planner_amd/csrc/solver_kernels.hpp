@@ -95,6 +95,12 @@ __device__ __forceinline__ void var_box(const mpcmp_config &c, const double *x0,
     } else { lo = c.lbT; hi = c.ubT; }
 }
 
+template <int NSEG>
+struct LinLds {
+    static constexpr bool TW = (NSEG <= 4);     // tangent wrenches parked in LDS (does not fit next to the rest for N = 19)
+    static constexpr int size = Dim<NSEG>::N * (14 + 147) + (TW ? 42 * Dim<NSEG>::NT : 0);
+};
+
 // ------------------------------------------------------------------------------------------------
 // Linearisation of all nodes of one problem (block-wide). zl: iterate in LDS (external order).
 // scr: LDS scratch of N*14 + N*147 + N*7 doubles. Writes g [8N], Gk [N][8][22], ceq [meq] (global).
@@ -118,7 +124,7 @@ __device__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__re
         const double *v = zl + 14 * k + 7, *a = zl + 14 * N + 7 * k;
         if (d < 21) {
             double tau[7], dtau[7];
-            rnea_dir<true, true>(mdl, q_sc, v, a, d / 7, d % 7, tau, dtau, tw + tid, D::NT);
+            rnea_dir<true, LinLds<NSEG>::TW>(mdl, q_sc, v, a, d / 7, d % 7, tau, dtau, tw + tid, D::NT);
 #pragma unroll
             for (int i = 0; i < 7; i++) raw[(k * 7 + i) * 21 + d] = dtau[i];
             if (d == 0) {
@@ -169,14 +175,12 @@ __device__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__re
     __syncthreads();
 }
 
-template <int NSEG>
-struct LinLds { static constexpr int size = Dim<NSEG>::N * (14 + 147) + 42 * Dim<NSEG>::NT; };
 
 // ------------------------------------------------------------------------------------------------
 // k_init
 template <int NSEG>
 __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, WS ws, const double *warm_x,
-                                                        const double *warm_u, const double *warm_T) {
+                                                        const double *warm_u, const double *warm_T, int reguess) {
     using D = Dim<NSEG>;
     constexpr int N = D::N, n = D::n;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -189,6 +193,9 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, WS ws,
             if (v < 14 * N) val = warm_x[(size_t)b * 14 * N + v];
             else if (v < 21 * N) val = warm_u[(size_t)b * 7 * N + (v - 14 * N)];
             else val = warm_T[b];
+            // re-guess from the previous solution: "Fix initial and final point at correct place" (motionPlanner.cpp:199-207)
+            if (reguess && v < 14) val = x0[v];
+            if (reguess && v >= 14 * (N - 1) && v < 14 * N) val = xf[v - 14 * (N - 1)];
             zl[v] = val;
         }
     } else {
@@ -903,6 +910,31 @@ __global__ __launch_bounds__(128) void k_sample(const mpcmp_model *mdl, int nseg
     o[0] = t * sT[b];
 #pragma unroll
     for (int r = 0; r < 7; r++) { o[1 + r] = q[r]; o[8 + r] = v[r]; o[15 + r] = a[r]; o[22 + r] = tau[r]; }
+}
+
+
+// Receding horizon: x0 <- MPC solution evaluated at physical time dt (MotionPlanner::get_MPC_point, motionPlanner.hpp:118-128,
+// including its clamp: for dt >= T the normalised time is set to T, not 1).  One thread per (problem, state component).
+__global__ __launch_bounds__(256) void k_advance(int nseg, int B, double dt, const double *sx, const double *sT, double *x0) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * 14) return;
+    const int b = gid / 14, r = gid % 14, N = 3 * nseg + 1;
+    const double T = sT[b];
+    const double t = (dt < T) ? dt / T : T;
+    const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    int s = (int)floor(t * nseg);
+    if (s >= nseg) s = nseg - 1;
+    if (s < 0) s = 0;
+    const double xx = 2.0 * (t * nseg - s) - 1.0;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double w = 1.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k != j) w *= (xx - xi[k]) / (xi[j] - xi[k]);
+        acc += w * sx[(size_t)b * 14 * N + 14 * (3 * s + j) + r];
+    }
+    x0[gid] = acc;
 }
 
 }  // namespace mpcmp

@@ -92,6 +92,22 @@ class Solver:
         check(lib().mpcmp_sample_batch_device(self._ctx, int(B), vp(sol_x), vp(sol_u), vp(sol_T), int(n_pts), vp(out),
                                               vp(stream or None)), self._ctx)
 
+    # -- receding horizon (BASELINE config #5)
+    def rh_init(self, x0, xf):
+        x0, xf = f64(x0), f64(xf)
+        self._rh_B = x0.shape[0]
+        check(lib().mpcmp_rh_init(self._ctx, self._rh_B, dp(x0), dp(xf)), self._ctx)
+
+    def rh_run(self, steps, dt, use_graph=True):
+        check(lib().mpcmp_rh_run(self._ctx, int(steps), C.c_double(dt), int(bool(use_graph))), self._ctx)
+
+    def rh_get(self):
+        B = self._rh_B
+        x0 = np.zeros((B, 14)); sx, su, sT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
+        info = np.zeros(B, dtype=capi.INFO_DTYPE)
+        check(lib().mpcmp_rh_get(self._ctx, dp(x0), dp(sx), dp(su), dp(sT), info.ctypes.data_as(C.c_void_p)), self._ctx)
+        return x0, sx, su, sT, info
+
     def kernel_timing(self, reset=False):
         name = C.c_char_p(); ms = C.c_double(); nl = C.c_int()
         check(lib().mpcmp_kernel_timing(self._ctx, int(reset), C.byref(name), C.byref(ms), C.byref(nl)), self._ctx)

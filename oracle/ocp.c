@@ -535,3 +535,27 @@ void orc_sample(const orc_model *mdl, int num_seg, const double *xs, const doubl
         memcpy(o + 1, q, sizeof q); memcpy(o + 8, v, sizeof v); memcpy(o + 15, a, sizeof a); memcpy(o + 22, tau, sizeof tau);
     }
 }
+
+/* MotionPlanner::get_MPC_point (motionPlanner.hpp:118-128): solution at physical time `time`, with the reference's
+   clamp (time >= T -> normalised time := T, not 1).  out: q(7), v(7), a(7), tau(7). */
+void orc_mpc_point(const orc_model *mdl, int num_seg, const double *xs, const double *us, double T, double time, double *out) {
+    static const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    double t = (time < T) ? time / T : T;
+    int s = (int)floor(t * num_seg); if (s >= num_seg) s = num_seg - 1; if (s < 0) s = 0;
+    double x = 2.0 * (t * num_seg - s) - 1.0, L[4];
+    for (int j = 0; j < 4; j++) {
+        double v = 1.0;
+        for (int k = 0; k < 4; k++) if (k != j) v *= (x - xi[k]) / (xi[j] - xi[k]);
+        L[j] = v;
+    }
+    double *q = out, *v = out + 7, *a = out + 14;
+    for (int r = 0; r < 7; r++) {
+        q[r] = v[r] = a[r] = 0.0;
+        for (int j = 0; j < 4; j++) {
+            q[r] += L[j] * xs[14 * (3 * s + j) + r];
+            v[r] += L[j] * xs[14 * (3 * s + j) + 7 + r];
+            a[r] += L[j] * us[7 * (3 * s + j) + r];
+        }
+    }
+    orc_rnea(mdl, q, v, a, out + 21);
+}

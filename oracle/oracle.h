@@ -121,6 +121,9 @@ void orc_solve_batch(const orc_model *m, const orc_config *c, int B, const doubl
 void orc_sample(const orc_model *m, int num_seg, const double *xs, const double *us, double T,
                 int n_pts, double *out /* (n_pts+1) x 29: t,q,v,a,tau */);
 
+/* get_MPC_point (motionPlanner.hpp:118-128) incl. its clamp; out = q(7), v(7), a(7), tau(7) */
+void orc_mpc_point(const orc_model *m, int num_seg, const double *xs, const double *us, double T, double time, double *out);
+
 /* ---- pieces exposed for unit tests of the QP layer ---- */
 /* Assemble the QP of one SQP iteration at (xs,us,T,lam) and run ADMM; returns iterations used. */
 int orc_debug_qp(const orc_model *m, const orc_config *c, const double *x0, const double *xf,

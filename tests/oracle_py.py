@@ -168,3 +168,9 @@ def debug_qp(cfg, x0, xf, xs, us, T, lam=None, model=None):
     it = lib().orc_debug_qp(C.byref(model), C.byref(cfg), _p(x0), _p(xf), _p(xs), _p(us), C.c_double(T),
                             _p(lam), _p(p), _p(y))
     return p, y, it
+
+
+def mpc_point(num_seg, xs, us, T, time, model=None):
+    model = model or default_model(); xs, us = f64(xs), f64(us)
+    out = np.zeros(28)
+    lib().orc_mpc_point(C.byref(model), num_seg, _p(xs), _p(us), C.c_double(T), C.c_double(time), _p(out)); return out

@@ -172,3 +172,35 @@ def test_error_behaviour(M):
     bad = M.default_config(3, 1)
     with pytest.raises(M.MpcmpError):
         M.Solver(bad, 1)                                   # unsupported NUM_SEG
+
+
+def test_receding_horizon_vs_oracle(M):
+    """BASELINE config #5 in miniature: warm-started re-solves + state advance, eager and hipGraph replay."""
+    cfg, ocfg = _cfgs(M, 4, 2)
+    from mpc_motion_planner_amd import scenarios
+    B, steps, dt = 3, 4, 0.05
+    x0, xf = scenarios.make_batch(B, stream_offset=40)
+    # oracle loop
+    xc = x0.copy(); prev = [None] * B; ref = []
+    for st in range(steps):
+        for b in range(B):
+            if prev[b] is None:
+                wx, wu, wT = o.warm_start(ocfg, xc[b], xf[b])
+            else:
+                wx, wu, wT = prev[b][0].copy(), prev[b][1], prev[b][2]
+                wx[0] = xc[b]; wx[-1] = xf[b]                      # motionPlanner.cpp:199-207
+            xs, us, T, _ = o.solve(ocfg, xc[b], xf[b], wx, wu, wT)
+            prev[b] = (xs, us, T)
+            xc[b] = o.mpc_point(4, xs, us, T, dt)[:14]
+        ref.append((xc.copy(), np.array([p[2] for p in prev])))
+    for use_graph in (False, True):
+        s = M.Solver(cfg, B)
+        s.rh_init(x0, xf)
+        s.rh_run(steps, dt, use_graph=use_graph)
+        xg, sx, su, sT, info = s.rh_get()
+        assert np.abs(xg - ref[-1][0]).max() < 1e-6, (use_graph, np.abs(xg - ref[-1][0]).max())
+        assert np.abs(sT - ref[-1][1]).max() < 1e-6
+        assert np.all(info["status"] == 0)
+    # graph replay continues where the eager run stopped: run 2 + 2 equals run 4
+    s = M.Solver(cfg, B); s.rh_init(x0, xf); s.rh_run(2, dt, use_graph=True); s.rh_run(2, dt, use_graph=True)
+    assert np.array_equal(s.rh_get()[0], xg)
