@@ -1,8 +1,8 @@
 // Counterpart of the reference's examples/offline_trajectory.cpp on the mpcmp C ABI: one random (start,target)
 // pair, margins (0.9,0.9,0.5,0.9,0.1), solve, resample 201 points of the initial guess and of the MPC solution,
 // write the 403x29 text file the reference's analysis/data_analysis.ipynb reads.
-//   g++ -O2 -std=c++17 -Iinclude examples/offline_trajectory.cpp -Lmpc_motion_planner_amd -lmpcmp \
-//       -Wl,-rpath,$PWD/mpc_motion_planner_amd -o offline_trajectory
+//   g++ -O2 -std=c++17 -Iinclude examples/offline_trajectory.cpp -Lmpc_motion_planner_amd -lmpcmp
+//     -Wl,-rpath,$PWD/mpc_motion_planner_amd -o offline_trajectory
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>

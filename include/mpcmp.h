@@ -138,6 +138,14 @@ int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double 
 int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sol_x, const double *d_sol_u,
                               const double *d_sol_T, int n_pts, double *d_out, void *hip_stream);
 
+/* ---- trajectory checks of the reference benchmark (examples/benchmark.cpp:58-160) ---- */
+/* out [B][74] = min(28) | max(28) of q,qd,qdd,tau over n_pts+1 uniform samples | x(T) - target (14) |
+ * flags (4; 1 = pass): jerk (|d qdd/dt| <= 10 max_jerk), linear task velocity <= 1.7, angular <= 2.5, tool z >= 0.
+ * One 162-number row of analysis/benchmark_data.txt = [guess min, guess max, mpc min, mpc max, guess err, mpc err,
+ * guess flags, mpc flags, target] (benchmark.cpp:164-194). */
+int mpcmp_traj_stats_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double *sol_u, const double *sol_T,
+                           const double *xf, int n_pts, double *out);
+
 /* ---- receding-horizon driver (BASELINE.json config #5) ---- */
 /* B instances; every step = re-solve warm-started from the previous solution with the reference's re-guess rule
  * (head := current state, tail := target; motionPlanner.cpp:199-207), then the current state advances along the

@@ -260,6 +260,36 @@ class MotionPlanner {
         std::fclose(f);
     }
 
+    // The 1000-iteration loop of examples/benchmark.cpp as ONE batched call: targets xf [B][14] from the current state,
+    // then one 162-number row per problem appended to `path` in the reference's layout (benchmark.cpp:164-194):
+    //   guess min(28) max(28) | MPC min(28) max(28) | guess terminal error(14) | MPC terminal error(14) |
+    //   guess flags(4: jerk, linear vel, angular vel, collision) | MPC flags(4) | target(14)
+    // ("guess" = the built-in initial trajectory standing in for Ruckig).
+    void benchmark_batch(int B, const double *xf, const std::string &path, int n_pts = 200) {
+        const size_t N = (size_t)N_;
+        std::vector<double> x0((size_t)B * 14), gx(B * 14 * N), gu(B * 7 * N), gT(B), sx(B * 14 * N), su(B * 7 * N), sT(B);
+        std::vector<double> sg((size_t)B * 74), sm((size_t)B * 74);
+        std::vector<mpcmp_info> info(B);
+        for (int b = 0; b < B; b++) for (int r = 0; r < 14; r++) x0[(size_t)b * 14 + r] = current_state(r);
+        chk(mpcmp_warm_start_batch(ctx_, B, x0.data(), xf, gx.data(), gu.data(), gT.data()));
+        chk(mpcmp_solve_batch(ctx_, B, x0.data(), xf, gx.data(), gu.data(), gT.data(), sx.data(), su.data(), sT.data(), info.data()));
+        chk(mpcmp_traj_stats_batch(ctx_, B, gx.data(), gu.data(), gT.data(), xf, n_pts, sg.data()));
+        chk(mpcmp_traj_stats_batch(ctx_, B, sx.data(), su.data(), sT.data(), xf, n_pts, sm.data()));
+        FILE *f = std::fopen(path.c_str(), "a");
+        if (!f) throw std::runtime_error("cannot open " + path);
+        for (int b = 0; b < B; b++) {
+            const double *g = sg.data() + (size_t)b * 74, *m = sm.data() + (size_t)b * 74;
+            for (int i = 0; i < 56; i++) std::fprintf(f, "%.6g ", g[i]);
+            for (int i = 0; i < 56; i++) std::fprintf(f, "%.6g ", m[i]);
+            for (int i = 56; i < 70; i++) std::fprintf(f, "%.6g ", g[i]);
+            for (int i = 56; i < 70; i++) std::fprintf(f, "%.6g ", m[i]);
+            for (int i = 70; i < 74; i++) std::fprintf(f, "%d ", (int)g[i]);
+            for (int i = 70; i < 74; i++) std::fprintf(f, "%d ", (int)m[i]);
+            for (int i = 0; i < 14; i++) std::fprintf(f, i == 13 ? "%.6g\n" : "%.6g ", xf[(size_t)b * 14 + i]);
+        }
+        std::fclose(f);
+    }
+
   private:
     mpcmp_ctx *ctx_ = nullptr;
     int N_ = 0, max_batch_ = 0;

@@ -47,7 +47,7 @@ SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_default_limits
            "mpcmp_create", "mpcmp_destroy", "mpcmp_set_config", "mpcmp_last_error", "mpcmp_solve_batch",
            "mpcmp_solve_batch_device", "mpcmp_warm_start_batch", "mpcmp_rnea_batch",
            "mpcmp_eval_constraints_batch", "mpcmp_qp_batch", "mpcmp_sample_batch", "mpcmp_sample_batch_device",
-           "mpcmp_kernel_timing", "mpcmp_debug_stamps", "mpcmp_rh_init", "mpcmp_rh_run", "mpcmp_rh_get"]
+           "mpcmp_kernel_timing", "mpcmp_debug_stamps", "mpcmp_rh_init", "mpcmp_rh_run", "mpcmp_rh_get", "mpcmp_traj_stats_batch"]
 
 
 def library_path():

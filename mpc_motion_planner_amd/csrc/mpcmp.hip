@@ -624,6 +624,34 @@ extern "C" int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sx, const
 }
 
 
+// examples/benchmark.cpp:58-160 for a batch of trajectories (either the initial guess or the MPC solution)
+extern "C" int mpcmp_traj_stats_batch(mpcmp_ctx *ctx, int B, const double *sx, const double *su, const double *sT, const double *xf,
+                                      int n_pts, double *out) {
+    if (!ctx || B < 1 || n_pts < 1 || n_pts > 1000 || !sx || !su || !sT || !xf || !out) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = ctx->N;
+    TmpBuf tb;
+    double *dx = tb.get<double>(14 * N * B), *du = tb.get<double>(7 * N * B), *dT = tb.get<double>(B), *df = tb.get<double>(14 * (size_t)B),
+           *dj = tb.get<double>(7), *dout = tb.get<double>(74 * (size_t)B);
+    if (!dx || !du || !dT || !df || !dj || !dout) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
+    double jerk[7], j10[7];
+    mpcmp_default_limits(nullptr, nullptr, nullptr, nullptr, jerk, nullptr);
+    for (int r = 0; r < 7; r++) j10[r] = 10.0 * jerk[r];                     // benchmark.cpp:128
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dx, sx, sizeof(double) * 14 * N * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(du, su, sizeof(double) * 7 * N * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dT, sT, sizeof(double) * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(df, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dj, j10, sizeof j10, hipMemcpyHostToDevice, st));
+    const size_t lds = sizeof(double) * 28 * (size_t)(n_pts + 1);
+    if (int rc = set_lds(ctx, k_traj_stats, lds)) return rc;
+    hipLaunchKernelGGL(k_traj_stats, dim3(B), dim3(256), lds, st, ctx->d_model, ctx->nseg, n_pts, dx, du, dT, df, 1.7, 2.5, dj, dout);   // pandaWrapper.hpp:37-38
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, dout, sizeof(double) * 74 * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // receding-horizon driver (BASELINE config #5): B instances, every step = warm-started re-solve from the previous
 // solution (re-guess rule of motionPlanner.cpp:199-207) + state advance along the new solution

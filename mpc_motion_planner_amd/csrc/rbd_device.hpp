@@ -164,4 +164,34 @@ __device__ __forceinline__ void fk_tool(const mpcmp_model *__restrict__ M, const
     }
 }
 
+
+// World-aligned velocity of the tool frame, J(q) qd with J = blockdiag(R,R) J_local (PandaWrapper::forward_velocities,
+// robot_utils/pandaWrapper.cpp:90-107), and the tool position (table-collision check, examples/benchmark.cpp:106-113).
+__device__ __forceinline__ void fk_task_velocity(const mpcmp_model *__restrict__ M, const double *sc, const double *qd,
+                                                 V3 *p_tool, V3 *vlin, V3 *vang) {
+    M3 Rw; V3 pw = mk(0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rw.a[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    V3 zax[7], org[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const M3 R = joint_rot(M->R0[i], sc[2 * i], sc[2 * i + 1]);
+        pw = pw + mul(Rw, ld3(M->p[i]));
+        M3 Rn;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                Rn.a[3 * r + c] = Rw.a[3 * r + 0] * R.a[0 + c] + Rw.a[3 * r + 1] * R.a[3 + c] + Rw.a[3 * r + 2] * R.a[6 + c];
+        Rw = Rn;
+        zax[i] = mk(Rw.a[2], Rw.a[5], Rw.a[8]);
+        org[i] = pw;
+    }
+    const V3 pt = pw + mul(Rw, ld3(M->tool));
+    V3 vl = mk(0, 0, 0), va = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 7; i++) { vl = vl + qd[i] * cross(zax[i], pt - org[i]); va = va + qd[i] * zax[i]; }
+    *p_tool = pt; *vlin = vl; *vang = va;
+}
+
 }  // namespace mpcmp

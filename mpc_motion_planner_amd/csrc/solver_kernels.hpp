@@ -937,4 +937,72 @@ __global__ __launch_bounds__(256) void k_advance(int nseg, int B, double dt, con
     x0[gid] = acc;
 }
 
+
+// Per-trajectory checks of examples/benchmark.cpp:58-160 in one pass: resample at n_pts+1 uniform times (interpolation + RNEA),
+// min / max of the 28 channels, terminal error, and the four pass flags (jerk, linear / angular task velocity, table
+// collision).  One workgroup per trajectory; out [B][74] = mins(28) | maxs(28) | x(T) - x_target (14) | flags (4, 1 = pass).
+__global__ __launch_bounds__(256) void k_traj_stats(const mpcmp_model *mdl, int nseg, int n_pts, const double *sx, const double *su,
+                                                    const double *sT, const double *xf, double max_lin, double max_ang,
+                                                    const double *jerk10 /*[7] = 10 x max_jerk*/, double *out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *smp = lds;                          // [n_pts+1][28]
+    __shared__ int fl[4];
+    const int b = blockIdx.x, tid = threadIdx.x, N = 3 * nseg + 1;
+    const double *X = sx + (size_t)b * 14 * N, *U = su + (size_t)b * 7 * N;
+    const double T = sT[b];
+    if (tid < 4) fl[tid] = 1;
+    __syncthreads();
+    const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    for (int ip = tid; ip <= n_pts; ip += blockDim.x) {
+        const double t = (double)ip / n_pts;
+        int s = (int)floor(t * nseg);
+        if (s >= nseg) s = nseg - 1;
+        if (s < 0) s = 0;
+        const double xx = 2.0 * (t * nseg - s) - 1.0;
+        double Lg[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double v = 1.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (k != j) v *= (xx - xi[k]) / (xi[j] - xi[k]);
+            Lg[j] = v;
+        }
+        double q[7], v[7], a[7], tau[7], sc[14];
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            q[r] = v[r] = a[r] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                q[r] += Lg[j] * X[14 * (3 * s + j) + r];
+                v[r] += Lg[j] * X[14 * (3 * s + j) + 7 + r];
+                a[r] += Lg[j] * U[7 * (3 * s + j) + r];
+            }
+            sincos(q[r], &sc[2 * r], &sc[2 * r + 1]);
+        }
+        rnea_dir<false>(mdl, sc, v, a, 0, 0, tau, nullptr);
+        V3 pt, vl, va;
+        fk_task_velocity(mdl, sc, v, &pt, &vl, &va);
+        if (sqrt(vl.x * vl.x + vl.y * vl.y + vl.z * vl.z) > max_lin) fl[1] = 0;     // benchmark.cpp:139-142
+        if (sqrt(va.x * va.x + va.y * va.y + va.z * va.z) > max_ang) fl[2] = 0;     // :143-146
+        if (pt.z < 0.0) fl[3] = 0;                                                  // :149-155
+        double *o = smp + (size_t)ip * 28;
+#pragma unroll
+        for (int r = 0; r < 7; r++) { o[r] = q[r]; o[7 + r] = v[r]; o[14 + r] = a[r]; o[21 + r] = tau[r]; }
+    }
+    __syncthreads();
+    const double dT = T / n_pts;                                                     // time(nPoints)/nPoints, :121
+    for (int ip = 1 + tid; ip <= n_pts; ip += blockDim.x)
+        for (int r = 0; r < 7; r++)
+            if (fabs((smp[(size_t)ip * 28 + 14 + r] - smp[(size_t)(ip - 1) * 28 + 14 + r]) / dT) > jerk10[r]) fl[0] = 0;   // :126-133
+    double *o = out + (size_t)b * 74;
+    if (tid < 28) {
+        double mn = smp[tid], mx = smp[tid];
+        for (int ip = 1; ip <= n_pts; ip++) { const double v = smp[(size_t)ip * 28 + tid]; mn = fmin(mn, v); mx = fmax(mx, v); }
+        o[tid] = mn; o[28 + tid] = mx;
+    }
+    if (tid < 14) o[56 + tid] = smp[(size_t)n_pts * 28 + tid] - xf[(size_t)b * 14 + tid];   // :176-179
+    __syncthreads();
+    if (tid < 4) o[70 + tid] = (double)fl[tid];
+}
+
 }  // namespace mpcmp

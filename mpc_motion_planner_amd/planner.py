@@ -92,6 +92,12 @@ class Solver:
         check(lib().mpcmp_sample_batch_device(self._ctx, int(B), vp(sol_x), vp(sol_u), vp(sol_T), int(n_pts), vp(out),
                                               vp(stream or None)), self._ctx)
 
+    def traj_stats(self, sx, su, sT, xf, n_pts=200):
+        sx, su, sT, xf = f64(sx), f64(su), f64(sT), f64(xf); B = sx.shape[0]
+        out = np.zeros((B, 74))
+        check(lib().mpcmp_traj_stats_batch(self._ctx, B, dp(sx), dp(su), dp(sT), dp(xf), int(n_pts), dp(out)), self._ctx)
+        return out
+
     # -- receding horizon (BASELINE config #5)
     def rh_init(self, x0, xf):
         x0, xf = f64(x0), f64(xf)

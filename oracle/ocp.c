@@ -559,3 +559,34 @@ void orc_mpc_point(const orc_model *mdl, int num_seg, const double *xs, const do
     }
     orc_rnea(mdl, q, v, a, out + 21);
 }
+
+/* examples/benchmark.cpp:58-160 for one trajectory: out[74] = min(28) | max(28) | x(T)-target (14) | flags (4, 1 = pass) */
+void orc_traj_stats(const orc_model *mdl, int num_seg, const double *xs, const double *us, double T, const double *xf,
+                    int n_pts, double *out) {
+    double *smp = (double *)malloc(sizeof(double) * 29 * (size_t)(n_pts + 1));
+    double jerk[7];
+    orc_default_limits(0, 0, 0, 0, jerk, 0);
+    orc_sample(mdl, num_seg, xs, us, T, n_pts, smp);
+    int fl[4] = {1, 1, 1, 1};
+    const double dT = T / n_pts;
+    for (int ip = 0; ip <= n_pts; ip++) {
+        const double *r = smp + (size_t)ip * 29;
+        if (ip >= 1) for (int j = 0; j < 7; j++)
+            if (fabs((r[15 + j] - r[15 + j - 29]) / dT) > 10.0 * jerk[j]) fl[0] = 0;
+        double J[42], vl[3] = {0, 0, 0}, va[3] = {0, 0, 0}, pt[3];
+        orc_frame_jacobian(mdl, r + 1, mdl->tool, J);
+        for (int d = 0; d < 3; d++) for (int j = 0; j < 7; j++) { vl[d] += J[d * 7 + j] * r[8 + j]; va[d] += J[(3 + d) * 7 + j] * r[8 + j]; }
+        if (sqrt(vl[0] * vl[0] + vl[1] * vl[1] + vl[2] * vl[2]) > 1.7) fl[1] = 0;
+        if (sqrt(va[0] * va[0] + va[1] * va[1] + va[2] * va[2]) > 2.5) fl[2] = 0;
+        orc_fk(mdl, r + 1, 0, 0, 0, pt);
+        if (pt[2] < 0.0) fl[3] = 0;
+    }
+    for (int c = 0; c < 28; c++) {
+        double mn = smp[1 + c], mx = smp[1 + c];
+        for (int ip = 1; ip <= n_pts; ip++) { double v = smp[(size_t)ip * 29 + 1 + c]; if (v < mn) mn = v; if (v > mx) mx = v; }
+        out[c] = mn; out[28 + c] = mx;
+    }
+    for (int c = 0; c < 14; c++) out[56 + c] = smp[(size_t)n_pts * 29 + 1 + c] - xf[c];
+    for (int c = 0; c < 4; c++) out[70 + c] = fl[c];
+    free(smp);
+}

@@ -124,6 +124,10 @@ void orc_sample(const orc_model *m, int num_seg, const double *xs, const double 
 /* get_MPC_point (motionPlanner.hpp:118-128) incl. its clamp; out = q(7), v(7), a(7), tau(7) */
 void orc_mpc_point(const orc_model *m, int num_seg, const double *xs, const double *us, double T, double time, double *out);
 
+/* examples/benchmark.cpp:58-160: out[74] = min(28) | max(28) | x(T)-target (14) | flags jerk, lin vel, ang vel, collision */
+void orc_traj_stats(const orc_model *m, int num_seg, const double *xs, const double *us, double T, const double *xf,
+                    int n_pts, double *out);
+
 /* ---- pieces exposed for unit tests of the QP layer ---- */
 /* Assemble the QP of one SQP iteration at (xs,us,T,lam) and run ADMM; returns iterations used. */
 int orc_debug_qp(const orc_model *m, const orc_config *c, const double *x0, const double *xf,

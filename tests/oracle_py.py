@@ -174,3 +174,9 @@ def mpc_point(num_seg, xs, us, T, time, model=None):
     model = model or default_model(); xs, us = f64(xs), f64(us)
     out = np.zeros(28)
     lib().orc_mpc_point(C.byref(model), num_seg, _p(xs), _p(us), C.c_double(T), C.c_double(time), _p(out)); return out
+
+
+def traj_stats(num_seg, xs, us, T, xf, n_pts=200, model=None):
+    model = model or default_model(); xs, us, xf = f64(xs), f64(us), f64(xf)
+    out = np.zeros(74)
+    lib().orc_traj_stats(C.byref(model), num_seg, _p(xs), _p(us), C.c_double(T), _p(xf), int(n_pts), _p(out)); return out

@@ -204,3 +204,45 @@ def test_receding_horizon_vs_oracle(M):
     # graph replay continues where the eager run stopped: run 2 + 2 equals run 4
     s = M.Solver(cfg, B); s.rh_init(x0, xf); s.rh_run(2, dt, use_graph=True); s.rh_run(2, dt, use_graph=True)
     assert np.array_equal(s.rh_get()[0], xg)
+
+
+def test_traj_stats_vs_oracle(M):
+    """examples/benchmark.cpp:58-160: extrema, terminal error and the four pass flags of a resampled trajectory"""
+    cfg, ocfg = _cfgs(M, 4, 3)
+    from mpc_motion_planner_amd import scenarios
+    B = 5
+    x0, xf = scenarios.make_batch(B, stream_offset=11)
+    s = M.Solver(cfg, B)
+    sx, su, sT, _ = s.solve(x0, xf)
+    su2 = su.copy(); su2[0, 3] = 1e5                # force a jerk failure in problem 0
+    sx2 = sx.copy(); sx2[1, :, 1] = 2.5; sx2[1, :, 3] = -0.1; sx2[1, :, 5] = 0.2   # arm pitched below the table: collision
+    for (X, U) in ((sx, su), (sx2, su2)):
+        out = s.traj_stats(X, U, sT, xf, n_pts=200)
+        for b in range(B):
+            ref = o.traj_stats(4, X[b], U[b], sT[b], xf[b], 200)
+            assert np.array_equal(out[b, 70:], ref[70:]), (b, out[b, 70:], ref[70:])
+            assert np.abs(out[b, :70] - ref[:70]).max() < 1e-8 * (1 + np.abs(ref[:70]).max())
+    out = s.traj_stats(sx2, su2, sT, xf)
+    assert out[0, 70] == 0.0 and out[1, 73] == 0.0
+
+
+def test_cpp_examples_run(M, tmp_path):
+    """the C++ MotionPlanner mirror end to end: offline_trajectory (403 x 29) and the batched benchmark (162 columns)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("offline_trajectory", "benchmark"):
+        exe = str(tmp_path / name)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(root, "include"),
+                               os.path.join(root, "examples", name + ".cpp"), "-L" + os.path.join(root, "mpc_motion_planner_amd"),
+                               "-lmpcmp", "-Wl,-rpath," + os.path.join(root, "mpc_motion_planner_amd"), "-o", exe])
+    out1 = str(tmp_path / "optimal_solution.txt")
+    subprocess.check_call([str(tmp_path / "offline_trajectory"), "", out1, "7"])
+    d = np.loadtxt(out1)
+    assert d.shape == (403, 29)                       # examples/offline_trajectory.cpp:69-105
+    assert abs(d[1, 0]) < 1e-12 and abs(d[202, 0]) < 1e-12 and d[402, 0] > 0.3
+    assert np.abs(d[402, 1:15] - d[0, 1:15]).max() < 5e-2      # MPC trajectory ends at the target
+    out2 = str(tmp_path / "benchmark_data.txt")
+    subprocess.check_call([str(tmp_path / "benchmark"), "", out2, "24"])
+    b = np.loadtxt(out2)
+    assert b.shape == (24, 162)                       # analysis/benchmark_analysis.ipynb cell 1
+    assert set(np.unique(b[:, 140:148])) <= {0.0, 1.0}
