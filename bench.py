@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=96)
+    ap.add_argument("--cpu-sample", type=int, default=192)
     ap.add_argument("--workload", choices=["batch", "rh"], default="batch",
                     help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon, extra line")
     args = ap.parse_args()

@@ -246,3 +246,26 @@ def test_cpp_examples_run(M, tmp_path):
     b = np.loadtxt(out2)
     assert b.shape == (24, 162)                       # analysis/benchmark_analysis.ipynb cell 1
     assert set(np.unique(b[:, 140:148])) <= {0.0, 1.0}
+
+
+def test_edge_cases(M):
+    """single problem, full-capacity batch, coincident start/target, non-finite input (flagged, not fatal)"""
+    cfg, ocfg = _cfgs(M, 4, 2)
+    from mpc_motion_planner_amd import scenarios
+    x0, xf = scenarios.make_batch(7, stream_offset=300)
+    s = M.Solver(cfg, 7)
+    sx7, su7, sT7, info7 = s.solve(x0, xf)                         # exactly max_batch
+    sx1, su1, sT1, info1 = s.solve(x0[3:4], xf[3:4])               # a single problem
+    assert np.array_equal(sx1[0], sx7[3]) and sT1[0] == sT7[3]
+    # start == target: the minimum-time problem degenerates; the solver must return finite numbers
+    sxe, sue, sTe, infoe = s.solve(x0[:2], x0[:2])
+    assert np.all(np.isfinite(sTe)) and np.all(infoe["status"] == 0) and np.all(sTe < sT7[:2])
+    # non-finite start state: reported through status bit 0 for that problem only
+    bad = x0.copy(); bad[2, 0] = np.nan
+    _, _, sTb, infob = s.solve(bad, xf)
+    assert infob["status"][2] & 1 and np.all(infob["status"][[0, 1, 3, 4, 5, 6]] == 0)
+    assert np.array_equal(sTb[[0, 1, 3, 4, 5, 6]], sT7[[0, 1, 3, 4, 5, 6]])
+    # the oracle agrees on the degenerate case
+    xg, ug, Tg = o.warm_start(ocfg, x0[0], x0[0])
+    xs, us, T, oi = o.solve(ocfg, x0[0], x0[0], xg, ug, Tg)
+    assert abs(sTe[0] - T) <= 1e-6 * max(T, 1e-3) + 1e-9
