@@ -90,7 +90,7 @@ struct Qp2 {
     static constexpr int HS = 2;                                   // segments factorised concurrently
     static constexpr int FAC = NSEG * (D::JP + D::JC);             // per-problem factor scratch in HBM (doubles)
     static_assert(8 * NPR <= NB && D::n <= NB, "role B mapping");
-    static_assert(8 * D::N <= 4 * NEQ && D::meq <= 4 * NEQ, "row lanes must fit the E^T quads");
+    static_assert(8 * D::N <= 4 * NEQ && D::meq <= NB, "path-row lanes must fit the E^T quads, dynamics rows role B");
     // LDS (doubles)
     static constexpr int RS = 7;                               // padded stride of the dynamics-row coefficients
     static constexpr int oRv = 0;                              // [meq][RS]    dynamics rows: D_i0..D_i3, -ts*T, -ts*f  (V part 1)
@@ -310,7 +310,6 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     const bool isPath = et < 8 * N;
     const int pk = et >> 3, prp = (et & 7) >> 1, phalf = et & 1;
     double *pcl = lds + L::oPc + et;
-    const double *rcl = lds + L::oRv + (et < meq ? et : 0) * L::RS;    // dynamics-row coefficients (written by the prologue)
     double zg = 0, yg = 0;
     int myrow = 0;
     if (isPath) {
@@ -325,21 +324,6 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     }
     const int groff = isPath ? (pk * 8 + 2 * prp) * GS + phalf * 12 : 0;     // columns 0..11 | 12..21 (+2 zero pads)
     const int xnoff = isPath ? pk * XS + phalf * 12 : 0;
-    // dynamics row owned by this lane
-    const bool isDyn = et < meq;
-    double lgd = 0, zgd = 0, ygd = 0;
-    int ix0 = 0, ixf = 0, ixT = 21;
-    if (isDyn) {
-        const int r = et, k = r / 14, rr = r % 14, s = k / 3;
-        ix0 = 3 * s * XS + rr;
-        ixf = k * XS + ((rr < 7) ? 7 + rr : 14 + rr - 7);
-        ixT = k * XS + 21;
-        lgd = -c.ws.ceq[(size_t)b * meq + r];
-    }
-    auto row_dot_dyn = [&](const double *xe) -> double {
-        return rcl[0] * xe[ix0] + rcl[1] * xe[ix0 + XS] + rcl[2] * xe[ix0 + 2 * XS] + rcl[3] * xe[ix0 + 3 * XS] +
-               rcl[4] * xe[ixf] + rcl[5] * xe[ixT];
-    };
     auto row_dot_path = [&](const double *xe) -> double {
         const double *g0 = gkl + groff, *g1 = g0 + GS, *xv = xe + xnoff;
         double a0 = 0.0, a1 = 0.0;
@@ -359,7 +343,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         return phalf ? a1 : a0;
     };
     __syncthreads();          // constants published (matches the barrier of the other roles)
-    const double alpha = c.alpha, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
+    const double alpha = c.alpha;
     const double *bj = rhsJ + 56 * seg + 14 * part;
     int it = 0, done = 0;
     for (it = 1; it <= cfg.qp_iters; it++) {
@@ -399,36 +383,20 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             tpl[myrow] = pcl[3 * L::NA2] * w;
             if (check) ys[myrow] = yg;
         }
-        if (isDyn) {
-            const double zt = row_dot_dyn(xn);
-            const double zr = alpha * zt + (1.0 - alpha) * zgd;
-            const double zn = clip(zr + ygd * inv_rho_eq, lgd, lgd);
-            ygd += rho_eq * (zr - zn);
-            zgd = zn;
-            const double w = rho_eq * zgd - ygd;
-            wg[et] = w;
-            tpl[et] = rcl[5] * w;
-            if (check) ys[et] = ygd;
-        }
         __syncthreads();
         if (check) {
-            double sums[2] = {(isPath ? pcl[3 * L::NA2] * yg : 0.0) + (isDyn ? rcl[5] * ygd : 0.0), 0.0};
+            double sums[2] = {isPath ? pcl[3 * L::NA2] * yg : 0.0, 0.0};
             block_reduce16<2, false>(sums, red, tid);
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isPath) {
                 const double ax = row_dot_path(xx);
                 mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg);
             }
-            if (isDyn) {
-                const double ax = row_dot_dyn(xx);
-                mx[0] = fmax(mx[0], fabs(ax - zgd)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zgd));
-            }
             done = qp2_converged<NSEG>(cfg, mx, red, tid);
         }
         if (done) break;
     }
     if (isPath) c.ws.y[(size_t)b * D::mn + myrow] = yg;
-    if (isDyn) c.ws.y[(size_t)b * D::mn + et] = ygd;
 }
 
 struct VarRole {
@@ -502,7 +470,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     const int tid = c.tid, b = c.b, u = tid - L::NA1 - L::NA2;
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
     double *rhsI = lds + L::oRhsI, *partl = lds + L::oPart, *xC = lds + L::oXC, *xn = lds + L::oXn, *xx = lds + L::oXx,
-           *wg = lds + L::oWg, *ys = lds + L::oYs, *misc = lds + L::oMisc, *rI = lds + L::oRI;
+           *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *misc = lds + L::oMisc, *rI = lds + L::oRI;
     const bool isP2 = (u >> 3) < L::NPR;
     const int rp2 = u >> 3, part2 = u & 7;
     const bool isVar = u < n, isT = u == n - 1;
@@ -589,7 +557,23 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         }
         return s;
     };
-    const double alpha = c.alpha, sigma = c.sigma;
+    // dynamics row owned by this lane (u < meq): ADMM state in registers, coefficients in the V area of LDS
+    const double *rcl = lds + L::oRv + (u < meq ? u : 0) * L::RS;
+    const bool isDyn = u < meq;
+    double lgd = 0, zgd = 0, ygd = 0;
+    int ix0 = 0, ixf = 0, ixT = 21;
+    if (isDyn) {
+        const int r = u, k = r / 14, rr = r % 14, s = k / 3;
+        ix0 = 3 * s * XS + rr;
+        ixf = k * XS + ((rr < 7) ? 7 + rr : 14 + rr - 7);
+        ixT = k * XS + 21;
+        lgd = -c.ws.ceq[(size_t)b * meq + r];
+    }
+    auto row_dot_dyn = [&](const double *xe) -> double {
+        return rcl[0] * xe[ix0] + rcl[1] * xe[ix0 + XS] + rcl[2] * xe[ix0 + 2 * XS] + rcl[3] * xe[ix0 + 3 * XS] +
+               rcl[4] * xe[ixf] + rcl[5] * xe[ixT];
+    };
+    const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
     double x = 0, zb = 0, yb = 0;
     int it = 0, done = 0;
     for (it = 1; it <= cfg.qp_iters; it++) {
@@ -645,8 +629,19 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         __syncthreads();
         // ---- P3: (group A) ----
         __syncthreads();
-        // ---- E: variables ----
+        // ---- E: variables and dynamics rows ----
         const bool check = (it % cfg.check_every == 0);
+        if (isDyn) {
+            const double zt = row_dot_dyn(xn);
+            const double zr = alpha * zt + (1.0 - alpha) * zgd;
+            const double zn = clip(zr + ygd * inv_rho_eq, lgd, lgd);
+            ygd += rho_eq * (zr - zn);
+            zgd = zn;
+            const double w = rho_eq * zgd - ygd;
+            wg[u] = w;
+            tpl[u] = rcl[5] * w;
+            if (check) ys[u] = ygd;
+        }
         if (isVar) {
             const double xtv = xn[v_xpos];
             x = alpha * xtv + (1.0 - alpha) * x;
@@ -661,9 +656,13 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         }
         __syncthreads();
         if (check) {
-            double sums[2] = {0.0, (isVar && !isT) ? vcl[8 * L::NB] * x : 0.0};
+            double sums[2] = {isDyn ? rcl[5] * ygd : 0.0, (isVar && !isT) ? vcl[8 * L::NB] * x : 0.0};
             block_reduce16<2, false>(sums, red, tid);
             double mx[6] = {0, 0, 0, 0, 0, 0};
+            if (isDyn) {
+                const double ax = row_dot_dyn(xx);
+                mx[0] = fabs(ax - zgd); mx[1] = fabs(ax); mx[2] = fabs(zgd);
+            }
             if (isVar) {
                 mx[0] = fmax(mx[0], fabs(x - zb)); mx[1] = fmax(mx[1], fabs(x)); mx[2] = fmax(mx[2], fabs(zb));
                 double hx, aty;
@@ -676,6 +675,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         }
         if (done) break;
     }
+    if (isDyn) c.ws.y[(size_t)b * D::mn + u] = ygd;
     if (isVar) {
         c.ws.p[(size_t)b * n + u] = x;
         c.ws.y[(size_t)b * D::mn + m + u] = yb;
