@@ -612,18 +612,16 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
                 a0 += s2[2 * j + 1] * r[j].y; a1 += sb2[j].y * r[j].y;
             }
             a0 = sum8(a0); a1 = sum8(a1);
-            if (myIrow >= 0) {
+            if (myIrow >= 0 && myIrow != nI - 1) {
                 const double xi = part2 ? a1 : a0;
-                if (myIrow == nI - 1) {
-#pragma unroll
-                    for (int k = 0; k < N; k++) xn[k * XS + 21] = xi;
-#pragma unroll
-                    for (int s = 0; s < NSEG; s++) xC[s * 32 + 28] = xi;
-                } else {
-                    xn[xdst] = xi;
-                    if (cdst1 >= 0) lds[cdst1] = xi;
-                    if (cdst2 >= 0) lds[cdst2] = xi;
-                }
+                xn[xdst] = xi;
+                if (cdst1 >= 0) lds[cdst1] = xi;
+                if (cdst2 >= 0) lds[cdst2] = xi;
+            }
+            if (rp2 == (nI - 1) / 2) {       // x_T is replicated (every node row, every C_s): the 8 lanes of its group share the writes
+                const double xT = ((nI - 1) & 1) ? a1 : a0;
+                for (int k = part2; k < N; k += 8) xn[k * XS + 21] = xT;
+                if (part2 < NSEG) xC[part2 * 32 + 28] = xT;
             }
         }
         __syncthreads();
