@@ -90,7 +90,7 @@ struct Qp2 {
     static constexpr int HS = 2;                                   // segments factorised concurrently
     static constexpr int FAC = NSEG * (D::JP + D::JC);             // per-problem factor scratch in HBM (doubles)
     static_assert(8 * NPR <= NB && D::n <= NB, "role B mapping");
-    static_assert(8 * D::N <= 4 * NEQ && D::meq <= NB, "path-row lanes must fit the E^T quads, dynamics rows role B");
+    static_assert(16 * D::N <= 4 * NEQ && D::meq <= NB, "path-row lanes must fit the E^T quads, dynamics rows role B");
     // LDS (doubles)
     static constexpr int RS = 7;                               // padded stride of the dynamics-row coefficients
     static constexpr int oRv = 0;                              // [meq][RS]    dynamics rows: D_i0..D_i3, -ts*T, -ts*f  (V part 1)
@@ -305,15 +305,15 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     }
     __syncthreads();          // (matches role A1/B: register blocks picked up)
     const int pdst = (act && part < 2 && 2 * le + part < 29) ? seg * 32 + 2 * le + part : -1;
-    // path row owned by this lane (ADMM state) and the 2x11 coefficient block it helps to evaluate; the row
-    // constants live in LDS (lane-transposed), only the ADMM state (z, y) stays in registers
-    const bool isPath = et < 8 * N;
-    const int pk = et >> 3, prp = (et & 7) >> 1, phalf = et & 1;
+    // path rows: the row constants live in LDS (lane-transposed), only the ADMM state (z, y) of the owned row stays in registers
+    const bool isPath = et < 16 * N;                    // four lanes per pair of path rows (six columns each)
+    const int pk = et >> 4, prp = (et & 15) >> 2, pq = et & 3;
+    const bool ownsRow = isPath && pq < 2;             // lanes 0,1 of the group own rows 2prp, 2prp+1
     double *pcl = lds + L::oPc + et;
     double zg = 0, yg = 0;
     int myrow = 0;
-    if (isPath) {
-        const int q = 2 * prp + phalf;
+    if (ownsRow) {
+        const int q = 2 * prp + pq;
         myrow = meq + 8 * pk + q;
         const double gv = c.ws.g[(size_t)b * 8 * N + 8 * pk + q];
         const double lg = cfg.lbg[q] - gv, ug = cfg.ubg[q] - gv;
@@ -322,25 +322,21 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         pcl[3 * L::NA2] = c.ws.Gk[((size_t)b * N + pk) * 176 + q * 22 + 21];
         pcl[4 * L::NA2] = 1.0 / pcl[2 * L::NA2];
     }
-    const int groff = isPath ? (pk * 8 + 2 * prp) * GS + phalf * 12 : 0;     // columns 0..11 | 12..21 (+2 zero pads)
-    const int xnoff = isPath ? pk * XS + phalf * 12 : 0;
+    const int groff = isPath ? (pk * 8 + 2 * prp) * GS + pq * 6 : 0;     // columns 6pq .. 6pq+5 of the 24-wide padded rows
+    const int xnoff = isPath ? pk * XS + pq * 6 : 0;
     auto row_dot_path = [&](const double *xe) -> double {
         const double *g0 = gkl + groff, *g1 = g0 + GS, *xv = xe + xnoff;
+        D2 x2[3], p0[3], p1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { x2[j] = lds2(xv + 2 * j); p0[j] = lds2(g0 + 2 * j); p1[j] = lds2(g1 + 2 * j); }
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int h = 0; h < 3; h++) {                      // three batches of six 16-byte reads
-            D2 x2[2], p0[2], p1[2];
-#pragma unroll
-            for (int j = 0; j < 2; j++) { x2[j] = lds2(xv + 4 * h + 2 * j); p0[j] = lds2(g0 + 4 * h + 2 * j); p1[j] = lds2(g1 + 4 * h + 2 * j); }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                a0 += p0[j].x * x2[j].x; a1 += p1[j].x * x2[j].x;
-                a0 += p0[j].y * x2[j].y; a1 += p1[j].y * x2[j].y;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 3; j++) {
+            a0 += p0[j].x * x2[j].x; a1 += p1[j].x * x2[j].x;
+            a0 += p0[j].y * x2[j].y; a1 += p1[j].y * x2[j].y;
         }
-        a0 = sum2(a0); a1 = sum2(a1);
-        return phalf ? a1 : a0;
+        a0 = sum4(a0); a1 = sum4(a1);
+        return (pq & 1) ? a1 : a0;
     };
     __syncthreads();          // constants published (matches the barrier of the other roles)
     const double alpha = c.alpha;
@@ -373,6 +369,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         const bool check = (it % cfg.check_every == 0);
         if (isPath) {
             const double zt = row_dot_path(xn);
+          if (ownsRow) {
             const double rr_ = pcl[2 * L::NA2];
             const double zr = alpha * zt + (1.0 - alpha) * zg;
             const double zn = clip(zr + yg * pcl[4 * L::NA2], pcl[0], pcl[L::NA2]);
@@ -382,21 +379,22 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             wg[myrow] = w;
             tpl[myrow] = pcl[3 * L::NA2] * w;
             if (check) ys[myrow] = yg;
+          }
         }
         __syncthreads();
         if (check) {
-            double sums[2] = {isPath ? pcl[3 * L::NA2] * yg : 0.0, 0.0};
+            double sums[2] = {ownsRow ? pcl[3 * L::NA2] * yg : 0.0, 0.0};
             block_reduce16<2, false>(sums, red, tid);
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isPath) {
                 const double ax = row_dot_path(xx);
-                mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg);
+                if (ownsRow) { mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg); }
             }
             done = qp2_converged<NSEG>(cfg, mx, red, tid);
         }
         if (done) break;
     }
-    if (isPath) c.ws.y[(size_t)b * D::mn + myrow] = yg;
+    if (ownsRow) c.ws.y[(size_t)b * D::mn + myrow] = yg;
 }
 
 struct VarRole {
