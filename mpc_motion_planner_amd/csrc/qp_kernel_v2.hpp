@@ -99,8 +99,7 @@ struct Qp2 {
     static constexpr int oRhsI = oRhsJ + NSEG * 56;            // [80]         rhs, interface part
     static constexpr int oRI = oRhsI + 2 * ((D::nI + 2) / 2);  // [80]         r_I = b_I - sum_s E_s^T b_Js
     static constexpr int oPart = oRI + 80;                     // [NSEG][32]   E_s^T b_Js
-    static constexpr int oXC = oPart + NSEG * 32;              // [NSEG][32]   x_I restricted to C_s
-    static constexpr int oXn = oXC + NSEG * 32;                // [N][XS]      x~ node-major
+    static constexpr int oXn = oPart + NSEG * 32;              // [N][XS]      x~ node-major
     static constexpr int oXx = oXn + D::N * XS;                // [N][XS]      x  node-major (termination tests)
     static constexpr int oWg = oXx + D::N * XS;                // [m]          w = rho z - y   (general rows)
     static constexpr int oYs = oWg + D::m;                     // [m]          y (termination tests)
@@ -118,11 +117,9 @@ struct Qp2 {
     static constexpr int CB = 4 * 64 > ((D::nI + 15) / 16 * 16) ? 4 * 64 : ((D::nI + 15) / 16 * 16);
     static constexpr int oEndF = oCol + 2 * CB;
     // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
-    static constexpr int oE3 = oS;                             // [16][4*NGQ] E_s blocks of role A1 (lane-transposed pairs)
-    static constexpr int oPc = oE3 + 16 * 4 * NGQ;             // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
-    static constexpr int oVc = oPc + 5 * NA2;                  // [10][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv
-    static constexpr int oS2 = oVc + 10 * NB;                  // [10][NB]   second row of each S^-1 block (role B)
-    static constexpr int oEndA = oS2 + 10 * NB;
+    static constexpr int oPc = oS;                             // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
+    static constexpr int oVc = oPc + 5 * NA2;                  // [13][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv, lb, ub, 1/rho_b
+    static constexpr int oEndA = oVc + 13 * NB;
     static constexpr int size = oEndF > oEndA ? oEndF : oEndA;
     static_assert(size * 8 <= 160 * 1024 - 512, "LDS budget (a 256-byte static block precedes the dynamic region)");
     static_assert(oGk + D::N * 8 * GS < (1 << 14), "assembly stream operand offsets are 14 bits");
@@ -164,18 +161,15 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid;
     double *red = lds + L::oRed;
-    double *rhsJ = lds + L::oRhsJ, *xC = lds + L::oXC, *xn = lds + L::oXn, *tpl = lds + L::oTp, *misc = lds + L::oMisc;
+    double *rhsJ = lds + L::oRhsJ, *xn = lds + L::oXn, *tpl = lds + L::oTp, *misc = lds + L::oMisc;
 #ifdef MPCMP_STAMPS
     unsigned long long stamp_acc[16] = {0}, stamp_t = clock64();
 #endif
     const int Q = tid >> 2, part = tid & 3;
     const bool act = Q < L::NGQ;
     const int seg = act ? Q / 25 : 0, lp = act ? Q % 25 : 0;
-    // rows (2lp, 2lp+1) of G_s x columns part*14..+13 in registers; of E_s x columns part*8..+7 in LDS
-    // (lane-transposed: element q of lane t at e3l[q*NA1 + t], conflict-free)
-    double m1[2][14];
-    constexpr int E3S = 4 * L::NGQ;
-    double *e3l = lds + L::oE3 + 2 * (act ? tid : 0);      // element q of this lane at e3l[(q/2)*2*E3S + (q&1)]
+    // rows (2lp, 2lp+1) of G_s x columns part*14..+13 and of E_s x columns part*8..+7, all in registers
+    double m1[2][14], e1[2][8];
     {
         const double *Gn = c.fac + seg * (D::JP + D::JC), *Es = Gn + D::JP;
 #pragma unroll
@@ -187,17 +181,16 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
                 m1[a][j] = (act && row < 49 && col < 49) ? -Gn[packed(row, col)] : 0.0;
                 if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);     // one-time loads: keep address temporaries few
             }
-        }
-        __syncthreads();      // every owner has picked up its blocks from the staging area (S is read by role B)
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const int row = 2 * lp + a;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const int col = part * 8 + j;
-                if (act) e3l[((a * 8 + j) / 2) * 2 * E3S + ((a * 8 + j) & 1)] = (row < 49 && col < 29) ? Es[row * 29 + col] : 0.0;
+                // x_C = [x_3s | x_3s+3 | T] is read in place from the node-major x~ (see xa/xb/xc3 below): the last quad lane
+                // takes columns 24..27 and, from the slot pair (u_6, T) of node 3s+3, column 28
+                const int col = part < 3 ? part * 8 + j : (j < 4 ? 24 + j : (j == 5 ? 28 : 64));
+                e1[a][j] = (act && row < 49 && col < 29) ? Es[row * 29 + col] : 0.0;
+                if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __syncthreads();      // every owner has picked up its blocks from the staging area (S is read by role B)
         __syncthreads();      // LDS-resident constants published
     }
     int jdst = -1;      // where row 2lp+part of x_J goes in the node-major x~
@@ -206,7 +199,11 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         jdst = v < 14 * N ? (v / 14) * XS + v % 14 : ((v - 14 * N) / 7) * XS + 14 + (v - 14 * N) % 7;
     }
     const double *bj = rhsJ + 56 * seg + 14 * part;
-    const double *xc = xC + 32 * seg + 8 * part;
+    // 16-byte reads of x_C: pairs 0,1 at xa, xa+2; pair 2 at xc3; pair 3 at xb
+    const double *xn0 = xn + 3 * seg * XS, *xn1 = xn0 + 3 * XS;
+    const double *xa = part == 0 ? xn0 : part == 1 ? xn0 + 8 : part == 2 ? xn1 + 2 : xn1 + 10;
+    const double *xc3 = part == 3 ? xn1 + 20 : xa + 4;
+    const double *xb = part == 0 ? xn0 + 6 : part == 1 ? xn1 : part == 2 ? xn1 + 8 : xn1 + 20;
     int it = 0, done = 0;
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: wave 0 sums the T column of A^T w ----
@@ -241,13 +238,14 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         // ---- P3 ----
         {
             double a0 = 0.0, a1 = 0.0;
-            D2 xv[4], e0[4], e1[4];
+            D2 xv[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { xv[j] = lds2(xc + 2 * j); e0[j] = lds2(e3l + 2 * j * E3S); e1[j] = lds2(e3l + (8 + 2 * j) * E3S); }
+            for (int j = 0; j < 2; j++) xv[j] = lds2(xa + 2 * j);
+            xv[2] = lds2(xc3); xv[3] = lds2(xb);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                a0 += e0[j].x * xv[j].x; a1 += e1[j].x * xv[j].x;
-                a0 += e0[j].y * xv[j].y; a1 += e1[j].y * xv[j].y;
+                a0 += e1[0][2 * j] * xv[j].x; a1 += e1[1][2 * j] * xv[j].x;
+                a0 += e1[0][2 * j + 1] * xv[j].y; a1 += e1[1][2 * j + 1] * xv[j].y;
             }
             a0 = sum4(a0); a1 = sum4(a1);
             if (jdst >= 0) xn[jdst] = part ? (t1 - a1) : (t0 - a0);
@@ -467,13 +465,13 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid, b = c.b, u = tid - L::NA1 - L::NA2;
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
-    double *rhsI = lds + L::oRhsI, *partl = lds + L::oPart, *xC = lds + L::oXC, *xn = lds + L::oXn, *xx = lds + L::oXx,
+    double *rhsI = lds + L::oRhsI, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx,
            *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *misc = lds + L::oMisc, *rI = lds + L::oRI;
     const bool isP2 = (u >> 3) < L::NPR;
     const int rp2 = u >> 3, part2 = u & 7;
     const bool isVar = u < n, isT = u == n - 1;
     const double sum_ha = lds[L::oMisc + 3];
-    // register block: row 2rp2 of S^-1 x columns part2*10..+9 in registers, row 2rp2+1 in LDS (lane-transposed pairs)
+    // register block: rows 2rp2, 2rp2+1 of S^-1 x columns part2*10..+9
     double s2[10], s2b[10];
     {
         const double *S = lds + L::oS;
@@ -492,13 +490,10 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         if (sb > 0) o2 = L::oPart + (sb - 1) * 32 + 14 + cc;
     }
     __syncthreads();          // S consumed; the staging area may now be overwritten
-    double *s2l = lds + L::oS2 + 2 * u;     // element j at s2l[(j/2)*2*NB + (j&1)]: 16-byte reads, conflict-free
-#pragma unroll
-    for (int j = 0; j < 10; j++) s2l[(j / 2) * 2 * L::NB + (j & 1)] = s2b[j];
     // variable role: the per-iteration state (x, z_b, y_b) and the box stay in registers, the gather coefficients
     // and Hessian entries live in LDS (lane-transposed)
     double *vcl = lds + L::oVc + u;
-    double v_lb, v_ub, v_rb, v_qv, v_rbi;
+    double v_rb;
     int v_rA, v_rB, v_rf, v_pb, v_gcol, v_xpos, v_rpos;
     bool v_hasG;
     {
@@ -508,13 +503,14 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
 #pragma unroll
         for (int i = 0; i < 3; i++) { vcl[(1 + i) * L::NB] = vr.dA[i]; vcl[(4 + i) * L::NB] = vr.dB[i]; }
         vcl[7 * L::NB] = vr.hd; vcl[8 * L::NB] = vr.ha; vcl[9 * L::NB] = vr.qv;
-        v_lb = vr.lb; v_ub = vr.ub; v_rb = vr.rb; v_qv = vr.qv; v_rbi = 1.0 / vr.rb;
+        vcl[10 * L::NB] = vr.lb; vcl[11 * L::NB] = vr.ub; vcl[12 * L::NB] = 1.0 / vr.rb;
+        v_rb = vr.rb;
         v_rA = vr.rA; v_rB = vr.rB; v_rf = vr.rf; v_pb = vr.pb; v_gcol = vr.gcol; v_xpos = vr.xpos; v_rpos = vr.rpos;
         v_hasG = vr.hasG;
     }
     __syncthreads();          // LDS-resident constants published
     // interface solve output: where x_I[row] goes
-    int xdst = -1, cdst1 = -1, cdst2 = -1, myIrow = -1;
+    int xdst = -1, myIrow = -1;
     if (isP2 && part2 < 2) {
         const int row = 2 * rp2 + part2;
         if (row < nI) {
@@ -522,8 +518,6 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             if (row < 14 * (NSEG + 1)) {
                 const int sb = row / 14, cc = row % 14;
                 xdst = 3 * sb * XS + cc;
-                if (sb < NSEG) cdst1 = L::oXC + sb * 32 + cc;
-                if (sb > 0) cdst2 = L::oXC + (sb - 1) * 32 + 14 + cc;
             } else if (row < nI - 1) {
                 xdst = (N - 1) * XS + 14 + (row - 14 * (NSEG + 1));
             }
@@ -558,18 +552,17 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     // dynamics row owned by this lane (u < meq): ADMM state in registers, coefficients in the V area of LDS
     const double *rcl = lds + L::oRv + (u < meq ? u : 0) * L::RS;
     const bool isDyn = u < meq;
-    double lgd = 0, zgd = 0, ygd = 0;
-    int ix0 = 0, ixf = 0, ixT = 21;
+    double zgd = 0, ygd = 0;
+    int ix0 = 0, ixf = 0;
     if (isDyn) {
         const int r = u, k = r / 14, rr = r % 14, s = k / 3;
         ix0 = 3 * s * XS + rr;
         ixf = k * XS + ((rr < 7) ? 7 + rr : 14 + rr - 7);
-        ixT = k * XS + 21;
-        lgd = -c.ws.ceq[(size_t)b * meq + r];
+        lds[L::oRv + u * L::RS + 6] = -c.ws.ceq[(size_t)b * meq + r];      // the row's bound l = u = -c_eq
     }
     auto row_dot_dyn = [&](const double *xe) -> double {
         return rcl[0] * xe[ix0] + rcl[1] * xe[ix0 + XS] + rcl[2] * xe[ix0 + 2 * XS] + rcl[3] * xe[ix0 + 3 * XS] +
-               rcl[4] * xe[ixf] + rcl[5] * xe[ixT];
+               rcl[4] * xe[ixf] + rcl[5] * xe[21];      // T is replicated at slot 21 of every node row
     };
     const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
     double x = 0, zb = 0, yb = 0;
@@ -577,9 +570,9 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: rhs = sigma x - q + rho_b zb - yb + A^T w ----
         if (isVar) {
-            const double base = sigma * x - v_qv + (v_rb * zb - yb);
-            if (isT) misc[1] = base;
-            else lds[v_rpos] = base + col_gather(wg);
+            const double sx = sigma * x, bz = v_rb * zb - yb;      // q is zero except for T (cost = T)
+            if (isT) misc[1] = (sx - 1.0) + bz;
+            else lds[v_rpos] = (sx + bz) + col_gather(wg);
         }
         __syncthreads();
         // ---- P1: (group A) ----
@@ -601,25 +594,22 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         if (isP2) {
             double a0 = 0.0, a1 = 0.0;
             const double *rv = rI + part2 * 10;
-            D2 r[5], sb2[5];
+            D2 r[5];
 #pragma unroll
-            for (int j = 0; j < 5; j++) { r[j] = lds2(rv + 2 * j); sb2[j] = lds2(s2l + 2 * j * L::NB); }
+            for (int j = 0; j < 5; j++) r[j] = lds2(rv + 2 * j);
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                a0 += s2[2 * j] * r[j].x; a1 += sb2[j].x * r[j].x;
-                a0 += s2[2 * j + 1] * r[j].y; a1 += sb2[j].y * r[j].y;
+                a0 += s2[2 * j] * r[j].x; a1 += s2b[2 * j] * r[j].x;
+                a0 += s2[2 * j + 1] * r[j].y; a1 += s2b[2 * j + 1] * r[j].y;
             }
             a0 = sum8(a0); a1 = sum8(a1);
             if (myIrow >= 0 && myIrow != nI - 1) {
                 const double xi = part2 ? a1 : a0;
                 xn[xdst] = xi;
-                if (cdst1 >= 0) lds[cdst1] = xi;
-                if (cdst2 >= 0) lds[cdst2] = xi;
             }
             if (rp2 == (nI - 1) / 2) {       // x_T is replicated (every node row, every C_s): the 8 lanes of its group share the writes
                 const double xT = ((nI - 1) & 1) ? a1 : a0;
                 for (int k = part2; k < N; k += 8) xn[k * XS + 21] = xT;
-                if (part2 < NSEG) xC[part2 * 32 + 28] = xT;
             }
         }
         __syncthreads();
@@ -630,6 +620,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         if (isDyn) {
             const double zt = row_dot_dyn(xn);
             const double zr = alpha * zt + (1.0 - alpha) * zgd;
+            const double lgd = rcl[6];
             const double zn = clip(zr + ygd * inv_rho_eq, lgd, lgd);
             ygd += rho_eq * (zr - zn);
             zgd = zn;
@@ -642,7 +633,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             const double xtv = xn[v_xpos];
             x = alpha * xtv + (1.0 - alpha) * x;
             const double zr = alpha * xtv + (1.0 - alpha) * zb;
-            const double zn = clip(zr + yb * v_rbi, v_lb, v_ub);
+            const double zn = clip(zr + yb * vcl[12 * L::NB], vcl[10 * L::NB], vcl[11 * L::NB]);
             yb += v_rb * (zr - zn);
             zb = zn;
             if (check) {
@@ -665,7 +656,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
                 const double hdv = vcl[7 * L::NB];
                 if (isT) { hx = hdv * x + sums[1]; aty = sums[0] + yb; }
                 else { hx = hdv * x + vcl[8 * L::NB] * xx[21]; aty = col_gather(ys) + yb; }
-                mx[3] = fabs(hx + aty + v_qv); mx[4] = fabs(hx); mx[5] = fabs(aty);
+                mx[3] = fabs(hx + aty + vcl[9 * L::NB]); mx[4] = fabs(hx); mx[5] = fabs(aty);
             }
             done = qp2_converged<NSEG>(cfg, mx, red, tid);
         }
