@@ -76,6 +76,48 @@ __device__ __forceinline__ void block_reduce16(double (&v)[K], double *red, int 
     __syncthreads();
 }
 
+// Workgroup reduction used inside the ADMM loop, where only the waves >= FIRSTW hold non-identity values (role A1
+// contributes nothing): contributing waves reduce inside 8-lane groups (three DPP steps) and publish one partial per
+// group; the 16 lanes of a DPP row then combine the partials of the 16 waves.  v_max_f64 is emitted directly: the
+// operands are never signalling NaNs, so the canonicalising self-max the compiler adds to fmax() is dead weight.
+// Two barriers; `red` (>= 128*K + 8 doubles) must not be shared with a reduction issued right before or after.
+__device__ __forceinline__ double max_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <bool MAX>
+__device__ __forceinline__ double red_raw(double a, double b) { return MAX ? max_raw(a, b) : a + b; }
+template <int K, bool MAX, int FIRSTW>
+__device__ __forceinline__ void block_reduce_roles(double (&v)[K], double *red, int tid, bool contributes) {
+    static_assert(K <= 8, "K");
+    if (contributes) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            double x = v[k];
+            x = red_raw<MAX>(x, dpp_mov<0xB1>(x)); x = red_raw<MAX>(x, dpp_mov<0x4E>(x)); x = red_raw<MAX>(x, dpp_mov<0x141>(x));
+            if ((tid & 7) == 0) red[(tid >> 3) * K + k] = x;
+        }
+    }
+    __syncthreads();
+    if (tid < 16 * K) {
+        const int w = tid & 15, k = tid >> 4;
+        double a = 0.0;                                   // identity of both reductions (maxima are of magnitudes)
+        if (w >= FIRSTW) {
+            const double *pr = red + (w * 8) * K + k;
+            a = pr[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) a = red_raw<MAX>(a, pr[j * K]);
+        }
+        a = red_raw<MAX>(a, dpp_mov<0xB1>(a)); a = red_raw<MAX>(a, dpp_mov<0x4E>(a));
+        a = red_raw<MAX>(a, dpp_mov<0x141>(a)); a = red_raw<MAX>(a, dpp_mov<0x140>(a));
+        if (w == 0) red[128 * K + k] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = red[128 * K + k];
+}
+
 template <int NSEG>
 struct Qp2 {
     using D = Dim<NSEG>;
@@ -119,7 +161,10 @@ struct Qp2 {
     // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
     static constexpr int oPc = oS;                             // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
     static constexpr int oVc = oPc + 5 * NA2;                  // [13][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv, lb, ub, 1/rho_b
-    static constexpr int oEndA = oVc + 13 * NB;
+    static constexpr int oRedS = oVc + 13 * NB;                // [128*2+8]  loop reductions: sums
+    static constexpr int oRedM = oRedS + 128 * 2 + 8;          // [128*6+8]  loop reductions: maxima
+    static constexpr int oStamp = oRedM + 128 * 6 + 8;         // [16]       cycle stamps (diagnostic builds only)
+    static constexpr int oEndA = oStamp + 16;
     static constexpr int size = oEndF > oEndA ? oEndF : oEndA;
     static_assert(size * 8 <= 160 * 1024 - 512, "LDS budget (a 256-byte static block precedes the dynamic region)");
     static_assert(oGk + D::N * 8 * GS < (1 << 14), "assembly stream operand offsets are 14 bits");
@@ -137,6 +182,7 @@ struct Qp2Ctx {
 };
 
 #ifdef MPCMP_STAMPS
+// the accumulators of the loop stamps live in LDS: role A1 has no registers to spare
 #define STAMP2(slot) do { if (c.tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
 #else
 #define STAMP2(slot) do { } while (0)
@@ -144,8 +190,9 @@ struct Qp2Ctx {
 
 // termination test shared by all roles (every thread contributes its maxima; result is workgroup-uniform)
 template <int NSEG>
-__device__ __forceinline__ int qp2_converged(const mpcmp_config &cfg, double (&mx)[6], double *red, int tid) {
-    block_reduce16<6, true>(mx, red, tid);
+__device__ __forceinline__ int qp2_converged(const mpcmp_config &cfg, double (&mx)[6], double *lds, int tid, bool contributes) {
+    using L = Qp2<NSEG>;
+    block_reduce_roles<6, true, L::NA1 / 64>(mx, lds + L::oRedM, tid, contributes);
     const double ep = cfg.eps_abs + cfg.eps_rel * fmax(mx[1], mx[2]);
     const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);
     return (mx[0] <= ep && mx[3] <= ed) ? 1 : 0;
@@ -160,10 +207,10 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid;
-    double *red = lds + L::oRed;
     double *rhsJ = lds + L::oRhsJ, *xn = lds + L::oXn, *tpl = lds + L::oTp, *misc = lds + L::oMisc;
 #ifdef MPCMP_STAMPS
-    unsigned long long stamp_acc[16] = {0}, stamp_t = clock64();
+    unsigned long long *stamp_acc = reinterpret_cast<unsigned long long *>(lds + L::oStamp), stamp_t = clock64();
+    if (tid == 0) for (int k = 0; k < 16; k++) stamp_acc[k] = 0;
 #endif
     const int Q = tid >> 2, part = tid & 3;
     const bool act = Q < L::NGQ;
@@ -204,7 +251,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     const double *xa = part == 0 ? xn0 : part == 1 ? xn0 + 8 : part == 2 ? xn1 + 2 : xn1 + 10;
     const double *xc3 = part == 3 ? xn1 + 20 : xa + 4;
     const double *xb = part == 0 ? xn0 + 6 : part == 1 ? xn1 : part == 2 ? xn1 + 8 : xn1 + 20;
-    int it = 0, done = 0;
+    int it = 0, done = 0, until_check = cfg.check_every;
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: wave 0 sums the T column of A^T w ----
         if (tid < 64) {
@@ -255,11 +302,16 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         // ---- E (roles A2, B) ----
         __syncthreads();
         STAMP2(7);
-        if (it % cfg.check_every == 0) {
+        const bool check = (--until_check == 0);     // countdown: a runtime integer modulo costs a serial ~30-instruction chain
+        if (check) {
+            until_check = cfg.check_every;
             double sums[2] = {0.0, 0.0};
-            block_reduce16<2, false>(sums, red, tid);
+            block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, false);
+#ifdef MPCMP_STAMPS_CHECKSPLIT
+            STAMP2(7);
+#endif
             double mx[6] = {0, 0, 0, 0, 0, 0};
-            done = qp2_converged<NSEG>(cfg, mx, red, tid);
+            done = qp2_converged<NSEG>(cfg, mx, lds, tid, false);
         }
         STAMP2(8);
         if (done) break;
@@ -280,7 +332,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid, b = c.b;
-    double *red = lds + L::oRed, *gkl = lds + L::oGk;
+    double *gkl = lds + L::oGk;
     double *rhsJ = lds + L::oRhsJ, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx, *wg = lds + L::oWg,
            *ys = lds + L::oYs, *tpl = lds + L::oTp;
     const int et = tid - L::NA1, Q = et >> 2, part = et & 3;
@@ -339,7 +391,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     __syncthreads();          // constants published (matches the barrier of the other roles)
     const double alpha = c.alpha;
     const double *bj = rhsJ + 56 * seg + 14 * part;
-    int it = 0, done = 0;
+    int it = 0, done = 0, until_check = cfg.check_every;
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A (role B) ----
         __syncthreads();
@@ -364,7 +416,8 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         // ---- P3 (role A1) ----
         __syncthreads();
         // ---- E: z~ = A x~, relaxation, projection, dual update ----
-        const bool check = (it % cfg.check_every == 0);
+        const bool check = (--until_check == 0);
+        if (check) until_check = cfg.check_every;
         if (isPath) {
             const double zt = row_dot_path(xn);
           if (ownsRow) {
@@ -382,13 +435,13 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         __syncthreads();
         if (check) {
             double sums[2] = {ownsRow ? pcl[3 * L::NA2] * yg : 0.0, 0.0};
-            block_reduce16<2, false>(sums, red, tid);
+            block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, true);
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isPath) {
                 const double ax = row_dot_path(xx);
                 if (ownsRow) { mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg); }
             }
-            done = qp2_converged<NSEG>(cfg, mx, red, tid);
+            done = qp2_converged<NSEG>(cfg, mx, lds, tid, true);
         }
         if (done) break;
     }
@@ -464,7 +517,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid, b = c.b, u = tid - L::NA1 - L::NA2;
-    double *red = lds + L::oRed, *gkl = lds + L::oGk;
+    double *gkl = lds + L::oGk;
     double *rhsI = lds + L::oRhsI, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx,
            *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *misc = lds + L::oMisc, *rI = lds + L::oRI;
     const bool isP2 = (u >> 3) < L::NPR;
@@ -566,7 +619,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     };
     const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
     double x = 0, zb = 0, yb = 0;
-    int it = 0, done = 0;
+    int it = 0, done = 0, until_check = cfg.check_every;
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: rhs = sigma x - q + rho_b zb - yb + A^T w ----
         if (isVar) {
@@ -616,7 +669,8 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         // ---- P3: (group A) ----
         __syncthreads();
         // ---- E: variables and dynamics rows ----
-        const bool check = (it % cfg.check_every == 0);
+        const bool check = (--until_check == 0);
+        if (check) until_check = cfg.check_every;
         if (isDyn) {
             const double zt = row_dot_dyn(xn);
             const double zr = alpha * zt + (1.0 - alpha) * zgd;
@@ -644,7 +698,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         __syncthreads();
         if (check) {
             double sums[2] = {isDyn ? rcl[5] * ygd : 0.0, (isVar && !isT) ? vcl[8 * L::NB] * x : 0.0};
-            block_reduce16<2, false>(sums, red, tid);
+            block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, true);
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isDyn) {
                 const double ax = row_dot_dyn(xx);
@@ -658,7 +712,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
                 else { hx = hdv * x + vcl[8 * L::NB] * xx[21]; aty = col_gather(ys) + yb; }
                 mx[3] = fabs(hx + aty + vcl[9 * L::NB]); mx[4] = fabs(hx); mx[5] = fabs(aty);
             }
-            done = qp2_converged<NSEG>(cfg, mx, red, tid);
+            done = qp2_converged<NSEG>(cfg, mx, lds, tid, true);
         }
         if (done) break;
     }
