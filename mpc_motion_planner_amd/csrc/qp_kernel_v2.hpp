@@ -28,10 +28,13 @@ __device__ __forceinline__ double dpp_mov(double x) {
 __device__ __forceinline__ double sum2(double x) { return x + dpp_mov<0xB1>(x); }                  // lanes i, i^1
 __device__ __forceinline__ double sum4(double x) { x += dpp_mov<0xB1>(x); return x + dpp_mov<0x4E>(x); }
 __device__ __forceinline__ double sum8(double x) { x = sum4(x); return x + dpp_mov<0x141>(x); }   // + row_half_mirror
-__device__ __forceinline__ double wave_sum(double x) {
+__device__ __forceinline__ double read_lane(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double x) {      // the total, valid in lanes 0..15 (no LDS permutes, no index registers)
     x = sum8(x); x += dpp_mov<0x140>(x);                                                           // row_mirror: 16 lanes
-    x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
-    return x;
+    return (x + read_lane(x, 16)) + (read_lane(x, 32) + read_lane(x, 48));
 }
 
 // 16-byte LDS read of two consecutive doubles (ds_read_b128: full LDS rate; ds_read2_b64 runs at half rate)
@@ -161,7 +164,9 @@ struct Qp2 {
     // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
     static constexpr int oPc = oS;                             // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
     static constexpr int oVc = oPc + 5 * NA2;                  // [13][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv, lb, ub, 1/rho_b
-    static constexpr int oRedS = oVc + 13 * NB;                // [128*2+8]  loop reductions: sums
+    static constexpr int oGp = oVc + 13 * NB;                  // [N][XS]    path-row part of A^T w, node-major like x~
+    static constexpr int oGpy = oGp + D::N * XS;               // [N][XS]    path-row part of A^T y (termination tests)
+    static constexpr int oRedS = oGpy + D::N * XS;             // [128*2+8]  loop reductions: sums
     static constexpr int oRedM = oRedS + 128 * 2 + 8;          // [128*6+8]  loop reductions: maxima
     static constexpr int oStamp = oRedM + 128 * 6 + 8;         // [16]       cycle stamps (diagnostic builds only)
     static constexpr int oEndA = oStamp + 16;
@@ -203,7 +208,7 @@ template <int NSEG>
 __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     using D = Dim<NSEG>;
     using L = Qp2<NSEG>;
-    constexpr int N = D::N, m = D::m, XS = L::XS;
+    constexpr int N = D::N, meq = D::meq, XS = L::XS;
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid;
@@ -256,7 +261,8 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         // ---- A: wave 0 sums the T column of A^T w ----
         if (tid < 64) {
             double sacc = 0.0;
-            for (int r = tid; r < m; r += 64) sacc += tpl[r];
+            for (int r = tid; r < meq; r += 64) sacc += tpl[r];          // dynamics rows
+            if (tid < N) sacc += lds[L::oGp + tid * XS + 21];            // path rows: per-node column sums (role A2)
             sacc = wave_sum(sacc);
             if (tid == 0) misc[2] = sacc;
         }
@@ -328,13 +334,12 @@ template <int NSEG>
 __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     using D = Dim<NSEG>;
     using L = Qp2<NSEG>;
-    constexpr int N = D::N, n = D::n, meq = D::meq, GS = L::GS, XS = L::XS;
+    constexpr int N = D::N, meq = D::meq, GS = L::GS, XS = L::XS;
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid, b = c.b;
     double *gkl = lds + L::oGk;
-    double *rhsJ = lds + L::oRhsJ, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx, *wg = lds + L::oWg,
-           *ys = lds + L::oYs, *tpl = lds + L::oTp;
+    double *rhsJ = lds + L::oRhsJ, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx;
     const int et = tid - L::NA1, Q = et >> 2, part = et & 3;
     const bool act = Q < L::NEQ;
     const int seg = act ? Q / 15 : 0, le = act ? Q % 15 : 0;
@@ -372,9 +377,16 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         pcl[3 * L::NA2] = c.ws.Gk[((size_t)b * N + pk) * 176 + q * 22 + 21];
         pcl[4 * L::NA2] = 1.0 / pcl[2 * L::NA2];
     }
+    if (isPath && prp == 0) {      // A^T w is read by the first rhs before any row has been updated
+#pragma unroll
+        for (int j = 0; j < 6; j++) lds[L::oGp + pk * XS + pq * 6 + j] = 0.0;
+    }
     const int groff = isPath ? (pk * 8 + 2 * prp) * GS + pq * 6 : 0;     // columns 6pq .. 6pq+5 of the 24-wide padded rows
     const int xnoff = isPath ? pk * XS + pq * 6 : 0;
-    auto row_dot_path = [&](const double *xe) -> double {
+    // z~ of the owned row (lanes 0,1 of the quad) and, from the same Jacobian operands, this node's path-row part of
+    // A^T w: every lane forms its six columns of g_row0*w0 + g_row1*w1, the four row pairs of the node (lane bits 2,3 of
+    // the DPP row) are summed with two row rotations, and the lanes of pair 0 publish the node's 24 padded columns.
+    auto path_rows = [&](const double *xe, double *gdst, auto &&row_update) -> double {
         const double *g0 = gkl + groff, *g1 = g0 + GS, *xv = xe + xnoff;
         D2 x2[3], p0[3], p1[3];
 #pragma unroll
@@ -386,7 +398,17 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             a0 += p0[j].y * x2[j].y; a1 += p1[j].y * x2[j].y;
         }
         a0 = sum4(a0); a1 = sum4(a1);
-        return (pq & 1) ? a1 : a0;
+        const double ax = (pq & 1) ? a1 : a0;
+        const double wq = row_update(ax);                                   // owners: the row's multiplier-like value
+        const double w0 = dpp_mov<0x00>(wq), w1 = dpp_mov<0x55>(wq);        // quad broadcast of lanes 0 and 1
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double cx = p0[j].x * w0 + p1[j].x * w1, cy = p0[j].y * w0 + p1[j].y * w1;
+            cx += dpp_mov<0x128>(cx); cy += dpp_mov<0x128>(cy);             // row_ror:8
+            cx += dpp_mov<0x124>(cx); cy += dpp_mov<0x124>(cy);             // row_ror:4
+            if (prp == 0) { D2 o; o.x = cx; o.y = cy; *reinterpret_cast<D2 *>(gdst + xnoff + 2 * j) = o; }
+        }
+        return ax;
     };
     __syncthreads();          // constants published (matches the barrier of the other roles)
     const double alpha = c.alpha;
@@ -419,28 +441,28 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
         if (isPath) {
-            const double zt = row_dot_path(xn);
-          if (ownsRow) {
-            const double rr_ = pcl[2 * L::NA2];
-            const double zr = alpha * zt + (1.0 - alpha) * zg;
-            const double zn = clip(zr + yg * pcl[4 * L::NA2], pcl[0], pcl[L::NA2]);
-            yg += rr_ * (zr - zn);
-            zg = zn;
-            const double w = rr_ * zg - yg;
-            wg[myrow] = w;
-            tpl[myrow] = pcl[3 * L::NA2] * w;
-            if (check) ys[myrow] = yg;
-          }
+            path_rows(xn, lds + L::oGp, [&](double zt) -> double {
+                double w = 0.0;
+                if (ownsRow) {
+                    const double rr_ = pcl[2 * L::NA2];
+                    const double zr = alpha * zt + (1.0 - alpha) * zg;
+                    const double zn = clip(zr + yg * pcl[4 * L::NA2], pcl[0], pcl[L::NA2]);
+                    yg += rr_ * (zr - zn);
+                    zg = zn;
+                    w = rr_ * zg - yg;
+                }
+                return w;
+            });
         }
         __syncthreads();
         if (check) {
             double sums[2] = {ownsRow ? pcl[3 * L::NA2] * yg : 0.0, 0.0};
-            block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, true);
             double mx[6] = {0, 0, 0, 0, 0, 0};
-            if (isPath) {
-                const double ax = row_dot_path(xx);
+            if (isPath) {       // A x of the owned row and the path-row part of A^T y (read by role B after the reduction's barriers)
+                const double ax = path_rows(xx, lds + L::oGpy, [&](double) -> double { return ownsRow ? yg : 0.0; });
                 if (ownsRow) { mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg); }
             }
+            block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, true);
             done = qp2_converged<NSEG>(cfg, mx, lds, tid, true);
         }
         if (done) break;
@@ -513,11 +535,10 @@ template <int NSEG>
 __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     using D = Dim<NSEG>;
     using L = Qp2<NSEG>;
-    constexpr int N = D::N, n = D::n, meq = D::meq, m = D::m, nI = D::nI, GS = L::GS, XS = L::XS;
+    constexpr int N = D::N, n = D::n, meq = D::meq, m = D::m, nI = D::nI, XS = L::XS;
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid, b = c.b, u = tid - L::NA1 - L::NA2;
-    double *gkl = lds + L::oGk;
     double *rhsI = lds + L::oRhsI, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx,
            *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *misc = lds + L::oMisc, *rI = lds + L::oRI;
     const bool isP2 = (u >> 3) < L::NPR;
@@ -547,8 +568,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     // and Hessian entries live in LDS (lane-transposed)
     double *vcl = lds + L::oVc + u;
     double v_rb;
-    int v_rA, v_rB, v_rf, v_pb, v_gcol, v_xpos, v_rpos;
-    bool v_hasG;
+    int v_rA, v_rB, v_rf, v_xpos, v_rpos;
     {
         VarRole vr = make_var_role<NSEG>(cfg, c.ws, b, u, isVar, c.ts, c.tsT, c.rho_in, c.rho_eq);
         if (isT) { vr.hd = sum_ha + cfg.hess_reg; vr.ha = 0.0; }
@@ -558,8 +578,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         vcl[7 * L::NB] = vr.hd; vcl[8 * L::NB] = vr.ha; vcl[9 * L::NB] = vr.qv;
         vcl[10 * L::NB] = vr.lb; vcl[11 * L::NB] = vr.ub; vcl[12 * L::NB] = 1.0 / vr.rb;
         v_rb = vr.rb;
-        v_rA = vr.rA; v_rB = vr.rB; v_rf = vr.rf; v_pb = vr.pb; v_gcol = vr.gcol; v_xpos = vr.xpos; v_rpos = vr.rpos;
-        v_hasG = vr.hasG;
+        v_rA = vr.rA; v_rB = vr.rB; v_rf = vr.rf; v_xpos = vr.xpos; v_rpos = vr.rpos;
     }
     __syncthreads();          // LDS-resident constants published
     // interface solve output: where x_I[row] goes
@@ -576,30 +595,18 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             }
         }
     }
-    auto col_gather = [&](const double *w) -> double {
-        double s = 0.0;
-        if (v_hasG) {                                  // batch 1: path-row part (8 Jacobian entries, 4 x 16-byte w reads)
-            const double *gc = gkl + v_gcol;
-            double gv[8];
-            D2 w2[4];
+    // A^T w restricted to this variable's column: the path-row part is formed by role A2 (gp, node-major like x~), the
+    // dynamics-row part is gathered here
+    auto col_gather = [&](const double *w, const double *gp) -> double {
+        double cv[7], wv[7];
+        double s = gp[v_xpos];
+        cv[0] = vcl[0]; wv[0] = w[v_rf];
 #pragma unroll
-            for (int q = 0; q < 8; q++) gv[q] = gc[q * GS];
+        for (int i = 0; i < 3; i++) { cv[1 + i] = vcl[(1 + i) * L::NB]; wv[1 + i] = w[v_rA + 14 * i]; }
 #pragma unroll
-            for (int q = 0; q < 4; q++) w2[q] = lds2(w + v_pb + 2 * q);
+        for (int i = 0; i < 3; i++) { cv[4 + i] = vcl[(4 + i) * L::NB]; wv[4 + i] = w[v_rB + 14 * i]; }
 #pragma unroll
-            for (int q = 0; q < 4; q++) { s += gv[2 * q] * w2[q].x; s += gv[2 * q + 1] * w2[q].y; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {                                              // batch 2: dynamics-row part
-            double cv[7], wv[7];
-            cv[0] = vcl[0]; wv[0] = w[v_rf];
-#pragma unroll
-            for (int i = 0; i < 3; i++) { cv[1 + i] = vcl[(1 + i) * L::NB]; wv[1 + i] = w[v_rA + 14 * i]; }
-#pragma unroll
-            for (int i = 0; i < 3; i++) { cv[4 + i] = vcl[(4 + i) * L::NB]; wv[4 + i] = w[v_rB + 14 * i]; }
-#pragma unroll
-            for (int i = 0; i < 7; i++) s += cv[i] * wv[i];
-        }
+        for (int i = 0; i < 7; i++) s += cv[i] * wv[i];
         return s;
     };
     // dynamics row owned by this lane (u < meq): ADMM state in registers, coefficients in the V area of LDS
@@ -625,7 +632,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         if (isVar) {
             const double sx = sigma * x, bz = v_rb * zb - yb;      // q is zero except for T (cost = T)
             if (isT) misc[1] = (sx - 1.0) + bz;
-            else lds[v_rpos] = (sx + bz) + col_gather(wg);
+            else lds[v_rpos] = (sx + bz) + col_gather(wg, lds + L::oGp);
         }
         __syncthreads();
         // ---- P1: (group A) ----
@@ -709,7 +716,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
                 double hx, aty;
                 const double hdv = vcl[7 * L::NB];
                 if (isT) { hx = hdv * x + sums[1]; aty = sums[0] + yb; }
-                else { hx = hdv * x + vcl[8 * L::NB] * xx[21]; aty = col_gather(ys) + yb; }
+                else { hx = hdv * x + vcl[8 * L::NB] * xx[21]; aty = col_gather(ys, lds + L::oGpy) + yb; }
                 mx[3] = fabs(hx + aty + vcl[9 * L::NB]); mx[4] = fabs(hx); mx[5] = fabs(aty);
             }
             done = qp2_converged<NSEG>(cfg, mx, lds, tid, true);
