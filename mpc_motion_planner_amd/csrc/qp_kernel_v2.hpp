@@ -158,9 +158,10 @@ struct Qp2 {
     static constexpr int oEh = oKJC + HS * D::JC;              // [HS][JC]
     static constexpr int oScr = oEh + HS * D::JC;              // [32] partial sums of split entries
     static constexpr int oRdv = oScr + 32;                     // [2][4] pivot reciprocals of the running sweep (double buffered)
-    static constexpr int oCol = oRdv + 8;                      // [2][CB] current / next pivot column(s) of the sweep
+    static constexpr int oCol = (oRdv + 8 + 1) / 2 * 2;                      // [2][CB] current / next pivot column(s) of the sweep
     static constexpr int CB = 4 * 64 > ((D::nI + 15) / 16 * 16) ? 4 * 64 : ((D::nI + 15) / 16 * 16);
     static constexpr int oEndF = oCol + 2 * CB;
+    static_assert(oCol % 2 == 0 && CB % 2 == 0, "16-byte reads of the pivot column");
     // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
     static constexpr int oPc = oS;                             // [5][NA2]   path-row lg, ug, rho, coefT, 1/rho
     static constexpr int oVc = oPc + 5 * NA2;                  // [13][NB]   variable role: cf, dA[3], dB[3], hd, ha, qv, lb, ub, 1/rho_b
@@ -821,59 +822,95 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         while (i * (i + 1) / 2 > e) i--;
         j = e - i * (i + 1) / 2;
     };
-    // symmetric sweep of `nblk` packed nb x nb SPD blocks (stride bstride) in LDS: A <- -(A^-1).
-    // Each thread keeps its (up to EPT) entries in registers for the whole sweep; per step only the pivot column and
-    // the pivot reciprocal travel through LDS (double buffered), so a step costs ONE barrier and no division outside
-    // the pivot owner:   a_ij -= a_ik a_jk / a_kk,   a_ik <- a_ik / a_kk,   a_kk <- -1 / a_kk.
-    auto sweep = [&](double *A, int nb, int cnt, int nblk, int bstride) {
-        constexpr int EPT = 5, CB = L::CB;
+    // symmetric sweep of `nblk` packed nb x nb SPD blocks (stride bstride) in LDS: A <- -(A^-1):
+    //     a_ij -= a_ik a_jk / a_kk,   a_ik <- a_ik / a_kk,   a_kk <- -1 / a_kk      for k = 0 .. nb-1.
+    // A thread owns one 4x4 tile of the lower block triangle (diagonal tiles hold both triangles, the lower one is
+    // authoritative) in registers for the whole sweep, so a step is 16 FMAs on four 16-byte LDS reads of the pivot column.
+    // Per step only the pivot column and the pivot reciprocal travel through LDS (double buffered): ONE barrier per step
+    // and no division outside the pivot owner. The step loop is unrolled over k mod 4, which makes every register index
+    // of the pivot row/column handling static.
+    auto sweep = [&](double *A, int nb, int nblk, int bstride) {
+        constexpr int CB = L::CB;
+        const int nt4 = (nb + 3) >> 2, ntile = nt4 * (nt4 + 1) / 2;
         const int cst = nblk > 1 ? 64 : CB;          // column-buffer stride per block
-        double *colb = lds + L::oCol;
-        int ei[EPT], ej[EPT], eb[EPT], eo[EPT];
-        double val[EPT];
+        const bool live = tid < ntile * nblk;
+        int blk = 0, Ib = 0, Jb = 0;
+        if (live) { blk = tid / ntile; tri_decode(tid % ntile, Ib, Jb); }
+        const bool diag = live && Ib == Jb;
+        double *Ab = A + blk * bstride;
+        double *cb0 = lds + L::oCol + blk * cst;
+        double v[4][4];
 #pragma unroll
-        for (int q = 0; q < EPT; q++) {
-            const int ge = tid + q * NT;
-            if (ge < cnt * nblk) {
-                const int blk = ge / cnt, e = ge % cnt;
-                tri_decode(e, ei[q], ej[q]);
-                eb[q] = blk; eo[q] = blk * bstride + e;
-                val[q] = A[eo[q]];
-                if (ej[q] == 0) {                    // column 0 (and its pivot reciprocal)
-                    colb[blk * cst + ei[q]] = val[q];
-                    if (ei[q] == 0) { if (!(val[q] > 0.0)) status |= 2; rdv[blk] = 1.0 / val[q]; }
-                }
-            } else { ei[q] = -1; ej[q] = 0; eo[q] = 0; eb[q] = 0; val[q] = 0.0; }
+        for (int a = 0; a < 4; a++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 4 * Ib + a, j = 4 * Jb + q;
+                v[a][q] = (live && i < nb && j < nb) ? Ab[i >= j ? packed(i, j) : packed(j, i)] : 0.0;
+            }
+        }
+        if (live && Jb == 0) {                       // column 0 (and its pivot reciprocal)
+#pragma unroll
+            for (int a = 0; a < 4; a++) cb0[4 * Ib + a] = v[a][0];
+            if (Ib == 0) { if (!(v[0][0] > 0.0)) status |= 2; rdv[blk] = 1.0 / v[0][0]; }
         }
         __syncthreads();
-        // invalid slots point at entry (0,0) of block 0 and never publish: the update below is branch-free
-        bool live[EPT];
+        for (int kb = 0; kb < nt4; kb++) {
 #pragma unroll
-        for (int q = 0; q < EPT; q++) { live[q] = ei[q] >= 0; if (!live[q]) ei[q] = 0; }
-        for (int k = 0; k < nb; k++) {
-            const double *cur = colb + (k & 1) * CB, *rdc = rdv + (k & 1) * 4;
-            double *nxt = colb + ((k + 1) & 1) * CB, *rdn = rdv + ((k + 1) & 1) * 4;
-            double pv = 0.0;             // value of the next pivot if this thread owns it
-            int pblk = -1;
+            for (int ka = 0; ka < 4; ka++) {
+                const int k = 4 * kb + ka;
+                if (k < nb) {                        // workgroup-uniform
+                    const int k1a = (ka + 1) & 3, k1b = kb + (ka == 3 ? 1 : 0);
+                    if (live) {
+                        const double *cur = cb0 + (k & 1) * CB;
+                        double *nxt = cb0 + ((k + 1) & 1) * CB;
+                        const D2 ci0 = lds2(cur + 4 * Ib), ci1 = lds2(cur + 4 * Ib + 2);
+                        const D2 cj0 = lds2(cur + 4 * Jb), cj1 = lds2(cur + 4 * Jb + 2);
+                        const double rd = rdv[(k & 1) * 4 + blk];
+                        const double cI[4] = {ci0.x, ci0.y, ci1.x, ci1.y};
+                        const double rJ[4] = {cj0.x * rd, cj0.y * rd, cj1.x * rd, cj1.y * rd};
 #pragma unroll
-            for (int q = 0; q < EPT; q++) {
-                const int i = ei[q], j = ej[q];
-                const double *cb = cur + eb[q] * cst;
-                const double rd = rdc[eb[q]], ci = cb[i], cj = cb[j];
-                const double upd = val[q] - ci * (cj * rd);
-                const double colv = (j == k ? ci : cj) * rd;
-                const bool ik = i == k, jk = j == k;
-                const double v = (ik && jk) ? -rd : ((ik || jk) ? colv : upd);
-                val[q] = v;
-                const bool pub = live[q] && (j == k + 1 || i == k + 1);
-                if (pub) nxt[eb[q] * cst + (j == k + 1 ? i : j)] = v;
-                if (pub && i == k + 1 && j == k + 1) { pv = v; pblk = eb[q]; }
+                        for (int a = 0; a < 4; a++) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) v[a][q] = v[a][q] - cI[a] * rJ[q];
+                        }
+                        if (Ib == kb) {              // pivot row
+#pragma unroll
+                            for (int q = 0; q < 4; q++) v[ka][q] = rJ[q];
+                        }
+                        if (Jb == kb) {              // pivot column
+#pragma unroll
+                            for (int a = 0; a < 4; a++) v[a][ka] = cI[a] * rd;
+                            if (Ib == kb) v[ka][ka] = -rd;
+                        }
+                        if (k + 1 < nb) {            // publish column k+1 and its pivot reciprocal
+                            if (Jb == k1b) {
+#pragma unroll
+                                for (int a = 0; a < 4; a++) nxt[4 * Ib + a] = (diag && a < k1a) ? v[k1a][a] : v[a][k1a];
+                                if (diag) {
+                                    const double pv = v[k1a][k1a];
+                                    if (!(pv > 0.0)) status |= 2;
+                                    rdv[((k + 1) & 1) * 4 + blk] = 1.0 / pv;
+                                }
+                            } else if (Ib == k1b) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) nxt[4 * Jb + q] = v[k1a][q];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
             }
-            if (pblk >= 0) { if (!(pv > 0.0)) status |= 2; rdn[pblk] = 1.0 / pv; }
-            __syncthreads();
         }
+        if (live) {
 #pragma unroll
-        for (int q = 0; q < EPT; q++) if (live[q]) A[eo[q]] = val[q];
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = 4 * Ib + a, j = 4 * Jb + q;
+                    if (i < nb && j <= i) Ab[packed(i, j)] = v[a][q];
+                }
+            }
+        }
         __syncthreads();
     };
     // pass 0: interface block S and every interior diagonal block K_JJ,s
@@ -896,7 +933,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
     }
     __syncthreads();
     STAMP(9);
-    sweep(KJJ, 49, D::JP, NSEG, D::JP);            // K_JJ,s <- -G_s, all segments concurrently
+    sweep(KJJ, 49, NSEG, D::JP);                   // K_JJ,s <- -G_s, all segments concurrently
     STAMP(11);
     for (int s0 = 0; s0 < NSEG; s0 += L::HS) {
         const int nh = (NSEG - s0 < L::HS) ? NSEG - s0 : L::HS;
@@ -970,7 +1007,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         STAMP(14);
     }
     STAMP(1);
-    sweep(S, nI, D::SP, 1, D::SP);                 // S <- -(S^-1)
+    sweep(S, nI, 1, D::SP);                        // S <- -(S^-1)
     STAMP(2);
     {
         const int any = __syncthreads_or(status);
