@@ -143,8 +143,7 @@ struct Qp2 {
     static constexpr int oRhsJ = oGk + D::N * 8 * GS;          // [NSEG][56]   rhs, interior part (zero padded)
     static constexpr int oRhsI = oRhsJ + NSEG * 56;            // [80]         rhs, interface part
     static constexpr int oRI = oRhsI + 2 * ((D::nI + 2) / 2);  // [80]         r_I = b_I - sum_s E_s^T b_Js
-    static constexpr int oPart = oRI + 80;                     // [NSEG][32]   E_s^T b_Js
-    static constexpr int oXn = oPart + NSEG * 32;              // [N][XS]      x~ node-major
+    static constexpr int oXn = oRI + 80;                       // [N][XS]      x~ node-major
     static constexpr int oXx = oXn + D::N * XS;                // [N][XS]      x  node-major (termination tests)
     static constexpr int oWg = oXx + D::N * XS;                // [m]          w = rho z - y   (general rows)
     static constexpr int oYs = oWg + D::m;                     // [m]          y (termination tests)
@@ -285,8 +284,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         }
         __syncthreads();
         STAMP2(4);
-        // ---- P2a, P2b (role B) ----
-        __syncthreads();
+        // ---- P2 (role B) ----
         __syncthreads();
         STAMP2(5);
         // ---- P3 ----
@@ -340,27 +338,47 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid, b = c.b;
     double *gkl = lds + L::oGk;
-    double *rhsJ = lds + L::oRhsJ, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx;
-    const int et = tid - L::NA1, Q = et >> 2, part = et & 3;
-    const bool act = Q < L::NEQ;
-    const int seg = act ? Q / 15 : 0, le = act ? Q % 15 : 0;
-    // register block: rows (2le, 2le+1) of E_s^T x columns part*14..+13
+    double *rhsJ = lds + L::oRhsJ, *rhsI = lds + L::oRhsI, *rI = lds + L::oRI, *xn = lds + L::oXn, *xx = lds + L::oXx;
+    const int et = tid - L::NA1, part = et & 3;
+    // P1 lanes of this role: one lane group per PAIR of interface entries, spanning every segment the entries couple to,
+    // so the group's reduction is the complete sum_s (E_s^T b_Js) of its entries and r_I is written without a further
+    // phase.  Groups: T (column 28 of every segment, 4*NSEG lanes, one row), then the entries of the interior interface
+    // nodes (two segments, 8 lanes per pair), then those of the first and last node (one segment, 4 lanes per pair).
+    // A lane holds rows (ec0, ec1) of E_seg^T x columns part*14..+13 in registers.
+    constexpr int TL = 4 * NSEG, G8 = (NSEG - 1) * 56;
+    static_assert(TL + G8 + 56 == 4 * L::NEQ && (TL == 8 || TL == 16), "lane groups of role A2");
+    int seg = 0, ec0 = -1, ec1 = -1, irow = -1;         // segment, E columns of the two rows, interface index of row 0
+    double f8 = 0.0, f16 = 0.0;                         // reduction width beyond the quad, as multipliers
+    int lig = et & 3;                                   // lane index inside the group
+    if (et < TL) {
+        seg = et >> 2; ec0 = 28; irow = D::nI - 1; lig = et;
+        f8 = 1.0; f16 = TL == 16 ? 1.0 : 0.0;
+    } else if (et < TL + G8) {
+        const int e = et - TL, nd = 1 + e / 56, pr = (e % 56) / 8, half = (e % 8) / 4, cc = 2 * pr;
+        seg = nd - 1 + half; ec0 = half == 0 ? 14 + cc : cc; ec1 = ec0 + 1; irow = 14 * nd + cc; lig = e % 8;
+        f8 = 1.0;
+    } else if (et < TL + G8 + 56) {
+        const int e = et - TL - G8, side = e / 28, pr = (e % 28) / 4, cc = 2 * pr;
+        seg = side == 0 ? 0 : NSEG - 1; ec0 = side == 0 ? cc : 14 + cc; ec1 = ec0 + 1; irow = (side == 0 ? 0 : 14 * NSEG) + cc;
+    }
     double m1[2][14];
     {
         const double *Es = c.fac + seg * (D::JP + D::JC) + D::JP;
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            const int cc = 2 * le + a;
+            const int cc = a == 0 ? ec0 : ec1;
 #pragma unroll
             for (int j = 0; j < 14; j++) {
                 const int i = part * 14 + j;
-                m1[a][j] = (act && cc < 29 && i < 49) ? Es[i * 29 + cc] : 0.0;
+                m1[a][j] = (cc >= 0 && i < 49) ? Es[i * 29 + cc] : 0.0;
                 if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
     __syncthreads();          // (matches role A1/B: register blocks picked up)
-    const int pdst = (act && part < 2 && 2 * le + part < 29) ? seg * 32 + 2 * le + part : -1;
+    // writer lanes (0 and 1 of a group): r_I[i] = (b_I[i] + extra) - sum, extra = the T column sum for T, else the zero slot
+    const int rdst = (lig < 2 && irow >= 0 && (lig == 0 || ec1 >= 0)) ? irow + lig : -1;
+    const int xoff = (rdst == D::nI - 1) ? L::oMisc + 2 : L::oMisc;
     // path rows: the row constants live in LDS (lane-transposed), only the ADMM state (z, y) of the owned row stays in registers
     const bool isPath = et < 16 * N;                    // four lanes per pair of path rows (six columns each)
     const int pk = et >> 4, prp = (et & 15) >> 2, pq = et & 3;
@@ -430,11 +448,12 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
                 a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
             }
             a0 = sum4(a0); a1 = sum4(a1);
-            if (pdst >= 0) partl[pdst] = part ? a1 : a0;
+            a0 += f8 * dpp_mov<0x141>(a0); a1 += f8 * dpp_mov<0x141>(a1);       // 8-lane groups: row_half_mirror
+            a0 += f16 * dpp_mov<0x140>(a0);                                       // the T group of 16: row_mirror
+            if (rdst >= 0) rI[rdst] = (rhsI[rdst] + lds[xoff]) - (lig ? a1 : a0);
         }
         __syncthreads();
-        // ---- P2a, P2b (role B) ----
-        __syncthreads();
+        // ---- P2 (role B) ----
         __syncthreads();
         // ---- P3 (role A1) ----
         __syncthreads();
@@ -492,7 +511,11 @@ __device__ __forceinline__ VarRole make_var_role(const mpcmp_config &cfg, const 
     if (isVar) {
         const int v = u;
         const int ipos = int_of_ext(NSEG, v);
-        vr.rpos = ipos < nJ ? L::oRhsJ + 56 * (ipos / 49) + ipos % 49 : L::oRhsI + (ipos - nJ);
+        // rhs slot: interior -> b_J, interface -> b_I; the controls of the last node couple to no interior block, so their
+        // b_I entry IS r_I
+        const int ia = ipos - nJ;
+        vr.rpos = ipos < nJ ? L::oRhsJ + 56 * (ipos / 49) + ipos % 49
+                            : ((ia >= 14 * (NSEG + 1) && ia < D::nI - 1) ? L::oRI + ia : L::oRhsI + ia);
         double lo, hi;
         var_box<NSEG>(cfg, ws.x0 + 14 * b, ws.xf + 14 * b, v, lo, hi);
         vr.rb = (hi - lo < 1e-4) ? rho_eq : rho_in;
@@ -540,8 +563,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid, b = c.b, u = tid - L::NA1 - L::NA2;
-    double *rhsI = lds + L::oRhsI, *partl = lds + L::oPart, *xn = lds + L::oXn, *xx = lds + L::oXx,
-           *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *misc = lds + L::oMisc, *rI = lds + L::oRI;
+    double *xn = lds + L::oXn, *xx = lds + L::oXx, *wg = lds + L::oWg, *ys = lds + L::oYs, *tpl = lds + L::oTp, *rI = lds + L::oRI;
     const bool isP2 = (u >> 3) < L::NPR;
     const int rp2 = u >> 3, part2 = u & 7;
     const bool isVar = u < n, isT = u == n - 1;
@@ -556,13 +578,6 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             s2[j] = (isP2 && 2 * rp2 < nI && col < nI) ? -S[packed(2 * rp2, col)] : 0.0;
             s2b[j] = (isP2 && 2 * rp2 + 1 < nI && col < nI) ? -S[packed(2 * rp2 + 1, col)] : 0.0;
         }
-    }
-    // P2a role (lanes u < nI): which E^T b terms enter r_I[u]
-    int o1 = L::oMisc, o2 = L::oMisc;                   // zero slot
-    if (u < 14 * (NSEG + 1)) {
-        const int sb = u / 14, cc = u % 14;
-        if (sb < NSEG) o1 = L::oPart + sb * 32 + cc;
-        if (sb > 0) o2 = L::oPart + (sb - 1) * 32 + 14 + cc;
     }
     __syncthreads();          // S consumed; the staging area may now be overwritten
     // variable role: the per-iteration state (x, z_b, y_b) and the box stay in registers, the gather coefficients
@@ -632,26 +647,13 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         // ---- A: rhs = sigma x - q + rho_b zb - yb + A^T w ----
         if (isVar) {
             const double sx = sigma * x, bz = v_rb * zb - yb;      // q is zero except for T (cost = T)
-            if (isT) misc[1] = (sx - 1.0) + bz;
+            if (isT) lds[v_rpos] = (sx - 1.0) + bz;      // b_T; its column sum and coupling terms are added by roles A1/A2
             else lds[v_rpos] = (sx + bz) + col_gather(wg, lds + L::oGp);
         }
         __syncthreads();
         // ---- P1: (group A) ----
         __syncthreads();
-        // ---- P2a: r_I = b_I - sum_s E_s^T b_Js  (one lane per interface entry) ----
-        if (u < nI) {
-            double r;
-            if (u == nI - 1) {       // T: b_T = (sigma x_T - q_T + box terms) + sum_r coefT_r w_r
-                r = misc[1] + misc[2];
-#pragma unroll
-                for (int sg = 0; sg < NSEG; sg++) r -= partl[sg * 32 + 28];
-            } else {
-                r = rhsI[u] - lds[o1] - lds[o2];
-            }
-            rI[u] = r;
-        }
-        __syncthreads();
-        // ---- P2b: x_I = S^-1 r_I  (2 rows x 10 columns per lane, 8-lane reduction) ----
+        // ---- P2: x_I = S^-1 r_I  (2 rows x 10 columns per lane, 8-lane reduction; r_I was completed by role A2) ----
         if (isP2) {
             double a0 = 0.0, a1 = 0.0;
             const double *rv = rI + part2 * 10;
