@@ -585,12 +585,13 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     double *vcl = lds + L::oVc + u;
     double v_rb;
     int v_rA, v_rB, v_rf, v_xpos, v_rpos;
+    double cv[7];                                       // column of the dynamics rows: cf, dA[3], dB[3]
     {
         VarRole vr = make_var_role<NSEG>(cfg, c.ws, b, u, isVar, c.ts, c.tsT, c.rho_in, c.rho_eq);
         if (isT) { vr.hd = sum_ha + cfg.hess_reg; vr.ha = 0.0; }
-        vcl[0] = vr.cf;
+        cv[0] = vr.cf;
 #pragma unroll
-        for (int i = 0; i < 3; i++) { vcl[(1 + i) * L::NB] = vr.dA[i]; vcl[(4 + i) * L::NB] = vr.dB[i]; }
+        for (int i = 0; i < 3; i++) { cv[1 + i] = vr.dA[i]; cv[4 + i] = vr.dB[i]; }
         vcl[7 * L::NB] = vr.hd; vcl[8 * L::NB] = vr.ha; vcl[9 * L::NB] = vr.qv;
         vcl[10 * L::NB] = vr.lb; vcl[11 * L::NB] = vr.ub; vcl[12 * L::NB] = 1.0 / vr.rb;
         v_rb = vr.rb;
@@ -614,13 +615,11 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     // A^T w restricted to this variable's column: the path-row part is formed by role A2 (gp, node-major like x~), the
     // dynamics-row part is gathered here
     auto col_gather = [&](const double *w, const double *gp) -> double {
-        double cv[7], wv[7];
+        double wv[7];
         double s = gp[v_xpos];
-        cv[0] = vcl[0]; wv[0] = w[v_rf];
+        wv[0] = w[v_rf];
 #pragma unroll
-        for (int i = 0; i < 3; i++) { cv[1 + i] = vcl[(1 + i) * L::NB]; wv[1 + i] = w[v_rA + 14 * i]; }
-#pragma unroll
-        for (int i = 0; i < 3; i++) { cv[4 + i] = vcl[(4 + i) * L::NB]; wv[4 + i] = w[v_rB + 14 * i]; }
+        for (int i = 0; i < 3; i++) { wv[1 + i] = w[v_rA + 14 * i]; wv[4 + i] = w[v_rB + 14 * i]; }
 #pragma unroll
         for (int i = 0; i < 7; i++) s += cv[i] * wv[i];
         return s;
@@ -628,17 +627,20 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     // dynamics row owned by this lane (u < meq): ADMM state in registers, coefficients in the V area of LDS
     const double *rcl = lds + L::oRv + (u < meq ? u : 0) * L::RS;
     const bool isDyn = u < meq;
-    double zgd = 0, ygd = 0;
+    double zgd = 0, ygd = 0, lgd = 0;
+    double rcT = 0;                                    // the T coefficient -ts*f of the row (D_i0..D_i3 stay in LDS, -ts*T is uniform)
     int ix0 = 0, ixf = 0;
     if (isDyn) {
         const int r = u, k = r / 14, rr = r % 14, s = k / 3;
         ix0 = 3 * s * XS + rr;
         ixf = k * XS + ((rr < 7) ? 7 + rr : 14 + rr - 7);
-        lds[L::oRv + u * L::RS + 6] = -c.ws.ceq[(size_t)b * meq + r];      // the row's bound l = u = -c_eq
+        lgd = -c.ws.ceq[(size_t)b * meq + r];          // the row's bound l = u = -c_eq
+        rcT = rcl[5];
     }
+    const double mtsT = -c.tsT;
     auto row_dot_dyn = [&](const double *xe) -> double {
         return rcl[0] * xe[ix0] + rcl[1] * xe[ix0 + XS] + rcl[2] * xe[ix0 + 2 * XS] + rcl[3] * xe[ix0 + 3 * XS] +
-               rcl[4] * xe[ixf] + rcl[5] * xe[21];      // T is replicated at slot 21 of every node row
+               mtsT * xe[ixf] + rcT * xe[21];           // T is replicated at slot 21 of every node row
     };
     const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
     double x = 0, zb = 0, yb = 0;
@@ -684,13 +686,12 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         if (isDyn) {
             const double zt = row_dot_dyn(xn);
             const double zr = alpha * zt + (1.0 - alpha) * zgd;
-            const double lgd = rcl[6];
             const double zn = clip(zr + ygd * inv_rho_eq, lgd, lgd);
             ygd += rho_eq * (zr - zn);
             zgd = zn;
             const double w = rho_eq * zgd - ygd;
             wg[u] = w;
-            tpl[u] = rcl[5] * w;
+            tpl[u] = rcT * w;
             if (check) ys[u] = ygd;
         }
         if (isVar) {
@@ -707,7 +708,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         }
         __syncthreads();
         if (check) {
-            double sums[2] = {isDyn ? rcl[5] * ygd : 0.0, (isVar && !isT) ? vcl[8 * L::NB] * x : 0.0};
+            double sums[2] = {isDyn ? rcT * ygd : 0.0, (isVar && !isT) ? vcl[8 * L::NB] * x : 0.0};
             block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, true);
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isDyn) {
