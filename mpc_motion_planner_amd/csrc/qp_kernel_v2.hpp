@@ -268,22 +268,31 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         }
         __syncthreads();
         STAMP2(3);
-        // ---- P1 ----
+        // ---- P1 / P2: t = G_s b_J is not needed before P3, so its operand reads are spread over both phases (P1 is
+        // bound by the LDS reads of b by roles A1 and A2 together, P2 only has role B's reads of r_I) ----
         double t0, t1;
         {
+            constexpr int JS = 4;                                          // 16-byte operand pairs taken in P1
             double a0 = 0.0, a1 = 0.0;
             D2 bv[7];
 #pragma unroll
-            for (int j = 0; j < 7; j++) bv[j] = lds2(bj + 2 * j);          // all operand reads in flight first
+            for (int j = 0; j < JS; j++) bv[j] = lds2(bj + 2 * j);
 #pragma unroll
-            for (int j = 0; j < 7; j++) {
+            for (int j = 0; j < JS; j++) {
+                a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
+                a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
+            }
+            __syncthreads();
+            STAMP2(4);
+#pragma unroll
+            for (int j = JS; j < 7; j++) bv[j] = lds2(bj + 2 * j);
+#pragma unroll
+            for (int j = JS; j < 7; j++) {
                 a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
                 a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
             }
             t0 = sum4(a0); t1 = sum4(a1);
         }
-        __syncthreads();
-        STAMP2(4);
         // ---- P2 (role B) ----
         __syncthreads();
         STAMP2(5);
