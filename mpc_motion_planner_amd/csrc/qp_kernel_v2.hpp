@@ -388,6 +388,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     // writer lanes (0 and 1 of a group): r_I[i] = (b_I[i] + extra) - sum, extra = the T column sum for T, else the zero slot
     const int rdst = (lig < 2 && irow >= 0 && (lig == 0 || ec1 >= 0)) ? irow + lig : -1;
     const int xoff = (rdst == D::nI - 1) ? L::oMisc + 2 : L::oMisc;
+    const int rsrc = rdst >= 0 ? rdst : 0;
     // path rows: the row constants live in LDS (lane-transposed), only the ADMM state (z, y) of the owned row stays in registers
     const bool isPath = et < 16 * N;                    // four lanes per pair of path rows (six columns each)
     const int pk = et >> 4, prp = (et & 15) >> 2, pq = et & 3;
@@ -451,6 +452,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             D2 bv[7];
 #pragma unroll
             for (int j = 0; j < 7; j++) bv[j] = lds2(bj + 2 * j);          // all operand reads in flight first
+            const double bI0 = rhsI[rsrc], bI1 = lds[xoff];                // (every lane reads: keeps the loads off the tail)
 #pragma unroll
             for (int j = 0; j < 7; j++) {
                 a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
@@ -459,7 +461,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             a0 = sum4(a0); a1 = sum4(a1);
             a0 += f8 * dpp_mov<0x141>(a0); a1 += f8 * dpp_mov<0x141>(a1);       // 8-lane groups: row_half_mirror
             a0 += f16 * dpp_mov<0x140>(a0);                                       // the T group of 16: row_mirror
-            if (rdst >= 0) rI[rdst] = (rhsI[rdst] + lds[xoff]) - (lig ? a1 : a0);
+            if (rdst >= 0) rI[rdst] = (bI0 + bI1) - (lig ? a1 : a0);
         }
         __syncthreads();
         // ---- P2 (role B) ----
@@ -470,12 +472,12 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
         if (isPath) {
+            const double rr_ = pcl[2 * L::NA2], rri = pcl[4 * L::NA2], lgp = pcl[0], ugp = pcl[L::NA2];   // in flight with the row operands
             path_rows(xn, lds + L::oGp, [&](double zt) -> double {
                 double w = 0.0;
                 if (ownsRow) {
-                    const double rr_ = pcl[2 * L::NA2];
                     const double zr = alpha * zt + (1.0 - alpha) * zg;
-                    const double zn = clip(zr + yg * pcl[4 * L::NA2], pcl[0], pcl[L::NA2]);
+                    const double zn = clip(zr + yg * rri, lgp, ugp);
                     yg += rr_ * (zr - zn);
                     zg = zn;
                     w = rr_ * zg - yg;
