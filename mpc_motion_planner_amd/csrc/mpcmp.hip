@@ -26,6 +26,7 @@ struct mpcmp_ctx {
     hipStream_t stream = nullptr;
     // device buffers
     mpcmp_model *d_model = nullptr;
+    mpcmp_model model;             // host copy: passed by value to the kernels that run the rigid-body recursions
     int *d_ext_of_int = nullptr, *d_entry_ptr = nullptr;
     uint32_t *d_terms = nullptr;
     WS ws{};
@@ -353,6 +354,7 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
     if (model) mdl = *model; else mpcmp_default_model(&mdl);
     TRY(dalloc(ctx, &ctx->d_model, 1));
     HIPTRY(hipMemcpy(ctx->d_model, &mdl, sizeof mdl, hipMemcpyHostToDevice));
+    ctx->model = mdl;
     StructureTables tab;
     if (!build_tables(cfg->num_seg, tab)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
     TRY(dalloc(ctx, &ctx->d_ext_of_int, tab.ext_of_int.size()));
@@ -431,7 +433,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
     else if (int rc = set_lds(ctx, k_qp<NSEG>, l_qp)) return rc;
     if (int rc = set_lds(ctx, k_step<NSEG>, l_step)) return rc;
-    hipLaunchKernelGGL(k_init<NSEG>, dim3(B), dim3(D::NT), l_init, st, ctx->cfg, w, d_wx, d_wu, d_wT, reguess);
+    hipLaunchKernelGGL(k_init<NSEG>, dim3(B), dim3(D::NT), l_init, st, ctx->cfg, ctx->model, w, d_wx, d_wu, d_wT, reguess);
     const int iters = only_qp ? 1 : ctx->cfg.sqp_iters;
     for (int it = 0; it < iters; it++) {
         hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
@@ -440,7 +442,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         else hipLaunchKernelGGL(k_qp<NSEG>, dim3(B), dim3(D::NT), l_qp, st, ctx->cfg, w);
         if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
         if (only_qp) break;
-        hipLaunchKernelGGL(k_step<NSEG>, dim3(B), dim3(D::NT), l_step, st, ctx->cfg, w, it == iters - 1 ? 1 : 0, it,
+        hipLaunchKernelGGL(k_step<NSEG>, dim3(B), dim3(D::NT), l_step, st, ctx->cfg, ctx->model, w, it == iters - 1 ? 1 : 0, it,
                            d_sx, d_su, d_sT, d_info);
     }
     HIPCHK(ctx, hipGetLastError());
@@ -512,7 +514,7 @@ extern "C" int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, c
     WS w = ctx->ws; w.x0 = ctx->d_x0; w.xf = ctx->d_xf;
     int rc = MPCMP_OK;
 #define LAUNCH_INIT(NS) { size_t l = InitLds<NS>::size * sizeof(double); rc = set_lds(ctx, k_init<NS>, l); \
-        if (!rc) hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); }
+        if (!rc) hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, ctx->model, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); }
     switch (ctx->nseg) { case 1: LAUNCH_INIT(1) break; case 2: LAUNCH_INIT(2) break; case 4: LAUNCH_INIT(4) break; case 6: LAUNCH_INIT(6) break; }
 #undef LAUNCH_INIT
     if (rc) return rc;
@@ -587,7 +589,7 @@ extern "C" int mpcmp_eval_constraints_batch(mpcmp_ctx *ctx, int n, const double 
     const size_t l = EvalLds<NS>::size * sizeof(double);
     if (int rc = set_lds(ctx, k_eval_constraints<NS>, l)) return rc;
     const int N = Dim<NS>::N;
-    hipLaunchKernelGGL(k_eval_constraints<NS>, dim3((n + N - 1) / N), dim3(Dim<NS>::NT), l, st, ctx->cfg, ctx->d_model, n, dx, du, dg, dG);
+    hipLaunchKernelGGL(k_eval_constraints<NS>, dim3((n + N - 1) / N), dim3(Dim<NS>::NT), l, st, ctx->cfg, ctx->model, n, dx, du, dg, dG);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(g, dg, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(G, dG, sizeof(double) * 176 * n, hipMemcpyDeviceToHost, st));

@@ -99,6 +99,7 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
             dw = dwn; dwd = dwdn; dal = daln;
         }
         w = wn; wd = wdn; al = aln;
+        __builtin_amdgcn_sched_barrier(0);      // keep each joint's model-constant loads next to their uses
     }
     V3 f = mk(0, 0, 0), n = mk(0, 0, 0), df = mk(0, 0, 0), dn = mk(0, 0, 0);
 #pragma unroll
@@ -128,6 +129,7 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
         f = fi; n = ni; df = dfi; dn = dni;
         tau[i] = n.z;
         if (TANGENT) dtau[i] = dn.z;
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -105,7 +105,7 @@ struct LinLds {
 // Linearisation of all nodes of one problem (block-wide). zl: iterate in LDS (external order).
 // scr: LDS scratch of N*14 + N*147 + N*7 doubles. Writes g [8N], Gk [N][8][22], ceq [meq] (global).
 template <int NSEG>
-__device__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__restrict__ mdl, const double *zl,
+__device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__restrict__ mdl, const double *zl,
                                 double *scr, double *g_out, double *Gk_out, double *ceq_out, int tid) {
     using D = Dim<NSEG>;
     constexpr int N = D::N;
@@ -118,7 +118,11 @@ __device__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__re
         sc[2 * t] = s; sc[2 * t + 1] = c;
     }
     __syncthreads();
-    for (int t = tid; t < N * 22; t += D::NT) {
+    // one pass (a plain `if`, not a loop: a loop makes the compiler hoist the ~180 model constants of the recursion
+    // out of it as loop invariants and spill them)
+    static_assert(N * 22 <= D::NT, "one (node, direction) pair per thread");
+    if (tid < N * 22) {
+        const int t = tid;
         const int k = t / 22, d = t % 22;
         const double *q_sc = sc + 14 * k;
         const double *v = zl + 14 * k + 7, *a = zl + 14 * N + 7 * k;
@@ -179,8 +183,10 @@ __device__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__re
 // ------------------------------------------------------------------------------------------------
 // k_init
 template <int NSEG>
-__global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, WS ws, const double *warm_x,
+__global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, mpcmp_model mdl, WS ws, const double *warm_x,
                                                         const double *warm_u, const double *warm_T, int reguess) {
+    // (the model is a by-value kernel argument: its ~180 constants become scalar-load operands of the recursion
+    //  instead of vector loads that get hoisted and spilled)
     using D = Dim<NSEG>;
     constexpr int N = D::N, n = D::n;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, WS ws,
     for (int v = tid; v < n; v += D::NT) ws.z[(size_t)b * n + v] = zl[v];
     for (int i = tid; i < D::mn; i += D::NT) ws.lam[(size_t)b * D::mn + i] = 0.0;
     if (tid == 0) { ws.qp_total[b] = 0; ws.status[b] = 0; ws.alpha[b] = 0.0; }
-    linearise_block<NSEG>(cfg, ws.model, zl, scr, ws.g + (size_t)b * 8 * N, ws.Gk + (size_t)b * N * 176,
+    linearise_block<NSEG>(cfg, &mdl, zl, scr, ws.g + (size_t)b * 8 * N, ws.Gk + (size_t)b * N * 176,
                           ws.ceq + (size_t)b * D::meq, tid);
 }
 template <int NSEG>
@@ -701,7 +707,7 @@ struct StepLds {
 };
 
 template <int NSEG>
-__global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, WS ws, int final_iter, int sqp_it,
+__global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_model mdl, WS ws, int final_iter, int sqp_it,
                                                         double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info) {
     using D = Dim<NSEG>;
     using L = StepLds<NSEG>;
@@ -743,7 +749,9 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, WS ws,
         sct[2 * t] = s; sct[2 * t + 1] = c;
     }
     __syncthreads();
-    for (int t = tid; t < ntr * N; t += NT) {
+    static_assert(9 * N <= NT, "one (trial, node) pair per thread");
+    if (tid < ntr * N) {           // (an `if`, not a loop: see linearise_block)
+        const int t = tid;
         const int tr = t / N, k = t % N;
         double al = 1.0;
         for (int q = 0; q < tr; q++) al *= cfg.ls_tau;
@@ -753,9 +761,9 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, WS ws,
             v[j] = zl[14 * k + 7 + j] + al * pl[14 * k + 7 + j];
             a[j] = zl[14 * N + 7 * k + j] + al * pl[14 * N + 7 * k + j];
         }
-        rnea_dir<false>(ws.model, sct + 14 * t, v, a, 0, 0, tau, nullptr);
+        rnea_dir<false>(&mdl, sct + 14 * t, v, a, 0, 0, tau, nullptr);
         V3 ptool;
-        fk_tool(ws.model, sct + 14 * t, &ptool, nullptr, nullptr, nullptr);
+        fk_tool(&mdl, sct + 14 * t, &ptool, nullptr, nullptr, nullptr);
         double s = viol(ptool.z, cfg.lbg[7], cfg.ubg[7]);
 #pragma unroll
         for (int j = 0; j < 7; j++) s += viol(tau[j], cfg.lbg[j], cfg.ubg[j]);
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, WS ws,
     for (int i = tid; i < D::mn; i += NT) lam[i] += alpha * (y[i] - lam[i]);
     __syncthreads();
     double *gout = ws.g + (size_t)b * 8 * N, *ceqo = ws.ceq + (size_t)b * meq;
-    linearise_block<NSEG>(cfg, ws.model, zl, scr, gout, ws.Gk + (size_t)b * N * 176, ceqo, tid);
+    linearise_block<NSEG>(cfg, &mdl, zl, scr, gout, ws.Gk + (size_t)b * N * 176, ceqo, tid);
     if (tid == 0) ws.alpha[b] = alpha;
     if (final_iter) {
         __threadfence_block();
@@ -845,7 +853,7 @@ __global__ __launch_bounds__(64) void k_rnea_batch(const mpcmp_model *mdl, int n
 
 // evalConstraints AD overload for a list of (x,u): processed in chunks of N "nodes" per workgroup
 template <int NSEG>
-__global__ __launch_bounds__(Dim<NSEG>::NT) void k_eval_constraints(mpcmp_config cfg, const mpcmp_model *mdl, int total,
+__global__ __launch_bounds__(Dim<NSEG>::NT) void k_eval_constraints(mpcmp_config cfg, mpcmp_model mdl, int total,
                                                                     const double *x, const double *u, double *g,
                                                                     double *G) {
     using D = Dim<NSEG>;
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_eval_constraints(mpcmp_config
     __syncthreads();
     double *gl = scr + LinLds<NSEG>::size, *Gl = gl + 8 * N;
     // write into LDS staging first (tail chunk may be partial), then copy the valid part out
-    linearise_block<NSEG>(cfg, mdl, zl, scr, gl, Gl, nullptr, tid);
+    linearise_block<NSEG>(cfg, &mdl, zl, scr, gl, Gl, nullptr, tid);
     const int valid = (total - base < N) ? total - base : N;
     for (int t = tid; t < valid * 8; t += D::NT) g[(size_t)base * 8 + t] = gl[t];
     for (int t = tid; t < valid * 176; t += D::NT) G[(size_t)base * 176 + t] = Gl[t];
