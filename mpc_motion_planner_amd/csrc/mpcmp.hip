@@ -369,7 +369,7 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
     TRY(dalloc(ctx, &w.z, B * n)); TRY(dalloc(ctx, &w.lam, B * mn)); TRY(dalloc(ctx, &w.ceq, B * ctx->meq));
     TRY(dalloc(ctx, &w.g, B * 8 * N)); TRY(dalloc(ctx, &w.Gk, B * N * 176)); TRY(dalloc(ctx, &w.p, B * n));
     TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.qp_total, B));
-    TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, B * 16));
+    TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, (size_t)B * MPCMP_DBG_WORDS));
     TRY(dalloc(ctx, &ctx->d_x0, B * 14)); TRY(dalloc(ctx, &ctx->d_xf, B * 14));
     TRY(dalloc(ctx, &ctx->d_wx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_wu, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
     TRY(dalloc(ctx, &ctx->d_sx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_su, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_sT, B));
@@ -734,7 +734,7 @@ extern "C" int mpcmp_debug_stamps(mpcmp_ctx *ctx, int B, unsigned long long *out
     if (!ctx || !out || B < 1 || B > ctx->max_batch) return MPCMP_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());
-    HIPCHK(ctx, hipMemcpy(out, ctx->ws.dbg, sizeof(unsigned long long) * 16 * B, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out, ctx->ws.dbg, sizeof(unsigned long long) * MPCMP_DBG_WORDS * B, hipMemcpyDeviceToHost));
     return MPCMP_OK;
 }
 

@@ -169,7 +169,8 @@ struct Qp2 {
     static constexpr int oRedS = oGpy + D::N * XS;             // [128*2+8]  loop reductions: sums
     static constexpr int oRedM = oRedS + 128 * 2 + 8;          // [128*6+8]  loop reductions: maxima
     static constexpr int oStamp = oRedM + 128 * 6 + 8;         // [16]       cycle stamps (diagnostic builds only)
-    static constexpr int oEndA = oStamp + 16;
+    static constexpr int oBusy = oStamp + 16;                  // [16][8]    per-wave busy cycles (diagnostic builds only)
+    static constexpr int oEndA = oBusy + 128;
     static constexpr int size = oEndF > oEndA ? oEndF : oEndA;
     static_assert(size * 8 <= 160 * 1024 - 512, "LDS budget (a 256-byte static block precedes the dynamic region)");
     static_assert(oGk + D::N * 8 * GS < (1 << 14), "assembly stream operand offsets are 14 bits");
@@ -189,8 +190,18 @@ struct Qp2Ctx {
 #ifdef MPCMP_STAMPS
 // the accumulators of the loop stamps live in LDS: role A1 has no registers to spare
 #define STAMP2(slot) do { if (c.tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
+// per-wave busy time of each ADMM phase (barrier exit -> arrival at the phase's closing barrier): dbg[16 + wave*8 + phase]
+#define BUSY_DECL unsigned long long busy_t = clock64(); \
+    unsigned long long *busy_acc = reinterpret_cast<unsigned long long *>(c.lds + L::oBusy) + (c.tid >> 6) * 8; \
+    if ((c.tid & 63) == 0) for (int k_ = 0; k_ < 8; k_++) busy_acc[k_] = 0
+#define BUSY_SYNC(ph) do { if ((c.tid & 63) == 0) busy_acc[ph] += clock64() - busy_t; __syncthreads(); busy_t = clock64(); } while (0)
+#define BUSY_DUMP do { if ((c.tid & 63) == 0) for (int k_ = 0; k_ < 8; k_++) \
+    c.ws.dbg[(size_t)c.b * MPCMP_DBG_WORDS + 16 + (c.tid >> 6) * 8 + k_] = busy_acc[k_]; } while (0)
 #else
 #define STAMP2(slot) do { } while (0)
+#define BUSY_DECL do { } while (0)
+#define BUSY_SYNC(ph) __syncthreads()
+#define BUSY_DUMP do { } while (0)
 #endif
 
 // termination test shared by all roles (every thread contributes its maxima; result is workgroup-uniform)
@@ -257,16 +268,23 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     const double *xc3 = part == 3 ? xn1 + 20 : xa + 4;
     const double *xb = part == 0 ? xn0 + 6 : part == 1 ? xn1 : part == 2 ? xn1 + 8 : xn1 + 20;
     int it = 0, done = 0, until_check = cfg.check_every;
+    BUSY_DECL;
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: wave 0 sums the T column of A^T w ----
         if (tid < 64) {
+            // all operand reads in flight at once (a rolled loop serialises one LDS round trip per 64 rows)
+            constexpr int NR = (meq + 63) / 64;
+            double tv[NR + 1];
+#pragma unroll
+            for (int q = 0; q < NR; q++) tv[q] = tpl[tid + 64 * q < meq ? tid + 64 * q : meq];     // dynamics rows (slot meq: zero)
+            tv[NR] = lds[tid < N ? L::oGp + tid * XS + 21 : L::oMisc];  // path rows: per-node column sums (role A2)
             double sacc = 0.0;
-            for (int r = tid; r < meq; r += 64) sacc += tpl[r];          // dynamics rows
-            if (tid < N) sacc += lds[L::oGp + tid * XS + 21];            // path rows: per-node column sums (role A2)
+#pragma unroll
+            for (int q = 0; q <= NR; q++) sacc += tv[q];
             sacc = wave_sum(sacc);
             if (tid == 0) misc[2] = sacc;
         }
-        __syncthreads();
+        BUSY_SYNC(0);
         STAMP2(3);
         // ---- P1 / P2: t = G_s b_J is not needed before P3, so its operand reads are spread over both phases (P1 is
         // bound by the LDS reads of b by roles A1 and A2 together, P2 only has role B's reads of r_I) ----
@@ -282,7 +300,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
                 a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
                 a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
             }
-            __syncthreads();
+            BUSY_SYNC(1);
             STAMP2(4);
 #pragma unroll
             for (int j = JS; j < 7; j++) bv[j] = lds2(bj + 2 * j);
@@ -294,7 +312,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
             t0 = sum4(a0); t1 = sum4(a1);
         }
         // ---- P2 (role B) ----
-        __syncthreads();
+        BUSY_SYNC(2);
         STAMP2(5);
         // ---- P3 ----
         {
@@ -311,10 +329,10 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
             a0 = sum4(a0); a1 = sum4(a1);
             if (jdst >= 0) xn[jdst] = part ? (t1 - a1) : (t0 - a0);
         }
-        __syncthreads();
+        BUSY_SYNC(3);
         STAMP2(6);
         // ---- E (roles A2, B) ----
-        __syncthreads();
+        BUSY_SYNC(4);
         STAMP2(7);
         const bool check = (--until_check == 0);     // countdown: a runtime integer modulo costs a serial ~30-instruction chain
         if (check) {
@@ -331,9 +349,10 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         if (done) break;
     }
     if (it > cfg.qp_iters) it = cfg.qp_iters;
+    BUSY_DUMP;
     if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; }
 #ifdef MPCMP_STAMPS
-    if (tid == 0) { unsigned long long *o = c.ws.dbg + (size_t)c.b * 16; for (int k = 3; k < 9; k++) o[k] = stamp_acc[k]; o[15] = it; }
+    if (tid == 0) { unsigned long long *o = c.ws.dbg + (size_t)c.b * MPCMP_DBG_WORDS; for (int k = 3; k < 9; k++) o[k] = stamp_acc[k]; o[15] = it; }
 #endif
 }
 
@@ -443,9 +462,10 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     const double alpha = c.alpha;
     const double *bj = rhsJ + 56 * seg + 14 * part;
     int it = 0, done = 0, until_check = cfg.check_every;
+    BUSY_DECL;
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A (role B) ----
-        __syncthreads();
+        BUSY_SYNC(0);
         // ---- P1 ----
         {
             double a0 = 0.0, a1 = 0.0;
@@ -463,11 +483,11 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             a0 += f16 * dpp_mov<0x140>(a0);                                       // the T group of 16: row_mirror
             if (rdst >= 0) rI[rdst] = (bI0 + bI1) - (lig ? a1 : a0);
         }
-        __syncthreads();
+        BUSY_SYNC(1);
         // ---- P2 (role B) ----
-        __syncthreads();
+        BUSY_SYNC(2);
         // ---- P3 (role A1) ----
-        __syncthreads();
+        BUSY_SYNC(3);
         // ---- E: z~ = A x~, relaxation, projection, dual update ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
@@ -485,7 +505,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
                 return w;
             });
         }
-        __syncthreads();
+        BUSY_SYNC(4);
         if (check) {
             double sums[2] = {ownsRow ? pcl[3 * L::NA2] * yg : 0.0, 0.0};
             double mx[6] = {0, 0, 0, 0, 0, 0};
@@ -498,6 +518,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         }
         if (done) break;
     }
+    BUSY_DUMP;
     if (ownsRow) c.ws.y[(size_t)b * D::mn + myrow] = yg;
 }
 
@@ -656,6 +677,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
     double x = 0, zb = 0, yb = 0;
     int it = 0, done = 0, until_check = cfg.check_every;
+    BUSY_DECL;
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: rhs = sigma x - q + rho_b zb - yb + A^T w ----
         if (isVar) {
@@ -663,9 +685,9 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             if (isT) lds[v_rpos] = (sx - 1.0) + bz;      // b_T; its column sum and coupling terms are added by roles A1/A2
             else lds[v_rpos] = (sx + bz) + col_gather(wg, lds + L::oGp);
         }
-        __syncthreads();
+        BUSY_SYNC(0);
         // ---- P1: (group A) ----
-        __syncthreads();
+        BUSY_SYNC(1);
         // ---- P2: x_I = S^-1 r_I  (2 rows x 10 columns per lane, 8-lane reduction; r_I was completed by role A2) ----
         if (isP2) {
             double a0 = 0.0, a1 = 0.0;
@@ -685,12 +707,13 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             }
             if (rp2 == (nI - 1) / 2) {       // x_T is replicated (every node row, every C_s): the 8 lanes of its group share the writes
                 const double xT = ((nI - 1) & 1) ? a1 : a0;
-                for (int k = part2; k < N; k += 8) xn[k * XS + 21] = xT;
+#pragma unroll
+                for (int q = 0; q < (N + 7) / 8; q++) { if (part2 + 8 * q < N) xn[(part2 + 8 * q) * XS + 21] = xT; }
             }
         }
-        __syncthreads();
+        BUSY_SYNC(2);
         // ---- P3: (group A) ----
-        __syncthreads();
+        BUSY_SYNC(3);
         // ---- E: variables and dynamics rows ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
@@ -717,7 +740,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
                 else xx[v_xpos] = x;
             }
         }
-        __syncthreads();
+        BUSY_SYNC(4);
         if (check) {
             double sums[2] = {isDyn ? rcT * ygd : 0.0, (isVar && !isT) ? vcl[8 * L::NB] * x : 0.0};
             block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, true);
@@ -738,6 +761,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         }
         if (done) break;
     }
+    BUSY_DUMP;
     if (isDyn) c.ws.y[(size_t)b * D::mn + u] = ygd;
     if (isVar) {
         c.ws.p[(size_t)b * n + u] = x;
@@ -1028,7 +1052,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         if (tid == 0 && any) ws.status[b] |= any;
     }
 #ifdef MPCMP_STAMPS
-    if (tid == 0) { unsigned long long *dbg = ws.dbg + (size_t)b * 16; for (int k = 0; k < 3; k++) dbg[k] = stamp_acc[k]; for (int k = 9; k < 15; k++) dbg[k] = stamp_acc[k]; }
+    if (tid == 0) { unsigned long long *dbg = ws.dbg + (size_t)b * MPCMP_DBG_WORDS; for (int k = 0; k < 3; k++) dbg[k] = stamp_acc[k]; for (int k = 9; k < 15; k++) dbg[k] = stamp_acc[k]; }
 #endif
     if (tid < L::NA1) qp2_role_a1<NSEG>(c);
     else if (tid < L::NA1 + L::NA2) qp2_role_a2<NSEG>(c);

@@ -38,9 +38,10 @@ struct WS {
     int *qp_total;            // [B]
     int *status;              // [B]
     double *alpha;            // [B]
-    unsigned long long *dbg;  // [B][16] phase cycle stamps (diagnostic builds with -DMPCMP_STAMPS only)
+    unsigned long long *dbg;  // [B][MPCMP_DBG_WORDS] phase cycle stamps (diagnostic builds with -DMPCMP_STAMPS only)
 };
 
+#define MPCMP_DBG_WORDS 144   /* 16 workgroup stamps + [16 waves][8] per-wave busy cycles of k_qp2 */
 #ifdef MPCMP_STAMPS
 #define STAMP(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
 #else

@@ -26,7 +26,7 @@ s = M.Solver(cfg, B)
 x0, xf = scenarios.make_batch(B)
 wx, wu, wT = s.warm_start(x0, xf)
 p, y, it = s.qp(x0, xf, wx, wu, wT)
-st = np.zeros((B, 16), dtype=np.uint64)
+st = np.zeros((B, 144), dtype=np.uint64)
 capi.check(capi.lib().mpcmp_debug_stamps(s._ctx, B, st.ctypes.data_as(C.c_void_p)))
 st = st.astype(np.float64)
 its = st[:, 15]
@@ -40,3 +40,10 @@ for k, nm in enumerate(names):
 print("loop total %10.1f cycles / iteration" % ((st[:, 3:9].sum(axis=1) / its).mean()))
 for k, nm in zip(range(9, 15), ["  assemble K_JJ,K_JC", "  diag/arrow", "  sweep K_JJ", "  E = G K_JC", "  S -= K_CJ E", "  park to HBM"]):
     print("%-26s %10.0f cycles (once, all segment groups)" % (nm, st[:, k].mean()))
+
+# per-wave busy cycles per iteration (k_qp2 only): which role is the critical one in each phase
+busy = st[:, 16:].reshape(B, 16, 8)
+if busy.sum() > 0:
+    print("per-wave busy cycles / iteration (phase A, P1, P2, P3, E); waves 0-6 role A1, 7-10 role A2, 11-15 role B")
+    for w in range(16):
+        print("  wave %2d  " % w + "  ".join("%7.1f" % (busy[:, w, ph] / its).mean() for ph in range(5)))
