@@ -434,11 +434,11 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     // z~ of the owned row (lanes 0,1 of the quad) and, from the same Jacobian operands, this node's path-row part of
     // A^T w: every lane forms its six columns of g_row0*w0 + g_row1*w1, the four row pairs of the node (lane bits 2,3 of
     // the DPP row) are summed with two row rotations, and the lanes of pair 0 publish the node's 24 padded columns.
-    auto path_rows = [&](const double *xe, double *gdst, auto &&row_update) -> double {
-        const double *g0 = gkl + groff, *g1 = g0 + GS, *xv = xe + xnoff;
-        D2 x2[3], p0[3], p1[3];
+    auto path_rows = [&](const D2 (&p0)[3], const D2 (&p1)[3], const double *xe, double *gdst, auto &&row_update) -> double {
+        const double *xv = xe + xnoff;
+        D2 x2[3];
 #pragma unroll
-        for (int j = 0; j < 3; j++) { x2[j] = lds2(xv + 2 * j); p0[j] = lds2(g0 + 2 * j); p1[j] = lds2(g1 + 2 * j); }
+        for (int j = 0; j < 3; j++) x2[j] = lds2(xv + 2 * j);
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -486,14 +486,21 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         BUSY_SYNC(1);
         // ---- P2 (role B) ----
         BUSY_SYNC(2);
-        // ---- P3 (role A1) ----
+        // ---- P3 (role A1): this role is idle, so the constant operands of the E phase (Jacobian rows, row bounds) are
+        // fetched now and only x~ remains to be read once P3 has produced it ----
+        D2 p0[3], p1[3];
+        {
+            const double *g0 = gkl + groff, *g1 = g0 + GS;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { p0[j] = lds2(g0 + 2 * j); p1[j] = lds2(g1 + 2 * j); }
+        }
+        const double rr_ = pcl[2 * L::NA2], rri = pcl[4 * L::NA2], lgp = pcl[0], ugp = pcl[L::NA2];
         BUSY_SYNC(3);
         // ---- E: z~ = A x~, relaxation, projection, dual update ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
         if (isPath) {
-            const double rr_ = pcl[2 * L::NA2], rri = pcl[4 * L::NA2], lgp = pcl[0], ugp = pcl[L::NA2];   // in flight with the row operands
-            path_rows(xn, lds + L::oGp, [&](double zt) -> double {
+            path_rows(p0, p1, xn, lds + L::oGp, [&](double zt) -> double {
                 double w = 0.0;
                 if (ownsRow) {
                     const double zr = alpha * zt + (1.0 - alpha) * zg;
@@ -510,7 +517,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             double sums[2] = {ownsRow ? pcl[3 * L::NA2] * yg : 0.0, 0.0};
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isPath) {       // A x of the owned row and the path-row part of A^T y (read by role B after the reduction's barriers)
-                const double ax = path_rows(xx, lds + L::oGpy, [&](double) -> double { return ownsRow ? yg : 0.0; });
+                const double ax = path_rows(p0, p1, xx, lds + L::oGpy, [&](double) -> double { return ownsRow ? yg : 0.0; });
                 if (ownsRow) { mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg); }
             }
             block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, true);
@@ -659,6 +666,8 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     // dynamics row owned by this lane (u < meq): ADMM state in registers, coefficients in the V area of LDS
     const double *rcl = lds + L::oRv + (u < meq ? u : 0) * L::RS;
     const bool isDyn = u < meq;
+    const bool waveDyn = (u & ~63) < meq;              // wave-uniform: some lane of this wave owns a dynamics row
+    static_assert((meq + 63) / 64 * 64 <= n - 1, "every lane of a wave with dynamics rows owns a variable other than T");
     double zgd = 0, ygd = 0, lgd = 0;
     double rcT = 0;                                    // the T coefficient -ts*f of the row (D_i0..D_i3 stay in LDS, -ts*T is uniform)
     int ix0 = 0, ixf = 0;
@@ -717,18 +726,28 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         // ---- E: variables and dynamics rows ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
-        if (isDyn) {
+        if (waveDyn) {
+            // waves whose lanes own dynamics rows (all of them also own a variable): one straight-line block, so the two
+            // independent update chains interleave; lanes past the last row compute on row 0's operands and store nothing
             const double zt = row_dot_dyn(xn);
+            const double xtv = xn[v_xpos];
+            const double vrbi = vcl[12 * L::NB], vlb = vcl[10 * L::NB], vub = vcl[11 * L::NB];
             const double zr = alpha * zt + (1.0 - alpha) * zgd;
-            const double zn = clip(zr + ygd * inv_rho_eq, lgd, lgd);
-            ygd += rho_eq * (zr - zn);
-            zgd = zn;
-            const double w = rho_eq * zgd - ygd;
-            wg[u] = w;
-            tpl[u] = rcT * w;
-            if (check) ys[u] = ygd;
-        }
-        if (isVar) {
+            ygd += rho_eq * (zr - lgd);                  // the row is an equality: the projection of anything onto [l, l] is l
+            zgd = lgd;
+            const double w = rho_eq * lgd - ygd;
+            x = alpha * xtv + (1.0 - alpha) * x;
+            const double zrv = alpha * xtv + (1.0 - alpha) * zb;
+            const double znv = clip(zrv + yb * vrbi, vlb, vub);
+            yb += v_rb * (zrv - znv);
+            zb = znv;
+            if (isDyn) {
+                wg[u] = w;
+                tpl[u] = rcT * w;
+                if (check) ys[u] = ygd;
+            }
+            if (check) xx[v_xpos] = x;
+        } else if (isVar) {
             const double xtv = xn[v_xpos];
             x = alpha * xtv + (1.0 - alpha) * x;
             const double zr = alpha * xtv + (1.0 - alpha) * zb;
