@@ -679,8 +679,8 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         rcT = rcl[5];
     }
     const double mtsT = -c.tsT;
-    auto row_dot_dyn = [&](const double *xe) -> double {
-        return rcl[0] * xe[ix0] + rcl[1] * xe[ix0 + XS] + rcl[2] * xe[ix0 + 2 * XS] + rcl[3] * xe[ix0 + 3 * XS] +
+    auto row_dot_dyn = [&](const double (&rc)[4], const double *xe) -> double {
+        return rc[0] * xe[ix0] + rc[1] * xe[ix0 + XS] + rc[2] * xe[ix0 + 2 * XS] + rc[3] * xe[ix0 + 3 * XS] +
                mtsT * xe[ixf] + rcT * xe[21];           // T is replicated at slot 21 of every node row
     };
     const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
@@ -721,7 +721,9 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             }
         }
         BUSY_SYNC(2);
-        // ---- P3: (group A) ----
+        // ---- P3: (group A); this role is idle: fetch the constant operands of the E phase ----
+        const double rc[4] = {rcl[0], rcl[1], rcl[2], rcl[3]};
+        const double vrbi = vcl[12 * L::NB], vlb = vcl[10 * L::NB], vub = vcl[11 * L::NB];
         BUSY_SYNC(3);
         // ---- E: variables and dynamics rows ----
         const bool check = (--until_check == 0);
@@ -729,9 +731,8 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         if (waveDyn) {
             // waves whose lanes own dynamics rows (all of them also own a variable): one straight-line block, so the two
             // independent update chains interleave; lanes past the last row compute on row 0's operands and store nothing
-            const double zt = row_dot_dyn(xn);
+            const double zt = row_dot_dyn(rc, xn);
             const double xtv = xn[v_xpos];
-            const double vrbi = vcl[12 * L::NB], vlb = vcl[10 * L::NB], vub = vcl[11 * L::NB];
             const double zr = alpha * zt + (1.0 - alpha) * zgd;
             ygd += rho_eq * (zr - lgd);                  // the row is an equality: the projection of anything onto [l, l] is l
             zgd = lgd;
@@ -751,7 +752,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             const double xtv = xn[v_xpos];
             x = alpha * xtv + (1.0 - alpha) * x;
             const double zr = alpha * xtv + (1.0 - alpha) * zb;
-            const double zn = clip(zr + yb * vcl[12 * L::NB], vcl[10 * L::NB], vcl[11 * L::NB]);
+            const double zn = clip(zr + yb * vrbi, vlb, vub);
             yb += v_rb * (zr - zn);
             zb = zn;
             if (check) {
@@ -765,7 +766,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             block_reduce_roles<2, false, L::NA1 / 64>(sums, lds + L::oRedS, tid, true);
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isDyn) {
-                const double ax = row_dot_dyn(xx);
+                const double ax = row_dot_dyn(rc, xx);
                 mx[0] = fabs(ax - zgd); mx[1] = fabs(ax); mx[2] = fabs(zgd);
             }
             if (isVar) {
