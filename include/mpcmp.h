@@ -138,6 +138,21 @@ int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double 
 int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sol_x, const double *d_sol_u,
                               const double *d_sol_T, int n_pts, double *d_out, void *hip_stream);
 
+/* ---- scenario helpers of the robot wrapper (host side, as in the reference; never called by the batched solve) ---- */
+/* World-aligned 6x7 Jacobian of the tool frame, rows [linear(3); angular(3)], row-major (J = blockdiag(R,R) * J_local,
+ * robot_utils/pandaWrapper.cpp:70-75,97-101); optional tool position p[3] and rotation R[9] (row-major). */
+int mpcmp_tool_jacobian(const mpcmp_model *model, const double *q, double *J, double *p, double *R);
+/* PandaWrapper::forward_velocities (pandaWrapper.cpp:90-107): out[6] = J(q) qd = [linear; angular] task velocity. */
+int mpcmp_forward_velocities(const mpcmp_model *model, const double *q, const double *qd, double *out);
+/* PandaWrapper::inverse_velocities (pandaWrapper.cpp:62-88): qd = J^T (J J^T + 1e-5 I)^-1 [lin; ang]. */
+int mpcmp_inverse_velocities(const mpcmp_model *model, const double *q, const double *lin, const double *ang, double *qd);
+/* PandaWrapper::inverse_kinematic (pandaWrapper.cpp:14-60): damped least squares on the tool frame, error = log6 of the
+ * pose error in the desired frame, step -J_local^T (J J^T + 1e-2 I)^-1 err * 0.1, stop at |err| < 1e-4 or 1000 iterations.
+ * The reference starts from pinocchio::randomConfiguration; here the start q_init[7] is an argument (NULL = zeros).
+ * R is row-major.  Returns MPCMP_OK when converged, 1 when the iteration cap was hit (q still holds the last iterate). */
+int mpcmp_inverse_kinematics(const mpcmp_model *model, const double *R, const double *p, const double *q_init, double *q,
+                             int *iters);
+
 /* ---- trajectory checks of the reference benchmark (examples/benchmark.cpp:58-160) ---- */
 /* out [B][74] = min(28) | max(28) of q,qd,qdd,tau over n_pts+1 uniform samples | x(T) - target (14) |
  * flags (4; 1 = pass): jerk (|d qdd/dt| <= 10 max_jerk), linear task velocity <= 1.7, angular <= 2.5, tool z >= 0.

@@ -85,6 +85,31 @@ class PandaWrapper {
         if (p_tool) for (int r = 0; r < 3; r++)
             p_tool[r] = p[r] + R[3 * r] * model.tool[0] + R[3 * r + 1] * model.tool[1] + R[3 * r + 2] * model.tool[2];
     }
+    // robot_utils/pandaWrapper.cpp:62-88: joint velocity realising a task velocity (damped pseudo-inverse)
+    Vec7 inverse_velocities(const Vec7 &q, const mpcmp_shim::Mat<3, 1> &linear_velocity, const mpcmp_shim::Mat<3, 1> &angular_velocity) const {
+        Vec7 qd;
+        if (mpcmp_inverse_velocities(&model, q.data(), linear_velocity.data(), angular_velocity.data(), qd.data()))
+            throw std::runtime_error("PandaWrapper::inverse_velocities failed");
+        return qd;
+    }
+    // robot_utils/pandaWrapper.cpp:90-107: [linear; angular] velocity of the tool frame, world-aligned
+    mpcmp_shim::Mat<6, 1> forward_velocities(const Vec7 &q, const Vec7 &qdot) const {
+        mpcmp_shim::Mat<6, 1> out;
+        if (mpcmp_forward_velocities(&model, q.data(), qdot.data(), out.data())) throw std::runtime_error("PandaWrapper::forward_velocities failed");
+        return out;
+    }
+    // robot_utils/pandaWrapper.cpp:14-60.  The reference starts from a random configuration and drops the success flag;
+    // here the start is explicit (default: zeros) and `converged`, when given, receives the flag.
+    Vec7 inverse_kinematic(const mpcmp_shim::Mat<3, 3> &orientation, const mpcmp_shim::Mat<3, 1> &position, const Vec7 *q_init = nullptr,
+                           bool *converged = nullptr) const {
+        double R[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = orientation(r, c);
+        Vec7 q;
+        const int rc = mpcmp_inverse_kinematics(&model, R, position.data(), q_init ? q_init->data() : nullptr, q.data(), nullptr);
+        if (rc != 0 && rc != 1) throw std::runtime_error("PandaWrapper::inverse_kinematic failed");
+        if (converged) *converged = rc == 0;
+        return q;
+    }
 };
 
 class MotionPlanner {
@@ -134,6 +159,8 @@ class MotionPlanner {
     }
     void set_min_height(double min_height) { mpcmp_set_min_height(&config, min_height); push_config(); }  // :92-100
 
+    // one draw in [-1,1) of the planner's seeded stream: what `Matrix<...>::Random()` coefficients are in the reference's examples
+    double random_unit() { return uniform(); }
     // motionPlanner.cpp:102-114 (Eigen::Random replaced by a SplitMix64 stream owned by the planner)
     void sample_random_state(Vec7 &random_position, Vec7 &random_velocity) {
         double p7[3];

@@ -3,12 +3,16 @@
 The product is the C-ABI shared library declared in include/mpcmp.h; this module is the thin ctypes
 binding used by bench.py and the parity tests, plus `BatchMotionPlanner`, a batched mirror of the
 reference's `MotionPlanner` façade (mpc_solver/motionPlanner.hpp:16-176).  There is no CPU fallback:
-loading fails loudly when the HIP library is missing, and every compute call fails when no GPU is present.
+loading fails loudly when the HIP library is missing, and every solver call fails when no GPU is present.
+(The scenario helpers of the robot wrapper — Jacobian, velocity maps, inverse kinematics — are host code in the
+reference and here; they are not part of the batched solve.)
 """
 from .capi import (Config, Info, Model, INFO_DTYPE, MpcmpError, build_library, default_config, default_limits,
-                   default_model, lib, library_path, model_from_urdf, num_nodes, time_nodes)
+                   default_model, forward_velocities, inverse_kinematic, inverse_velocities, lib, library_path,
+                   model_from_urdf, num_nodes, time_nodes, tool_jacobian)
 from .planner import BatchMotionPlanner, Solver
 
 __all__ = ["Config", "Info", "Model", "INFO_DTYPE", "MpcmpError", "build_library", "default_config",
            "default_limits", "default_model", "lib", "library_path", "model_from_urdf", "num_nodes",
-           "time_nodes", "BatchMotionPlanner", "Solver"]
+           "time_nodes", "BatchMotionPlanner", "Solver", "forward_velocities", "inverse_kinematic",
+           "inverse_velocities", "tool_jacobian"]

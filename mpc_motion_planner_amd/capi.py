@@ -47,7 +47,8 @@ SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_default_limits
            "mpcmp_create", "mpcmp_destroy", "mpcmp_set_config", "mpcmp_last_error", "mpcmp_solve_batch",
            "mpcmp_solve_batch_device", "mpcmp_warm_start_batch", "mpcmp_rnea_batch",
            "mpcmp_eval_constraints_batch", "mpcmp_qp_batch", "mpcmp_sample_batch", "mpcmp_sample_batch_device",
-           "mpcmp_kernel_timing", "mpcmp_debug_stamps", "mpcmp_rh_init", "mpcmp_rh_run", "mpcmp_rh_get", "mpcmp_traj_stats_batch"]
+           "mpcmp_kernel_timing", "mpcmp_debug_stamps", "mpcmp_rh_init", "mpcmp_rh_run", "mpcmp_rh_get", "mpcmp_traj_stats_batch",
+           "mpcmp_tool_jacobian", "mpcmp_forward_velocities", "mpcmp_inverse_velocities", "mpcmp_inverse_kinematics"]
 
 
 def library_path():
@@ -57,7 +58,8 @@ def library_path():
 def build_library(force=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "qp_kernel_v2.hpp", "rbd_device.hpp", "structure.hpp")]
+    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "qp_kernel_v2.hpp", "rbd_device.hpp", "structure.hpp",
+                                           "kinematics_host.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "mpcmp.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         subprocess.check_call(["make", "-C", src, "-B"], stdout=subprocess.DEVNULL)
@@ -101,6 +103,38 @@ def default_model():
 
 def model_from_urdf(path):
     m = Model(); check(lib().mpcmp_model_from_urdf(path.encode(), C.byref(m))); return m
+
+
+# ---- scenario helpers of the robot wrapper (host side; robot_utils/pandaWrapper.cpp:14-107) ----
+def tool_jacobian(model, q):
+    """World-aligned 6x7 tool-frame Jacobian [linear; angular], tool position and rotation."""
+    q = f64(q); J = np.zeros((6, 7)); p = np.zeros(3); R = np.zeros((3, 3))
+    check(lib().mpcmp_tool_jacobian(C.byref(model), dp(q), dp(J), dp(p), dp(R)))
+    return J, p, R
+
+
+def forward_velocities(model, q, qd):
+    """PandaWrapper::forward_velocities: task velocity [linear(3); angular(3)] of the tool frame."""
+    q, qd = f64(q), f64(qd); out = np.zeros(6)
+    check(lib().mpcmp_forward_velocities(C.byref(model), dp(q), dp(qd), dp(out)))
+    return out
+
+
+def inverse_velocities(model, q, linear_velocity, angular_velocity):
+    """PandaWrapper::inverse_velocities: damped (1e-5) pseudo-inverse map from task to joint velocity."""
+    q, lin, ang = f64(q), f64(linear_velocity), f64(angular_velocity); out = np.zeros(7)
+    check(lib().mpcmp_inverse_velocities(C.byref(model), dp(q), dp(lin), dp(ang), dp(out)))
+    return out
+
+
+def inverse_kinematic(model, orientation, position, q_init=None):
+    """PandaWrapper::inverse_kinematic: returns (q, converged, iterations); the start configuration is explicit."""
+    R, p = f64(orientation), f64(position); q = np.zeros(7); it = C.c_int(0)
+    qi = f64(q_init) if q_init is not None else None
+    rc = lib().mpcmp_inverse_kinematics(C.byref(model), dp(R), dp(p), dp(qi), dp(q), C.byref(it))
+    if rc not in (0, 1):
+        check(rc)
+    return q, rc == 0, it.value
 
 
 def default_limits():

@@ -15,6 +15,7 @@
 #include "../../include/mpcmp.h"
 #include "solver_kernels.hpp"
 #include "qp_kernel_v2.hpp"
+#include "kinematics_host.hpp"
 
 using namespace mpcmp;
 
@@ -152,6 +153,68 @@ static void rpy_to_R(const double rpy[3], double R[9]) {
     R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
     R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
     R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+
+// ---- scenario helpers (host): robot_utils/pandaWrapper.cpp:14-107 ----
+extern "C" int mpcmp_tool_jacobian(const mpcmp_model *model, const double *q, double *J, double *p, double *R) {
+    if (!model || !q || !J) return MPCMP_EINVAL;
+    double pp[3], RR[9];
+    mpcmp_host::tool_jacobian(*model, q, J, pp, RR);
+    if (p) for (int k = 0; k < 3; k++) p[k] = pp[k];
+    if (R) for (int k = 0; k < 9; k++) R[k] = RR[k];
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_forward_velocities(const mpcmp_model *model, const double *q, const double *qd, double *out) {
+    if (!model || !q || !qd || !out) return MPCMP_EINVAL;
+    double J[42], p[3], R[9];
+    mpcmp_host::tool_jacobian(*model, q, J, p, R);
+    for (int r = 0; r < 6; r++) { double s = 0; for (int k = 0; k < 7; k++) s += J[r * 7 + k] * qd[k]; out[r] = s; }
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_inverse_velocities(const mpcmp_model *model, const double *q, const double *lin, const double *ang, double *qd) {
+    if (!model || !q || !lin || !ang || !qd) return MPCMP_EINVAL;
+    double J[42], p[3], R[9], x[6];
+    mpcmp_host::tool_jacobian(*model, q, J, p, R);
+    const double b[6] = {lin[0], lin[1], lin[2], ang[0], ang[1], ang[2]};
+    if (!mpcmp_host::solve_normal(J, 1e-5, b, x)) return MPCMP_ERUNTIME;
+    for (int k = 0; k < 7; k++) { double s = 0; for (int r = 0; r < 6; r++) s += J[r * 7 + k] * x[r]; qd[k] = s; }
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_inverse_kinematics(const mpcmp_model *model, const double *Rdes, const double *pdes, const double *q_init,
+                                        double *q, int *iters) {
+    if (!model || !Rdes || !pdes || !q) return MPCMP_EINVAL;
+    const double eps = 1e-4, DT = 1e-1, damp = 1e-2;
+    const int IT_MAX = 1000;
+    for (int k = 0; k < 7; k++) q[k] = q_init ? q_init[k] : 0.0;
+    for (int it = 0;; it++) {
+        double J[42], p[3], R[9];
+        mpcmp_host::tool_jacobian(*model, q, J, p, R);
+        // dMf = oMdes^-1 * oMf
+        double dR[9], dp[3], err[6];
+        const double t[3] = {p[0] - pdes[0], p[1] - pdes[1], p[2] - pdes[2]};
+        for (int r = 0; r < 3; r++) {
+            dp[r] = Rdes[0 * 3 + r] * t[0] + Rdes[1 * 3 + r] * t[1] + Rdes[2 * 3 + r] * t[2];
+            for (int c = 0; c < 3; c++) dR[3 * r + c] = Rdes[0 * 3 + r] * R[0 * 3 + c] + Rdes[1 * 3 + r] * R[1 * 3 + c] + Rdes[2 * 3 + r] * R[2 * 3 + c];
+        }
+        mpcmp_host::log6(dR, dp, err);
+        double nrm = 0;
+        for (int k = 0; k < 6; k++) nrm += err[k] * err[k];
+        if (iters) *iters = it;
+        if (std::sqrt(nrm) < eps) return MPCMP_OK;
+        if (it >= IT_MAX) return 1;
+        // LOCAL-frame Jacobian: rotate the world-aligned rows back with R^T
+        double Jl[42], x[6];
+        for (int i = 0; i < 7; i++)
+            for (int r = 0; r < 3; r++) {
+                Jl[r * 7 + i] = R[0 * 3 + r] * J[0 * 7 + i] + R[1 * 3 + r] * J[1 * 7 + i] + R[2 * 3 + r] * J[2 * 7 + i];
+                Jl[(3 + r) * 7 + i] = R[0 * 3 + r] * J[3 * 7 + i] + R[1 * 3 + r] * J[4 * 7 + i] + R[2 * 3 + r] * J[5 * 7 + i];
+            }
+        if (!mpcmp_host::solve_normal(Jl, damp, err, x)) return MPCMP_ERUNTIME;
+        for (int k = 0; k < 7; k++) { double s = 0; for (int r = 0; r < 6; r++) s += Jl[r * 7 + k] * x[r]; q[k] -= DT * s; }
+    }
 }
 
 extern "C" int mpcmp_default_model(mpcmp_model *m) {

@@ -692,7 +692,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         return rc[0] * xe[ix0] + rc[1] * xe[ix0 + XS] + rc[2] * xe[ix0 + 2 * XS] + rc[3] * xe[ix0 + 3 * XS] +
                mtsT * xe[ixf] + rcT * xe[21];           // T is replicated at slot 21 of every node row
     };
-    const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq, inv_rho_eq = 1.0 / c.rho_eq;
+    const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq;
     double x = 0, zb = 0, yb = 0;
     int it = 0, done = 0, until_check = cfg.check_every;
     BUSY_DECL;

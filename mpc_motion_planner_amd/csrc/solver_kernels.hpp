@@ -712,7 +712,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
                                                         double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info) {
     using D = Dim<NSEG>;
     using L = StepLds<NSEG>;
-    constexpr int N = D::N, n = D::n, meq = D::meq, m = D::m, NT = D::NT;
+    constexpr int N = D::N, n = D::n, meq = D::meq, NT = D::NT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     double *zl = lds + L::oZ, *pl = lds + L::oP, *pv = lds + L::oPv, *scr = lds + L::oScr, *red = lds + L::oRed;

@@ -126,3 +126,59 @@ def test_cpp_shim_and_example_compile(M, tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+# ---- scenario helpers of the robot wrapper (robot_utils/pandaWrapper.cpp:14-107): host code, no GPU needed ----
+def _rand_q(rng, M):
+    lim = M.default_limits()
+    return lim["qmin"] + (lim["qmax"] - lim["qmin"]) * (0.15 + 0.7 * rng.random(7))
+
+
+def test_tool_jacobian_and_forward_velocities_match_oracle(M):
+    rng = np.random.default_rng(7)
+    mdl, omdl = M.default_model(), o.default_model()
+    for _ in range(20):
+        q, qd = _rand_q(rng, M), rng.normal(size=7)
+        J, p, R = M.tool_jacobian(mdl, q)
+        Jo = o.frame_jacobian(q, np.array(omdl.tool), omdl)
+        p7, R7, p8, pt = o.fk(q, omdl)
+        assert np.abs(J - Jo).max() < 1e-12 and np.abs(p - pt).max() < 1e-12 and np.abs(R - R7).max() < 1e-12
+        assert np.abs(M.forward_velocities(mdl, q, qd) - Jo @ qd).max() < 1e-12
+        # the linear rows are the derivative of the tool position (central differences)
+        for j in range(7):
+            e = np.zeros(7); e[j] = 1e-6
+            dp = (M.tool_jacobian(mdl, q + e)[1] - M.tool_jacobian(mdl, q - e)[1]) / 2e-6
+            assert np.abs(dp - J[:3, j]).max() < 1e-8
+
+
+def test_inverse_velocities_is_the_damped_pseudo_inverse(M):
+    rng = np.random.default_rng(8)
+    mdl = M.default_model()
+    for _ in range(20):
+        q = _rand_q(rng, M)
+        lin, ang = rng.uniform(-1.7, 1.7, 3), np.zeros(3)          # examples/benchmark.cpp:20: zero angular speed
+        J = M.tool_jacobian(mdl, q)[0]
+        qd = M.inverse_velocities(mdl, q, lin, ang)
+        ref = J.T @ np.linalg.solve(J @ J.T + 1e-5 * np.eye(6), np.concatenate([lin, ang]))
+        assert np.abs(qd - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+        back = M.forward_velocities(mdl, q, qd)
+        if np.linalg.cond(J @ J.T) < 1e3:                          # away from singularities the damping is negligible
+            assert np.abs(back - np.concatenate([lin, ang])).max() < 1e-2
+
+
+def test_inverse_kinematic_reaches_reachable_poses(M):
+    rng = np.random.default_rng(9)
+    mdl = M.default_model()
+    ok = 0
+    for _ in range(10):
+        q_true = _rand_q(rng, M)
+        _, p, R = M.tool_jacobian(mdl, q_true)
+        q, conv, it = M.inverse_kinematic(mdl, R, p, q_init=q_true + 0.3 * rng.normal(size=7))
+        _, p2, R2 = M.tool_jacobian(mdl, q)
+        if conv:
+            ok += 1
+            assert it <= 1000 and np.abs(p2 - p).max() < 2e-4 and np.abs(R2 - R).max() < 2e-4
+    assert ok >= 8
+    # an unreachable pose hits the iteration cap and says so
+    q, conv, it = M.inverse_kinematic(mdl, np.eye(3), np.array([3.0, 0.0, 0.0]))
+    assert not conv and it == 1000
