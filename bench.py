@@ -83,9 +83,14 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=192)
-    ap.add_argument("--workload", choices=["batch", "rh"], default="batch",
-                    help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon, extra line")
+    ap.add_argument("--workload", choices=["batch", "rh", "shipped"], default="batch",
+                    help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon, extra line; "
+                         "shipped: the reference-as-shipped solver depth (N=19, 2 SQP iterations; SURVEY.md 8d), extra line")
     args = ap.parse_args()
+    global NUM_SEG, SQP_ITERS, BYTES_PER_TRAJ
+    if args.workload == "shipped":
+        NUM_SEG, SQP_ITERS = 6, 2            # robot_ocp.hpp:32 NUM_SEG as shipped (N=19), motionPlanner.cpp:15 max_iter 2
+        BYTES_PER_TRAJ = 6656                # compulsory I/O per trajectory at N=19
 
     import torch
     import mpc_motion_planner_amd as M
@@ -169,13 +174,15 @@ def main():
         except Exception:
             traffic = None
         out = {
-            "metric": "trajectories/sec, 7-DoF Panda min-time OCP, 1k batch @ 1/2/4/8 GPU",
+            "metric": "trajectories/sec, 7-DoF Panda min-time OCP, 1k batch @ 1/2/4/8 GPU" if args.workload == "batch"
+                      else "trajectories/sec, 7-DoF Panda min-time OCP, reference-as-shipped depth (N=19, 2 SQP), 1k batch",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d-problem random batch per GPU, 7-DoF Panda, N=%d Chebyshev nodes (cubic x %d segments), "
-                                   "%d SQP iters, <=700 ADMM iters, built-in warm start (BASELINE.json configs[1])"
-                                   % (B, N, NUM_SEG, SQP_ITERS),
+                                   "%d SQP iters, <=700 ADMM iters, built-in warm start (%s)"
+                                   % (B, N, NUM_SEG, SQP_ITERS, "BASELINE.json configs[1]" if args.workload == "batch"
+                                      else "reference as shipped: robot_ocp.hpp:32, motionPlanner.cpp:15"),
                        "batch_per_gpu": B, "seed": scenarios.SEED, "margins": list(MARGINS)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
