@@ -37,6 +37,15 @@ __device__ __forceinline__ double wave_sum(double x) {      // the total, valid 
     return (x + read_lane(x, 16)) + (read_lane(x, 32) + read_lane(x, 48));
 }
 
+// reciprocal of a positive, normal-range pivot: hardware estimate + two Newton steps (the full IEEE division sequence is
+// ~25 dependent instructions on the critical path of every sweep step; scaling/denormal handling is not needed here)
+__device__ __forceinline__ double pivot_rcp(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+}
+
 // 16-byte LDS read of two consecutive doubles (ds_read_b128: full LDS rate; ds_read2_b64 runs at half rate)
 struct alignas(16) D2 { double x, y; };
 __device__ __forceinline__ D2 lds2(const double *p) { return *reinterpret_cast<const D2 *>(__builtin_assume_aligned(p, 16)); }
@@ -153,12 +162,12 @@ struct Qp2 {
     // factor area (must match build_streams): S | KJJ[NSEG] | KJC[HS] | Eh[HS] | scratch[32] | rdv[8]
     static constexpr int oS = oRed + NW * 8;                   // packed S, then -(S^-1)
     static constexpr int oKJJ = oS + D::SP;                    // [NSEG][JP]
-    static constexpr int oKJC = oKJJ + NSEG * D::JP;           // [HS][JC]
+    static constexpr int oKJC = oKJJ + NSEG * D::JP;           // [NSEG][JC] = stream group 0 [HS][JC] | group 1 (the 'Eh' slot of build_streams); E_s in place after the sweep
     static constexpr int oEh = oKJC + HS * D::JC;              // [HS][JC]
     static constexpr int oScr = oEh + HS * D::JC;              // [32] partial sums of split entries
     static constexpr int oRdv = oScr + 32;                     // [2][4] pivot reciprocals of the running sweep (double buffered)
     static constexpr int oCol = (oRdv + 8 + 1) / 2 * 2;                      // [2][CB] current / next pivot column(s) of the sweep
-    static constexpr int CB = 4 * 64 > ((D::nI + 15) / 16 * 16) ? 4 * 64 : ((D::nI + 15) / 16 * 16);
+    static constexpr int CB = NSEG * 80 > ((D::nI + 15) / 16 * 16) ? NSEG * 80 : ((D::nI + 15) / 16 * 16);   // column buffer: NSEG blocks of 78 (+2 pads)
     static constexpr int oEndF = oCol + 2 * CB;
     static_assert(oCol % 2 == 0 && CB % 2 == 0, "16-byte reads of the pivot column");
     // ADMM view, overlaying [oS, ...) once the factor blocks have been picked up by their owners:
@@ -860,11 +869,11 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
     }
     STAMP(0);
     // ---------------- assembly + factorisation ----------------
-    double *F = lds + L::oS;                      // factor area: S | KJJ[NSEG] | KJC[HS] | Eh[HS] | scratch | rdv
-    double *S = F, *KJJ = lds + L::oKJJ, *KJC = lds + L::oKJC, *Eh = lds + L::oEh, *rdv = lds + L::oRdv;
+    double *F = lds + L::oS;                      // factor area: S | KJJ[NSEG] | KJC[NSEG] (two stream groups of HS) | scratch | rdv
+    double *S = F, *KJJ = lds + L::oKJJ, *KJC = lds + L::oKJC, *rdv = lds + L::oRdv;
     const double *V = lds + L::oRv;
     // one assembly pass: every thread interprets its own (load-balanced) word stream
-    auto run_pass = [&](int p) {
+    auto run_pass = [&](int p, int dst_off) {
         const uint32_t *wp = st.words + st.off[p] + tid;
         const int W = st.W[p];
         double acc = 0.0;
@@ -878,7 +887,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
                 if ((int)x >= 0) {
                     acc += ((x >> 28) & 1u ? rho_eq : rho_in) * V[x & 0x3fffu] * V[(x >> 14) & 0x3fffu];
                 } else if (x != 0xFFFFFFFFu) {
-                    F[x & 0xFFFFFu] = acc;
+                    F[(x & 0xFFFFFu) + dst_off] = acc;
                     acc = 0.0;
                 }
             }
@@ -890,22 +899,23 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         while (i * (i + 1) / 2 > e) i--;
         j = e - i * (i + 1) / 2;
     };
-    // symmetric sweep of `nblk` packed nb x nb SPD blocks (stride bstride) in LDS: A <- -(A^-1):
-    //     a_ij -= a_ik a_jk / a_kk,   a_ik <- a_ik / a_kk,   a_kk <- -1 / a_kk      for k = 0 .. nb-1.
+    // Symmetric sweep of `nblk` symmetric nb x nb blocks on their first `npiv` pivots:
+    //     a_ij -= a_ik a_jk / a_kk,   a_ik <- a_ik / a_kk,   a_kk <- -1 / a_kk      for k = 0 .. npiv-1,
+    // i.e. [[A, B], [B^T, D]] -> [[-A^-1, A^-1 B], [(A^-1 B)^T, D - B^T A^-1 B]] (npiv = nb: the whole block becomes -(A^-1)).
     // A thread owns one 4x4 tile of the lower block triangle (diagonal tiles hold both triangles, the lower one is
     // authoritative) in registers for the whole sweep, so a step is 16 FMAs on four 16-byte LDS reads of the pivot column.
     // Per step only the pivot column and the pivot reciprocal travel through LDS (double buffered): ONE barrier per step
     // and no division outside the pivot owner. The step loop is unrolled over k mod 4, which makes every register index
-    // of the pivot row/column handling static.
-    auto sweep = [&](double *A, int nb, int nblk, int bstride) {
+    // of the pivot row/column handling static.  ld(blk,i,j) (i >= j) reads an entry; st(blk,i,j,v) stores an entry that has a
+    // pivot index (j < npiv); st_trail(blk,i,j,v) receives the trailing (Schur) entries, one block at a time with a barrier
+    // in between (the trailing blocks of different segments overlap in S).
+    auto sweep = [&](int nb, int npiv, int nblk, int cst, auto &&ld, auto &&st_, auto &&st_trail) {
         constexpr int CB = L::CB;
         const int nt4 = (nb + 3) >> 2, ntile = nt4 * (nt4 + 1) / 2;
-        const int cst = nblk > 1 ? 64 : CB;          // column-buffer stride per block
         const bool live = tid < ntile * nblk;
         int blk = 0, Ib = 0, Jb = 0;
         if (live) { blk = tid / ntile; tri_decode(tid % ntile, Ib, Jb); }
         const bool diag = live && Ib == Jb;
-        double *Ab = A + blk * bstride;
         double *cb0 = lds + L::oCol + blk * cst;
         double v[4][4];
 #pragma unroll
@@ -913,20 +923,20 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int i = 4 * Ib + a, j = 4 * Jb + q;
-                v[a][q] = (live && i < nb && j < nb) ? Ab[i >= j ? packed(i, j) : packed(j, i)] : 0.0;
+                v[a][q] = (live && i < nb && j < nb) ? (i >= j ? ld(blk, i, j) : ld(blk, j, i)) : 0.0;
             }
         }
         if (live && Jb == 0) {                       // column 0 (and its pivot reciprocal)
 #pragma unroll
             for (int a = 0; a < 4; a++) cb0[4 * Ib + a] = v[a][0];
-            if (Ib == 0) { if (!(v[0][0] > 0.0)) status |= 2; rdv[blk] = 1.0 / v[0][0]; }
+            if (Ib == 0) { if (!(v[0][0] > 0.0)) status |= 2; rdv[blk] = pivot_rcp(v[0][0]); }
         }
         __syncthreads();
-        for (int kb = 0; kb < nt4; kb++) {
+        for (int kb = 0; 4 * kb < npiv; kb++) {
 #pragma unroll
             for (int ka = 0; ka < 4; ka++) {
                 const int k = 4 * kb + ka;
-                if (k < nb) {                        // workgroup-uniform
+                if (k < npiv) {                      // workgroup-uniform
                     const int k1a = (ka + 1) & 3, k1b = kb + (ka == 3 ? 1 : 0);
                     if (live) {
                         const double *cur = cb0 + (k & 1) * CB;
@@ -950,14 +960,14 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
                             for (int a = 0; a < 4; a++) v[a][ka] = cI[a] * rd;
                             if (Ib == kb) v[ka][ka] = -rd;
                         }
-                        if (k + 1 < nb) {            // publish column k+1 and its pivot reciprocal
+                        if (k + 1 < npiv) {          // publish column k+1 and its pivot reciprocal
                             if (Jb == k1b) {
 #pragma unroll
                                 for (int a = 0; a < 4; a++) nxt[4 * Ib + a] = (diag && a < k1a) ? v[k1a][a] : v[a][k1a];
                                 if (diag) {
                                     const double pv = v[k1a][k1a];
                                     if (!(pv > 0.0)) status |= 2;
-                                    rdv[((k + 1) & 1) * 4 + blk] = 1.0 / pv;
+                                    rdv[((k + 1) & 1) * 4 + blk] = pivot_rcp(pv);
                                 }
                             } else if (Ib == k1b) {
 #pragma unroll
@@ -975,14 +985,29 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int i = 4 * Ib + a, j = 4 * Jb + q;
-                    if (i < nb && j <= i) Ab[packed(i, j)] = v[a][q];
+                    if (i < nb && j <= i && j < npiv) st_(blk, i, j, v[a][q]);
                 }
             }
         }
         __syncthreads();
+        if (npiv < nb) {
+            for (int sblk = 0; sblk < nblk; sblk++) {
+                if (live && blk == sblk) {
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int i = 4 * Ib + a, j = 4 * Jb + q;
+                            if (i < nb && j <= i && j >= npiv) st_trail(blk, i, j, v[a][q]);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
     };
     // pass 0: interface block S and every interior diagonal block K_JJ,s
-    run_pass(0);
+    run_pass(0, 0);
     __syncthreads();
     if (isT && st.split_dst >= 0) {               // the T-T entry was accumulated in chunks
         double acc = 0.0;
@@ -1000,82 +1025,43 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         }
     }
     __syncthreads();
+    // coupling blocks K_JC of every segment (the stream passes are grouped by HS segments: later groups land behind)
+    for (int g = 0; g < st.npass - 1; g++) run_pass(1 + g, g * L::HS * D::JC);
+    __syncthreads();
+    if (isVar && ipos < nJ) KJC[(ipos / 49) * D::JC + (ipos % 49) * 29 + 28] += v_ha;
+    __syncthreads();
     STAMP(9);
-    sweep(KJJ, 49, NSEG, D::JP);                   // K_JJ,s <- -G_s, all segments concurrently
+    // One sweep per segment of the symmetric [[K_JJ, K_JC], [K_CJ, 0]] (78 x 78) on its 49 interior pivots, all segments
+    // concurrently:  K_JJ <- -G_s,  K_JC <- E_s = G_s K_JC,  trailing block = -K_CJ E_s, which is the segment's Schur
+    // complement contribution and is added to S.
+    sweep(49 + 29, 49, NSEG, 80,
+          [&](int blk, int i, int j) -> double {
+              return i < 49 ? KJJ[blk * D::JP + packed(i, j)] : (j < 49 ? KJC[blk * D::JC + j * 29 + (i - 49)] : 0.0);
+          },
+          [&](int blk, int i, int j, double val) {
+              if (i < 49) KJJ[blk * D::JP + packed(i, j)] = val;
+              else KJC[blk * D::JC + j * 29 + (i - 49)] = val;
+          },
+          [&](int blk, int i, int j, double val) {
+              const int ca = i - 49, cb = j - 49;
+              const int ia = ca < 28 ? 14 * blk + ca : nI - 1, ib = cb < 28 ? 14 * blk + cb : nI - 1;
+              S[packed(ia, ib)] += val;
+          });
     STAMP(11);
-    for (int s0 = 0; s0 < NSEG; s0 += L::HS) {
-        const int nh = (NSEG - s0 < L::HS) ? NSEG - s0 : L::HS;
-        run_pass(1 + s0 / L::HS);                  // coupling blocks K_JC of this segment group
-        __syncthreads();
-        if (isVar && ipos < nJ && ipos / 49 >= s0 && ipos / 49 < s0 + nh)
-            KJC[(ipos / 49 - s0) * D::JC + (ipos % 49) * 29 + 28] += v_ha;
-        __syncthreads();
-        STAMP(10);
-        // E_h = G K_JC: a thread produces a 2 x 4 block (rows 2rp, 2rp+1; columns 4cq..4cq+3, cq < 7) so every LDS operand
-        // feeds two or four FMAs, or one entry of the T column (column 28); rows of -G are walked along the packed triangle
-        for (int t = tid; t < nh * (25 * 7 + 49); t += NT) {
-            const int h = t / (25 * 7 + 49), tt = t % (25 * 7 + 49);
-            const double *Gn = KJJ + (s0 + h) * D::JP, *Kc = KJC + h * D::JC;
-            double *Eo = Eh + h * D::JC;
-            if (tt < 25 * 7) {
-                const int rp = tt / 7, c0 = 4 * (tt % 7);
-                const int r0 = 2 * rp, r1 = (2 * rp + 1 < 49) ? 2 * rp + 1 : r0;
-                const int t0 = r0 * (r0 + 1) / 2, t1 = r1 * (r1 + 1) / 2;
-                double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-                int tj = 0;
-                for (int j = 0; j < 49; j++) {
-                    tj += j;                                   // j (j+1) / 2 - j ... running triangular base of row j
-                    const double g0 = Gn[j <= r0 ? t0 + j : tj + r0];
-                    const double g1 = Gn[j <= r1 ? t1 + j : tj + r1];
-                    const double *kr = Kc + j * 29 + c0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { a0[q] -= g0 * kr[q]; a1[q] -= g1 * kr[q]; }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    Eo[r0 * 29 + c0 + q] = a0[q];
-                    if (r1 != r0) Eo[r1 * 29 + c0 + q] = a1[q];
-                }
-            } else {
-                const int r0 = tt - 25 * 7, t0 = r0 * (r0 + 1) / 2;
-                double acc = 0.0;
-                int tj = 0;
-                for (int j = 0; j < 49; j++) {
-                    tj += j;
-                    acc -= Gn[j <= r0 ? t0 + j : tj + r0] * Kc[j * 29 + 28];
-                }
-                Eo[r0 * 29 + 28] = acc;
-            }
-        }
-        __syncthreads();
-        STAMP(12);
-        // S -= K_CJ E on the lower triangle of each 29x29 coupled block
-        for (int h = 0; h < nh; h++) {
-            const int sg = s0 + h;
-            for (int e = tid; e < 29 * 30 / 2; e += NT) {
-                int ca, cb;
-                tri_decode(e, ca, cb);
-                const double *kc = KJC + h * D::JC + ca, *ec = Eh + h * D::JC + cb;
-                double acc = 0.0;
-                for (int i = 0; i < 49; i++) acc += kc[i * 29] * ec[i * 29];
-                const int ia = ca < 28 ? 14 * sg + ca : nI - 1, ib = cb < 28 ? 14 * sg + cb : nI - 1;
-                S[packed(ia, ib)] -= acc;
-            }
-            __syncthreads();      // consecutive segments update overlapping entries of S (shared node, T)
-        }
-        STAMP(13);
-        // park -G and E of this group in the per-problem HBM scratch; the role threads load their register blocks
-        // from there once the whole factorisation is done (keeps the factorisation's register footprint small)
-        for (int h = 0; h < nh; h++) {
-            double *dst = fac + (s0 + h) * (D::JP + D::JC);
-            for (int e = tid; e < D::JP; e += NT) dst[e] = KJJ[(s0 + h) * D::JP + e];
-            for (int e = tid; e < D::JC; e += NT) dst[D::JP + e] = Eh[h * D::JC + e];
-        }
-        __syncthreads();
-        STAMP(14);
+    // park -G and E in the per-problem HBM scratch; the role threads load their register blocks from there once the
+    // whole factorisation is done (keeps the factorisation's register footprint small)
+    for (int sg = 0; sg < NSEG; sg++) {
+        double *dst = fac + sg * (D::JP + D::JC);
+        for (int e = tid; e < D::JP; e += NT) dst[e] = KJJ[sg * D::JP + e];
+        for (int e = tid; e < D::JC; e += NT) dst[D::JP + e] = KJC[sg * D::JC + e];
     }
+    __syncthreads();
+    STAMP(14);
     STAMP(1);
-    sweep(S, nI, 1, D::SP);                        // S <- -(S^-1)
+    sweep(nI, nI, 1, L::CB,
+          [&](int, int i, int j) -> double { return S[packed(i, j)]; },
+          [&](int, int i, int j, double val) { S[packed(i, j)] = val; },
+          [&](int, int, int, double) {});                  // S <- -(S^-1)
     STAMP(2);
     {
         const int any = __syncthreads_or(status);
