@@ -877,12 +877,13 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         const uint32_t *wp = st.words + st.off[p] + tid;
         const int W = st.W[p];
         double acc = 0.0;
-        for (int w0 = 0; w0 < W; w0 += 4) {
-            uint32_t xw[4];
+        constexpr int WC = 16;                       // stream words fetched per round trip (coalesced, L2-resident)
+        for (int w0 = 0; w0 < W; w0 += WC) {
+            uint32_t xw[WC];
 #pragma unroll
-            for (int q = 0; q < 4; q++) xw[q] = (w0 + q < W) ? wp[(size_t)(w0 + q) * NT] : 0xFFFFFFFFu;   // 4 loads in flight
+            for (int q = 0; q < WC; q++) xw[q] = (w0 + q < W) ? wp[(size_t)(w0 + q) * NT] : 0xFFFFFFFFu;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < WC; q++) {
                 const uint32_t x = xw[q];
                 if ((int)x >= 0) {
                     acc += ((x >> 28) & 1u ? rho_eq : rho_in) * V[x & 0x3fffu] * V[(x >> 14) & 0x3fffu];
