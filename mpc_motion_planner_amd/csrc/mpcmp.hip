@@ -431,7 +431,7 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
     w.model = ctx->d_model; w.ext_of_int = ctx->d_ext_of_int; w.entry_ptr = ctx->d_entry_ptr; w.terms = ctx->d_terms;
     TRY(dalloc(ctx, &w.z, B * n)); TRY(dalloc(ctx, &w.lam, B * mn)); TRY(dalloc(ctx, &w.ceq, B * ctx->meq));
     TRY(dalloc(ctx, &w.g, B * 8 * N)); TRY(dalloc(ctx, &w.Gk, B * N * 176)); TRY(dalloc(ctx, &w.p, B * n));
-    TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.qp_total, B));
+    TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.perm, B)); TRY(dalloc(ctx, &w.okey, B)); TRY(dalloc(ctx, &w.qp_total, B));
     TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, (size_t)B * MPCMP_DBG_WORDS));
     TRY(dalloc(ctx, &ctx->d_x0, B * 14)); TRY(dalloc(ctx, &ctx->d_xf, B * 14));
     TRY(dalloc(ctx, &ctx->d_wx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_wu, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
@@ -505,6 +505,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         else hipLaunchKernelGGL(k_qp<NSEG>, dim3(B), dim3(D::NT), l_qp, st, ctx->cfg, w);
         if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
         if (only_qp) break;
+        if (it + 1 < iters) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, B, w.qpit, w.okey, w.perm);
         hipLaunchKernelGGL(k_step<NSEG>, dim3(B), dim3(D::NT), l_step, st, ctx->cfg, ctx->model, w, it == iters - 1 ? 1 : 0, it,
                            d_sx, d_su, d_sT, d_info);
     }

@@ -823,9 +823,9 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
     constexpr int N = D::N, n = D::n, meq = D::meq, nJ = D::nJ, nI = D::nI, NT = L::NT;
     constexpr int GS = L::GS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x, b = ws.perm[blockIdx.x];      // launch order: solver_kernels.hpp k_order
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
-    double *fac = fac_all + (size_t)b * L::FAC;
+    double *fac = fac_all + (size_t)blockIdx.x * L::FAC;
     Qp2Ctx<NSEG> c;
     c.cfg = &cfg; c.ws = ws; c.lds = lds; c.fac = fac; c.tid = tid; c.b = b;
     c.ts = 1.0 / (2.0 * NSEG);
