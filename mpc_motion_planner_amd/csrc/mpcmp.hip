@@ -36,7 +36,6 @@ struct mpcmp_ctx {
     double *d_x0 = nullptr, *d_xf = nullptr, *d_wx = nullptr, *d_wu = nullptr, *d_wT = nullptr;
     double *d_sx = nullptr, *d_su = nullptr, *d_sT = nullptr;
     mpcmp_info *d_info = nullptr;
-    double *d_fac = nullptr;   // k_qp2: per-problem factor scratch
     uint32_t *d_stream = nullptr;
     Qp2Streams streams{};
     // timing of the dominant kernel (k_qp)
@@ -438,7 +437,6 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
     TRY(dalloc(ctx, &ctx->d_sx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_su, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_sT, B));
     TRY(dalloc(ctx, &ctx->d_info, B));
     if (cfg->num_seg == 2 || cfg->num_seg == 4) {
-        TRY(dalloc(ctx, &ctx->d_fac, B * (size_t)cfg->num_seg * (1225 + 1421)));
         AsmStreams as;
         const int GS = cfg->num_seg == 4 ? Qp2<4>::GS : Qp2<2>::GS, RSv = Qp2<4>::RS;
         if (!build_streams(cfg->num_seg, 1024, Qp2<4>::HS, GS, RSv, as)) { ctx->err = "internal: assembly stream generation failed"; return fail(MPCMP_EINVAL); }
@@ -501,7 +499,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     for (int it = 0; it < iters; it++) {
         hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
         if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
-        if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(B), dim3(1024), l_qp2, st, ctx->cfg, w, ctx->d_fac, ctx->streams);
+        if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(B), dim3(1024), l_qp2, st, ctx->cfg, w, ctx->streams);
         else hipLaunchKernelGGL(k_qp<NSEG>, dim3(B), dim3(D::NT), l_qp, st, ctx->cfg, w);
         if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
         if (only_qp) break;

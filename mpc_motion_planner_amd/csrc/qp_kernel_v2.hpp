@@ -142,7 +142,6 @@ struct Qp2 {
     static constexpr int GS = 24;                                  // row stride of the path Jacobians in LDS (22 + 2 zero pads)
     static constexpr int XS = 24;                                  // node-major x~ stride: [x_k(14) u_k(7) T pad pad]
     static constexpr int HS = 2;                                   // segments factorised concurrently
-    static constexpr int FAC = NSEG * (D::JP + D::JC);             // per-problem factor scratch in HBM (doubles)
     static_assert(8 * NPR <= NB && D::n <= NB, "role B mapping");
     static_assert(16 * D::N <= 4 * NEQ && D::meq <= NB, "path-row lanes must fit the E^T quads, dynamics rows role B");
     // LDS (doubles)
@@ -191,7 +190,6 @@ struct Qp2Ctx {
     const mpcmp_config *cfg;
     WS ws;
     double *lds;
-    const double *fac;      // this problem's factor scratch: per segment [-G packed (JP) | E (49x29)]
     int tid, b;
     double ts, tsT, rho_in, rho_eq, sigma, alpha;
 };
@@ -240,7 +238,6 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     double *rhsJ = lds + L::oRhsJ, *xn = lds + L::oXn, *tpl = lds + L::oTp, *misc = lds + L::oMisc;
 #ifdef MPCMP_STAMPS
     unsigned long long *stamp_acc = reinterpret_cast<unsigned long long *>(lds + L::oStamp), stamp_t = clock64();
-    if (tid == 0) for (int k = 0; k < 16; k++) stamp_acc[k] = 0;
 #endif
     const int Q = tid >> 2, part = tid & 3;
     const bool act = Q < L::NGQ;
@@ -248,7 +245,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     // rows (2lp, 2lp+1) of G_s x columns part*14..+13 and of E_s x columns part*8..+7, all in registers
     double m1[2][14], e1[2][8];
     {
-        const double *Gn = c.fac + seg * (D::JP + D::JC), *Es = Gn + D::JP;
+        const double *Gn = lds + L::oKJJ + seg * D::JP, *Es = lds + L::oKJC + seg * D::JC;      // still in the factor area
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             const int row = 2 * lp + a;
@@ -267,7 +264,10 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
                 if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();      // every owner has picked up its blocks from the staging area (S is read by role B)
+        __syncthreads();      // every owner has picked up its blocks from the factor area (S is read by role B)
+#ifdef MPCMP_STAMPS
+        if (tid == 0) for (int k = 0; k < 16; k++) stamp_acc[k] = 0;      // (the accumulators overlay the factor area)
+#endif
         __syncthreads();      // LDS-resident constants published
     }
     int jdst = -1;      // where row 2lp+part of x_J goes in the node-major x~
@@ -283,6 +283,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     const double *xb = part == 0 ? xn0 + 6 : part == 1 ? xn1 : part == 2 ? xn1 + 8 : xn1 + 20;
     int it = 0, done = 0, until_check = cfg.check_every;
     BUSY_DECL;
+    STAMP2(12);                 // role prologue: register blocks fetched from the factor scratch, constants published
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: wave 0 sums the T column of A^T w ----
         if (tid < 64 && MPCMP_ABL != 4) {
@@ -370,7 +371,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     BUSY_DUMP;
     if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; }
 #ifdef MPCMP_STAMPS
-    if (tid == 0) { unsigned long long *o = c.ws.dbg + (size_t)c.b * MPCMP_DBG_WORDS; for (int k = 3; k < 9; k++) o[k] = stamp_acc[k]; o[15] = it; }
+    if (tid == 0) { unsigned long long *o = c.ws.dbg + (size_t)c.b * MPCMP_DBG_WORDS; for (int k = 3; k < 9; k++) o[k] = stamp_acc[k]; o[12] = stamp_acc[12]; o[15] = it; }
 #endif
 }
 
@@ -409,7 +410,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     }
     double m1[2][14];
     {
-        const double *Es = c.fac + seg * (D::JP + D::JC) + D::JP;
+        const double *Es = lds + L::oKJC + seg * D::JC;
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             const int cc = a == 0 ? ec0 : ec1;
@@ -817,7 +818,7 @@ struct Qp2Streams {
 };
 
 template <int NSEG>
-__global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *fac_all, Qp2Streams st) {
+__global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, Qp2Streams st) {
     using D = Dim<NSEG>;
     using L = Qp2<NSEG>;
     constexpr int N = D::N, n = D::n, meq = D::meq, nJ = D::nJ, nI = D::nI, NT = L::NT;
@@ -825,9 +826,8 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = ws.perm[blockIdx.x];      // launch order: solver_kernels.hpp k_order
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
-    double *fac = fac_all + (size_t)blockIdx.x * L::FAC;
     Qp2Ctx<NSEG> c;
-    c.cfg = &cfg; c.ws = ws; c.lds = lds; c.fac = fac; c.tid = tid; c.b = b;
+    c.cfg = &cfg; c.ws = ws; c.lds = lds; c.tid = tid; c.b = b;
     c.ts = 1.0 / (2.0 * NSEG);
     c.rho_in = cfg.rho; c.rho_eq = cfg.rho * cfg.rho_eq_scale; c.sigma = cfg.sigma; c.alpha = cfg.alpha;
     const double ts = c.ts, rho_in = c.rho_in, rho_eq = c.rho_eq, sigma = c.sigma;
@@ -1049,14 +1049,8 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
               S[packed(ia, ib)] += val;
           });
     STAMP(11);
-    // park -G and E in the per-problem HBM scratch; the role threads load their register blocks from there once the
-    // whole factorisation is done (keeps the factorisation's register footprint small)
-    for (int sg = 0; sg < NSEG; sg++) {
-        double *dst = fac + sg * (D::JP + D::JC);
-        for (int e = tid; e < D::JP; e += NT) dst[e] = KJJ[sg * D::JP + e];
-        for (int e = tid; e < D::JC; e += NT) dst[D::JP + e] = KJC[sg * D::JC + e];
-    }
-    __syncthreads();
+    // -G_s and E_s stay where the sweep left them (K_JJ / K_JC areas): the role threads pick their register blocks up from
+    // there before the ADMM view overlays the factor area
     STAMP(14);
     STAMP(1);
     sweep(nI, nI, 1, L::CB,
@@ -1069,7 +1063,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, double *f
         if (tid == 0 && any) ws.status[b] |= any;
     }
 #ifdef MPCMP_STAMPS
-    if (tid == 0) { unsigned long long *dbg = ws.dbg + (size_t)b * MPCMP_DBG_WORDS; for (int k = 0; k < 3; k++) dbg[k] = stamp_acc[k]; for (int k = 9; k < 15; k++) dbg[k] = stamp_acc[k]; }
+    if (tid == 0) { unsigned long long *dbg = ws.dbg + (size_t)b * MPCMP_DBG_WORDS; for (int k = 0; k < 3; k++) dbg[k] = stamp_acc[k]; for (int k = 9; k < 15; k++) if (k != 12) dbg[k] = stamp_acc[k]; }
 #endif
     if (tid < L::NA1) qp2_role_a1<NSEG>(c);
     else if (tid < L::NA1 + L::NA2) qp2_role_a2<NSEG>(c);

@@ -38,7 +38,7 @@ for k, nm in enumerate(names):
     else:
         print("%-26s %10.1f cycles / iteration" % (nm, (st[:, k] / its).mean()))
 print("loop total %10.1f cycles / iteration" % ((st[:, 3:9].sum(axis=1) / its).mean()))
-for k, nm in zip(range(9, 15), ["  assemble K_JJ,K_JC", "  diag/arrow", "  sweep K_JJ", "  E = G K_JC", "  S -= K_CJ E", "  park to HBM"]):
+for k, nm in zip(range(9, 15), ["  assemble K_JJ,K_JC", "  (unused)", "  augmented sweep K_JJ|K_JC", "  role prologue (after the factorisation)", "  (unused)", "  park to HBM"]):
     print("%-26s %10.0f cycles (once, all segment groups)" % (nm, st[:, k].mean()))
 
 # per-wave busy cycles per iteration (k_qp2 only): which role is the critical one in each phase
