@@ -7,10 +7,12 @@
 //     over the 1024 threads); LDS carries only the exchanged vectors and the (padded) path Jacobians;
 //   * each thread owns a 2-row x k-column register block, so one LDS operand read feeds two FMAs; the
 //     k-way partial sums are combined with DPP (quad_perm / row_half_mirror), not through LDS;
-//   * waves are role-specialised (group A = segment quads for the interior solves + all general rows, group B =
-//     interface solve + variables), 5 workgroup barriers per ADMM iteration.
-// Factorisation: segment blocks are processed two at a time in LDS (symmetric sweep), then loaded by their
-// owner threads, so the LDS footprint stays at ~125 KB.
+//   * waves are role-specialised (A1: G_s / E_s blocks of the interior solves; A2: E_s^T blocks grouped by interface entry
+//     pair + the path rows; B: S^-1 blocks, variables, dynamics rows), 5 workgroup barriers per ADMM iteration, and the
+//     roles that are idle in a phase prefetch their constants for the next one.
+// Factorisation: one augmented symmetric sweep per segment (all segments concurrently, 4x4 register tiles) yields -G_s,
+// E_s and the Schur contribution; a second sweep inverts S.  The factor never leaves the CU: the role threads copy their
+// register blocks straight out of the factor area in LDS.
 #pragma once
 #include "solver_kernels.hpp"
 
