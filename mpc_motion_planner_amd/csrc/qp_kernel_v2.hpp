@@ -30,6 +30,21 @@ __device__ __forceinline__ double dpp_mov(double x) {
 __device__ __forceinline__ double sum2(double x) { return x + dpp_mov<0xB1>(x); }                  // lanes i, i^1
 __device__ __forceinline__ double sum4(double x) { x += dpp_mov<0xB1>(x); return x + dpp_mov<0x4E>(x); }
 __device__ __forceinline__ double sum8(double x) { x = sum4(x); return x + dpp_mov<0x141>(x); }   // + row_half_mirror
+// Two-row quad reduction.  A lane of a quad holds partial sums of TWO rows; lanes store the row of their own parity first
+// ("own": row 2p + (lane & 1)) and the other row second, so the exchange with the xor-1 neighbour completes both rows at
+// once: even lanes end with the total of row 2p, odd lanes with that of row 2p+1 -- half the DPP traffic of two sum4()
+// and no select afterwards (the summation order per row is the one of sum4).
+__device__ __forceinline__ double quad_sum2(double own, double other) {
+    const double s = own + dpp_mov<0xB1>(other);
+    return s + dpp_mov<0x4E>(s);
+}
+// value of lane ^ 4 (parity preserving, unlike row_half_mirror): row_shl:4 into the even banks, row_shr:4 into the odd ones
+__device__ __forceinline__ double dpp_xor4(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    int tl = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xf, 0x5, false), th = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xf, 0x5, false);
+    tl = __builtin_amdgcn_update_dpp(tl, lo, 0x114, 0xf, 0xA, false); th = __builtin_amdgcn_update_dpp(th, hi, 0x114, 0xf, 0xA, false);
+    return __hiloint2double(th, tl);
+}
 __device__ __forceinline__ double read_lane(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
@@ -244,13 +259,13 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     const int Q = tid >> 2, part = tid & 3;
     const bool act = Q < L::NGQ;
     const int seg = act ? Q / 25 : 0, lp = act ? Q % 25 : 0;
-    // rows (2lp, 2lp+1) of G_s x columns part*14..+13 and of E_s x columns part*8..+7, all in registers
+    // rows (2lp, 2lp+1) of G_s x columns part*14..+13 and of E_s x columns part*8..+7, all in registers (own row first)
     double m1[2][14], e1[2][8];
     {
         const double *Gn = lds + L::oKJJ + seg * D::JP, *Es = lds + L::oKJC + seg * D::JC;      // still in the factor area
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            const int row = 2 * lp + a;
+            const int row = 2 * lp + (a ^ (part & 1));      // [0]: the row of this lane's parity, [1]: the other (quad_sum2)
 #pragma unroll
             for (int j = 0; j < 14; j++) {
                 const int col = part * 14 + j;
@@ -305,7 +320,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         STAMP2(3);
         // ---- P1 / P2: t = G_s b_J is not needed before P3, so its operand reads are spread over both phases (P1 is
         // bound by the LDS reads of b by roles A1 and A2 together, P2 only has role B's reads of r_I) ----
-        double t0, t1;
+        double tq;              // (G_s b_J)[own row]
         {
             constexpr int JS = 4;                                          // 16-byte operand pairs taken in P1
             double a0 = 0.0, a1 = 0.0;
@@ -329,8 +344,8 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
                     a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
                     a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
                 }
-                t0 = sum4(a0); t1 = sum4(a1);
-            } else { t0 = a0; t1 = a1; }
+                tq = quad_sum2(a0, a1);
+            } else { tq = a0 + a1; }
         }
         // ---- P2 (role B) ----
         BUSY_SYNC(2);
@@ -347,8 +362,8 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
                 a0 += e1[0][2 * j] * xv[j].x; a1 += e1[1][2 * j] * xv[j].x;
                 a0 += e1[0][2 * j + 1] * xv[j].y; a1 += e1[1][2 * j + 1] * xv[j].y;
             }
-            a0 = sum4(a0); a1 = sum4(a1);
-            if (jdst >= 0) xn[jdst] = part ? (t1 - a1) : (t0 - a0);
+            const double aq = quad_sum2(a0, a1);         // (E_s x_C)[own row]
+            if (jdst >= 0) xn[jdst] = tq - aq;
         }
         BUSY_SYNC(3);
         STAMP2(6);
@@ -415,7 +430,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         const double *Es = lds + L::oKJC + seg * D::JC;
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            const int cc = a == 0 ? ec0 : ec1;
+            const int cc = (a ^ (lig & 1)) == 0 ? ec0 : ec1;      // own row first (quad_sum2); lig and part have the same parity
 #pragma unroll
             for (int j = 0; j < 14; j++) {
                 const int i = part * 14 + j;
@@ -466,10 +481,9 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             a0 += p0[j].x * x2[j].x; a1 += p1[j].x * x2[j].x;
             a0 += p0[j].y * x2[j].y; a1 += p1[j].y * x2[j].y;
         }
-        a0 = sum4(a0); a1 = sum4(a1);
-        const double ax = (pq & 1) ? a1 : a0;
+        const double ax = quad_sum2(a0, a1);                                // p0 = own row (2 prp + (pq & 1)), p1 = the other
         const double wq = row_update(ax);                                   // owners: the row's multiplier-like value
-        const double w0 = dpp_mov<0x00>(wq), w1 = dpp_mov<0x55>(wq);        // quad broadcast of lanes 0 and 1
+        const double w0 = dpp_mov<0x44>(wq), w1 = dpp_mov<0x11>(wq);        // quad broadcasts: owner of the own row, of the other row
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             double cx = p0[j].x * w0 + p1[j].x * w1, cy = p0[j].y * w0 + p1[j].y * w1;
@@ -499,10 +513,10 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
                 a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
                 a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
             }
-            a0 = sum4(a0); a1 = sum4(a1);
-            a0 += f8 * dpp_mov<0x141>(a0); a1 += f8 * dpp_mov<0x141>(a1);       // 8-lane groups: row_half_mirror
-            a0 += f16 * dpp_mov<0x140>(a0);                                       // the T group of 16: row_mirror
-            if (rdst >= 0) rI[rdst] = (bI0 + bI1) - (lig ? a1 : a0);
+            double sq = quad_sum2(a0, a1);                  // even lanes: row ec0, odd lanes: row ec1
+            sq += f8 * dpp_xor4(sq);                        // 8-lane groups: the other segment's quad
+            sq += f16 * dpp_mov<0x128>(sq);                 // the T group of 16: row_ror:8 = lane ^ 8
+            if (rdst >= 0) rI[rdst] = (bI0 + bI1) - sq;
         }
         BUSY_SYNC(1);
         // ---- P2 (role B) ----
@@ -511,7 +525,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         // fetched now and only x~ remains to be read once P3 has produced it ----
         D2 p0[3], p1[3];
         {
-            const double *g0 = gkl + groff, *g1 = g0 + GS;
+            const double *g0 = gkl + groff + (pq & 1) * GS, *g1 = gkl + groff + (1 - (pq & 1)) * GS;     // own row first
 #pragma unroll
             for (int j = 0; j < 3; j++) { p0[j] = lds2(g0 + 2 * j); p1[j] = lds2(g1 + 2 * j); }
         }
@@ -635,8 +649,9 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
 #pragma unroll
         for (int j = 0; j < 10; j++) {
             const int col = part2 * 10 + j;
-            s2[j] = (isP2 && 2 * rp2 < nI && col < nI) ? -S[packed(2 * rp2, col)] : 0.0;
-            s2b[j] = (isP2 && 2 * rp2 + 1 < nI && col < nI) ? -S[packed(2 * rp2 + 1, col)] : 0.0;
+            const int ro = 2 * rp2 + (part2 & 1), rx = 2 * rp2 + 1 - (part2 & 1);      // own row first (quad_sum2)
+            s2[j] = (isP2 && ro < nI && col < nI) ? -S[packed(ro, col)] : 0.0;
+            s2b[j] = (isP2 && rx < nI && col < nI) ? -S[packed(rx, col)] : 0.0;
         }
     }
     __syncthreads();          // S consumed; the staging area may now be overwritten
@@ -730,15 +745,13 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
                 a0 += s2[2 * j] * r[j].x; a1 += s2b[2 * j] * r[j].x;
                 a0 += s2[2 * j + 1] * r[j].y; a1 += s2b[2 * j + 1] * r[j].y;
             }
-            a0 = sum8(a0); a1 = sum8(a1);
-            if (myIrow >= 0 && myIrow != nI - 1) {
-                const double xi = part2 ? a1 : a0;
-                xn[xdst] = xi;
-            }
-            if (rp2 == (nI - 1) / 2) {       // x_T is replicated (every node row, every C_s): the 8 lanes of its group share the writes
-                const double xT = ((nI - 1) & 1) ? a1 : a0;
+            double xi = quad_sum2(a0, a1);                 // even lanes: row 2 rp2, odd lanes: row 2 rp2 + 1
+            xi += dpp_xor4(xi);
+            if (myIrow >= 0 && myIrow != nI - 1) xn[xdst] = xi;
+            if (rp2 == (nI - 1) / 2 && (part2 & 1) == ((nI - 1) & 1)) {
+                // x_T is replicated (slot 21 of every node row): the four lanes of its group that hold it share the writes
 #pragma unroll
-                for (int q = 0; q < (N + 7) / 8; q++) { if (part2 + 8 * q < N) xn[(part2 + 8 * q) * XS + 21] = xT; }
+                for (int q = 0; q < (N + 3) / 4; q++) { if ((part2 >> 1) + 4 * q < N) xn[((part2 >> 1) + 4 * q) * XS + 21] = xi; }
             }
         }
         BUSY_SYNC(2);

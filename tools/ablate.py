@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = {0: "product build", 1: "B: E (rows+vars)", 2: "A2: E (path rows)", 3: "B: A (rhs gather)", 4: "A1 wave0: T column sum",
-         5: "A2: P1 (r_I)", 6: "A1: P1 part of G b", 7: "B: P2 (S^-1 r)", 8: "A1: P3 (x_J)", 9: "A1: P2 part of G b"}
+         5: "A2: P1 (r_I)", 6: "A1: P1 part of G b", 7: "B: P2 (S^-1 r)", 8: "A1: P3 (x_J)", 9: "A1: P2 part of G b", 11: "candidate build"}
 which = [int(a) for a in sys.argv[1:]] or sorted(NAMES)
 B = 1024
 import mpc_motion_planner_amd.capi as capi
