@@ -13,4 +13,4 @@ mkdir -p "$TMP/../include_ab" && true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o tools/micro/libabl11.bin mpc_motion_planner_amd/csrc/mpcmp.hip &
 wait
 rm -rf "$TMP"
-timeout 3000 /usr/local/graft/bin/gpurun --timeout 900 -- 'python tools/ablate.py 0 11 0 11 2>&1 | tail -4' 2>&1 | tail -4
+timeout 3000 /usr/local/graft/bin/gpurun --timeout 900 -- 'python tools/ablate.py 0 11 0 11 0 11 0 11 2>&1 | tail -8' 2>&1 | tail -8
