@@ -175,8 +175,8 @@ int mpcmp_rh_get(mpcmp_ctx *ctx, double *x0_now, double *sol_x, double *sol_u, d
  * last reset; launches = number of launches accumulated. */
 int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name, double *ms_total, int *launches);
 
-/* diagnostics: per-problem phase cycle stamps of the last k_qp launch, [B][144] (16 workgroup stamps, then
- * [16 waves][8] busy cycles per ADMM phase); zeros unless the library was built with -DMPCMP_STAMPS (tools/stamps.py). */
+/* diagnostics: per-problem phase cycle stamps of the last k_qp launch, [B][160] (16 workgroup stamps, then
+ * [16 waves][8] busy cycles per ADMM phase, then 16 stamps of the step kernel); zeros unless the library was built with -DMPCMP_STAMPS (tools/stamps.py). */
 int mpcmp_debug_stamps(mpcmp_ctx *ctx, int B, unsigned long long *out);
 
 #ifdef __cplusplus

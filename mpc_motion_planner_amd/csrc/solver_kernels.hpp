@@ -43,7 +43,7 @@ struct WS {
     unsigned long long *dbg;  // [B][MPCMP_DBG_WORDS] phase cycle stamps (diagnostic builds with -DMPCMP_STAMPS only)
 };
 
-#define MPCMP_DBG_WORDS 144   /* 16 workgroup stamps + [16 waves][8] per-wave busy cycles of k_qp2 */
+#define MPCMP_DBG_WORDS 160   /* 16 workgroup stamps + [16 waves][8] per-wave busy cycles of k_qp2 + 16 stamps of k_step */
 #ifdef MPCMP_STAMPS
 #define STAMP(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
 #else
@@ -724,6 +724,12 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
     double *lam = ws.lam + (size_t)b * D::mn;
     const double *y = ws.y + (size_t)b * D::mn;
     const double ts = 1.0 / (2.0 * NSEG);
+#ifdef MPCMP_STAMPS
+    unsigned long long kst_t = clock64();
+#define KSTAMP(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); ws.dbg[(size_t)b * MPCMP_DBG_WORDS + 144 + (slot)] = now_ - kst_t; kst_t = now_; } } while (0)
+#else
+#define KSTAMP(slot) do { } while (0)
+#endif
     for (int v = tid; v < n; v += NT) { zl[v] = ws.z[(size_t)b * n + v]; pl[v] = ws.p[(size_t)b * n + v]; }
     // mu = ||lambda||_inf (polympc_redef.hpp:86), l1 violation at the current iterate (:79)
     double r2[1] = {0.0};
@@ -738,6 +744,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
     if (tid < 8 * N) c0[0] += viol(ws.g[(size_t)b * 8 * N + tid], cfg.lbg[tid % 8], cfg.ubg[tid % 8]);
     if (isVar) c0[0] += viol(zl[tid], lo, hi);
     block_reduce<D::NW, 1, false>(c0, red, tid);
+    KSTAMP(0);
     const double constr = c0[0];
     const double Tcur = zl[n - 1], pT = pl[n - 1];
     const double phi = Tcur + mu * constr;           // :93  (cost = T)
@@ -754,6 +761,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
         sct[2 * t] = s; sct[2 * t + 1] = c;
     }
     __syncthreads();
+    KSTAMP(1);
     static_assert(9 * N <= NT, "one (trial, node) pair per thread");
     if (tid < ntr * N) {           // (an `if`, not a loop: see linearise_block)
         const int t = tid;
@@ -775,6 +783,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
         pv[t] = s;
     }
     __syncthreads();
+    KSTAMP(2);
     double acc[9];
     double al = 1.0;
 #pragma unroll
@@ -798,7 +807,9 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
             if (isVar) acc[t] += viol(zl[tid] + al * pl[tid], lo, hi);
         }
     }
+    KSTAMP(3);
     block_reduce<D::NW, 9, false>(acc, red, tid);
+    KSTAMP(4);
     double alpha = 1.0;
     // polympc_redef.hpp:97-117: i = 1 .. line_search_max_iter-1
     for (int t = 0; t < cfg.ls_iters - 1; t++) {
@@ -814,7 +825,9 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
     for (int i = tid; i < D::mn; i += NT) lam[i] += alpha * (y[i] - lam[i]);
     __syncthreads();
     double *gout = ws.g + (size_t)b * 8 * N, *ceqo = ws.ceq + (size_t)b * meq;
+    KSTAMP(5);
     linearise_block<NSEG>(cfg, &mdl, zl, scr, gout, ws.Gk + (size_t)b * N * 176, ceqo, tid);
+    KSTAMP(6);
     if (tid == 0) ws.alpha[b] = alpha;
     if (final_iter) {
         __threadfence_block();
@@ -840,6 +853,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
             info[b] = o;
         }
     }
+    KSTAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------

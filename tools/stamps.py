@@ -26,7 +26,7 @@ s = M.Solver(cfg, B)
 x0, xf = scenarios.make_batch(B)
 wx, wu, wT = s.warm_start(x0, xf)
 p, y, it = s.qp(x0, xf, wx, wu, wT)
-st = np.zeros((B, 144), dtype=np.uint64)
+st = np.zeros((B, 160), dtype=np.uint64)
 capi.check(capi.lib().mpcmp_debug_stamps(s._ctx, B, st.ctypes.data_as(C.c_void_p)))
 st = st.astype(np.float64)
 its = st[:, 15]
@@ -42,8 +42,19 @@ for k, nm in zip(range(9, 15), ["  assemble K_JJ,K_JC", "  (unused)", "  augment
     print("%-26s %10.0f cycles (once, all segment groups)" % (nm, st[:, k].mean()))
 
 # per-wave busy cycles per iteration (k_qp2 only): which role is the critical one in each phase
-busy = st[:, 16:].reshape(B, 16, 8)
+busy = st[:, 16:144].reshape(B, 16, 8)
 if busy.sum() > 0:
     print("per-wave busy cycles / iteration (phase A, P1, P2, P3, E); waves 0-6 role A1, 7-10 role A2, 11-15 role B")
     for w in range(16):
         print("  wave %2d  " % w + "  ".join("%7.1f" % (busy[:, w, ph] / its).mean() for ph in range(5)))
+
+# k_step phases (one SQP iteration through the public solve entry point)
+sx, su, sT, info = s.solve(x0, xf, (wx, wu, wT))
+st2 = np.zeros((B, 160), dtype=np.uint64)
+capi.check(capi.lib().mpcmp_debug_stamps(s._ctx, B, st2.ctypes.data_as(C.c_void_p)))
+ks = st2[:, 144:152].astype(np.float64)
+if ks.sum() > 0:
+    for k, nm in enumerate(["load, mu, l1 at the iterate", "sincos of the trial points", "trial RNEA + FK (9 x N)", "defect / box violation of the trials",
+                            "reduction of the 9 merits", "Armijo, update of z and lambda", "re-linearisation (tangent RNEA, Jacobian rows, defects)", "final report"]):
+        print("k_step %-52s %9.0f cycles" % (nm, ks[:, k].mean()))
+    print("k_step total %9.0f cycles" % ks.sum(axis=1).mean())
