@@ -163,13 +163,16 @@ def main():
         admm_mean = float(inf["qp_iters_total"].mean())
         flops_traj = canonical_flops(N, SQP_ITERS, admm_mean)
         k_avg_s = (k_ms / max(k_launches, 1)) * 1e-3
-        alg_bytes_launch = B * BYTES_PER_TRAJ / SQP_ITERS
+        # a large batch is solved as two half-batches on two streams (mpcmp.hip: solve_impl), so a launch of the dominant kernel
+        # covers B / launches_per_sqp problems; its duration is measured with HIP events on the stream it was launched on
+        launches_per_sqp = max(1, round(k_launches / float(args.steps * SQP_ITERS)))
+        problems_per_launch = B / launches_per_sqp
+        alg_bytes_launch = problems_per_launch * BYTES_PER_TRAJ / SQP_ITERS
         achieved_gbs = alg_bytes_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-        qp_flops_launch = B * (flops_traj / SQP_ITERS)
         traffic = None
         try:    # HBM bytes per k_qp2 launch from the committed rocprofv3 PMC passes (see profiles/r01_traffic.json)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("kernel") == kname and B == 1024:
+            if tj.get("kernel") == kname and tj.get("problems_per_launch") == problems_per_launch:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -186,12 +189,13 @@ def main():
                        "batch_per_gpu": B, "seed": scenarios.SEED, "margins": list(MARGINS)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches,
+                         "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "problems_per_launch": problems_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY.md 8d); see fp64"},
-            "fp64": {"achieved_tflops": qp_flops_launch / k_avg_s / 1e12 if k_avg_s > 0 else 0.0, "peak_tflops": FP64_PEAK_TFLOPS,
-                     "frac": (qp_flops_launch / k_avg_s / 1e12) / FP64_PEAK_TFLOPS if k_avg_s > 0 else 0.0,
-                     "canonical_gflop_per_traj": flops_traj / 1e9, "admm_iters_per_traj": admm_mean},
+            "fp64": {"achieved_tflops": (value / world) * flops_traj / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
+                     "frac": (value / world) * flops_traj / 1e12 / FP64_PEAK_TFLOPS,
+                     "canonical_gflop_per_traj": flops_traj / 1e9, "admm_iters_per_traj": admm_mean,
+                     "note": "whole solve on the wall clock, per GPU (canonical dense-equivalent flops, SURVEY.md 8d)"},
             "quality": {"status_ok_frac": float((inf["status"] == 0).mean()), "T_mean": float(inf["T"].mean()),
                         "defect_inf_median": float(np.median(inf["defect_inf"])),
                         "term_err_inf_median": float(np.median(inf["term_err_inf"])),
