@@ -438,7 +438,8 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
     w.model = ctx->d_model; w.ext_of_int = ctx->d_ext_of_int; w.entry_ptr = ctx->d_entry_ptr; w.terms = ctx->d_terms;
     TRY(dalloc(ctx, &w.z, B * n)); TRY(dalloc(ctx, &w.lam, B * mn)); TRY(dalloc(ctx, &w.ceq, B * ctx->meq));
     TRY(dalloc(ctx, &w.g, B * 8 * N)); TRY(dalloc(ctx, &w.Gk, B * N * 176)); TRY(dalloc(ctx, &w.p, B * n));
-    TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.perm, B)); TRY(dalloc(ctx, &w.okey, B)); TRY(dalloc(ctx, &w.qp_total, B));
+    TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.perm, B)); TRY(dalloc(ctx, &w.okey, B)); TRY(dalloc(ctx, &w.done, 2));
+    HIPTRY(hipMemset(w.done, 0, 2 * sizeof(int))); TRY(dalloc(ctx, &w.qp_total, B));
     TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, (size_t)B * MPCMP_DBG_WORDS));
     TRY(dalloc(ctx, &ctx->d_x0, B * 14)); TRY(dalloc(ctx, &ctx->d_xf, B * 14));
     TRY(dalloc(ctx, &ctx->d_wx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_wu, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
@@ -520,7 +521,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         const size_t b0 = h == 0 ? 0 : (size_t)Bh[0];
         WS v = w;
         v.x0 += 14 * b0; v.xf += 14 * b0; v.z += D::n * b0; v.lam += D::mn * b0; v.ceq += D::meq * b0; v.g += 8 * D::N * b0;
-        v.Gk += (size_t)D::N * 176 * b0; v.p += D::n * b0; v.y += D::mn * b0; v.qpit += b0; v.perm += b0; v.okey += b0;
+        v.Gk += (size_t)D::N * 176 * b0; v.p += D::n * b0; v.y += D::mn * b0; v.qpit += b0; v.perm += b0; v.okey += b0; v.done += h;
         v.qp_total += b0; v.status += b0; v.alpha += b0; v.dbg += (size_t)MPCMP_DBG_WORDS * b0;
         wh[h] = v;
         if (d_wx) { hx[h] = d_wx + 14 * D::N * b0; hu[h] = d_wu + 7 * D::N * b0; hT[h] = d_wT + b0; }
@@ -539,7 +540,6 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
             else hipLaunchKernelGGL(k_qp<NSEG>, dim3(Bh[h]), dim3(D::NT), l_qp, sh[h], ctx->cfg, wh[h]);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;
-            if (it + 1 < iters) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, sh[h], Bh[h], wh[h].qpit, wh[h].okey, wh[h].perm);
             hipLaunchKernelGGL(k_step<NSEG>, dim3(Bh[h]), dim3(D::NT), l_step, sh[h], ctx->cfg, ctx->model, wh[h], it == iters - 1 ? 1 : 0, it,
                                ox[h], ou[h], oT[h], oi[h]);
         }

@@ -37,6 +37,7 @@ struct WS {
     int *qpit;                // [B] iterations of the last QP
     int *perm;                // [B] launch order of the QP kernel: workgroup g solves problem perm[g] (longest expected first)
     int *okey;                // [B] ordering key: decayed maximum of the problem's previous QP iteration counts
+    int *done;                // [1] workgroups of the running step launch that have finished (the last one computes the next QP order)
     int *qp_total;            // [B]
     int *status;              // [B]
     double *alpha;            // [B]
@@ -711,6 +712,36 @@ struct StepLds {
                          oRed = oScr + LinLds<NSEG>::size + 9 * D::N * 14, size = oRed + D::NW * 12;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Launch order of the next QP kernel.  A QP runs between 25 and qp_iters ADMM iterations, a 1024-problem batch is only four
+// workgroups per CU, and workgroups are dispatched in index order: whatever starts last sets the tail of the launch.  The
+// iteration counts of a problem's previous QPs predict the next one well (correlation 0.9+), so problems are ordered
+// longest-first by counting sort.  A long QP that was predicted short and therefore starts last costs a whole QP of tail, so
+// the key is a decayed maximum over the history (key <- max(count, 0.9 key)) rather than the last count alone: replaying the
+// bench workload's counts (tools/sched_sim.py) gives 0.985 of the batch-order makespan for the last count, 0.944 for this
+// key, 0.904 for a perfect oracle.  The order only changes which workgroup solves which problem, never a result.
+__device__ __forceinline__ void order_body(int B, const int *qpit, int *okey, int *perm, int *hist /* [256] LDS */, int tid, int nt) {
+    int *base = hist + 128;
+    if (tid < 128) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < B; i += nt) {
+        const int decayed = (okey[i] * 29) >> 5, cnt = qpit[i];
+        const int key = cnt > decayed ? cnt : decayed;
+        okey[i] = key;
+        const int bucket = key >> 3;
+        atomicAdd(&hist[127 - (bucket > 127 ? 127 : bucket)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int k = 0; k < 128; k++) { base[k] = acc; acc += hist[k]; } }
+    __syncthreads();
+    for (int i = tid; i < B; i += nt) {
+        const int bucket = okey[i] >> 3;
+        perm[atomicAdd(&base[127 - (bucket > 127 ? 127 : bucket)], 1)] = i;
+    }
+}
+// (order_body runs in the last workgroup of k_step to finish: a separate one-workgroup launch would queue behind the other
+//  stream's QP launch, whose workgroups fill whole CUs, and stall its own stream's chain for hundreds of microseconds)
+
 template <int NSEG>
 __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_model mdl, WS ws, int final_iter, int sqp_it,
                                                         double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info) {
@@ -854,34 +885,18 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
         }
     }
     KSTAMP(7);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Launch order of the next QP kernel.  A QP runs between 25 and qp_iters ADMM iterations, a 1024-problem batch is only four
-// workgroups per CU, and workgroups are dispatched in index order: whatever starts last sets the tail of the launch.  The
-// iteration counts of a problem's previous QPs predict the next one well (correlation 0.9+), so problems are ordered
-// longest-first by counting sort.  A long QP that was predicted short and therefore starts last costs a whole QP of tail, so
-// the key is a decayed maximum over the history (key <- max(count, 0.9 key)) rather than the last count alone: replaying the
-// bench workload's counts (tools/sched_sim.py) gives 0.985 of the batch-order makespan for the last count, 0.944 for this
-// key, 0.904 for a perfect oracle.  The order only changes which workgroup solves which problem, never a result.
-__global__ __launch_bounds__(1024) void k_order(int B, const int *qpit, int *okey, int *perm) {
-    __shared__ int hist[128], base[128];
-    const int tid = threadIdx.x;
-    if (tid < 128) hist[tid] = 0;
+    // launch order of the next QP launch: computed by the workgroup that finishes last
     __syncthreads();
-    for (int i = tid; i < B; i += 1024) {
-        const int decayed = (okey[i] * 29) >> 5, cnt = qpit[i];
-        const int key = cnt > decayed ? cnt : decayed;
-        okey[i] = key;
-        const int bucket = key >> 3;
-        atomicAdd(&hist[127 - (bucket > 127 ? 127 : bucket)], 1);
+    int *flag = reinterpret_cast<int *>(lds);
+    if (tid == 0) {
+        __threadfence();
+        flag[0] = atomicAdd(ws.done, 1) == (int)gridDim.x - 1;
     }
     __syncthreads();
-    if (tid == 0) { int acc = 0; for (int k = 0; k < 128; k++) { base[k] = acc; acc += hist[k]; } }
-    __syncthreads();
-    for (int i = tid; i < B; i += 1024) {
-        const int bucket = okey[i] >> 3;
-        perm[atomicAdd(&base[127 - (bucket > 127 ? 127 : bucket)], 1)] = i;
+    if (flag[0]) {
+        __threadfence();
+        order_body((int)gridDim.x, ws.qpit, ws.okey, ws.perm, flag + 16, tid, NT);
+        if (tid == 0) *ws.done = 0;
     }
 }
 
