@@ -507,9 +507,9 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     // (QP -> order -> step), and a QP launch ends in a tail in which most CUs are idle (its problems run 25..700 ADMM
     // iterations, four workgroups per CU); with two independent chains in flight the tail of one half is filled by the other
     // half's next launch.  Replay of the bench workload's iteration counts: -5.8 % makespan.  Results are unaffected (problems
-    // are independent); graph capture and small batches stay on one stream.
+    // are independent); small batches stay on one stream.
     static const bool single_stream = std::getenv("MPCMP_SINGLE_STREAM") != nullptr;
-    const bool dual = !single_stream && !ctx->capturing && !only_qp && B >= 512;
+    const bool dual = !single_stream && !only_qp && B >= 512;      // (also under stream capture: the fork/join events carry the second stream into the graph)
     const int nhalf = dual ? 2 : 1;
     const int Bh[2] = {dual ? (B + 1) / 2 : B, dual ? B - (B + 1) / 2 : 0};
     hipStream_t sh[2] = {st, ctx->stream2};
