@@ -691,7 +691,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
     }
     if (isRow) ws.y[(size_t)b * D::mn + tid] = yg;
 #ifdef MPCMP_STAMPS
-    if (tid == 0) { for (int k = 0; k < 16; k++) ws.dbg[(size_t)b * 16 + k] = stamp_acc[k]; ws.dbg[(size_t)b * 16 + 15] = it; }
+    if (tid == 0) { for (int k = 0; k < 16; k++) ws.dbg[(size_t)b * MPCMP_DBG_WORDS + k] = stamp_acc[k]; ws.dbg[(size_t)b * MPCMP_DBG_WORDS + 15] = it; }
 #endif
     {
         int any = __syncthreads_or(status);
