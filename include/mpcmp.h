@@ -138,6 +138,21 @@ int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double 
 int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sol_x, const double *d_sol_u,
                               const double *d_sol_T, int n_pts, double *d_out, void *hip_stream);
 
+/* ---- jerk-limited, time-synchronised warm start (stands in for Ruckig, mpc_solver/motionPlanner.cpp:146-175) ----
+ * Per joint: S-curve velocity transition, cruise, S-curve transition (zero boundary accelerations as in
+ * motionPlanner.cpp:27-54); minimum time of the slowest joint, every other joint re-planned to exactly that duration.
+ * Velocity / acceleration limits are the context's margin-applied bounds (mpcmp_set_margins), jmax[7] = margin_jerk *
+ * max_jerk (motionPlanner.cpp:86-88).  Outputs in the layout mpcmp_solve_batch takes as warm start: warm_x [B][N][14],
+ * warm_u [B][N][7], warm_T [B] (x_guess / u_guess / p_guess, motionPlanner.cpp:158-174). */
+int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax,
+                                double *warm_x, double *warm_u, double *warm_T);
+int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *jmax,
+                                       double *d_warm_x, double *d_warm_u, double *d_warm_T, void *hip_stream);
+/* the same trajectory sampled uniformly, out [B][n_pts+1][22] = t, q(7), qd(7), qdd(7); T_out [B] (may be NULL):
+ * MotionPlanner::get_ruckig_trajectory<n_pts> (motionPlanner.hpp:73-96) without the torque column block */
+int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, int n_pts,
+                                double *out, double *T_out);
+
 /* ---- scenario helpers of the robot wrapper (host side, as in the reference; never called by the batched solve) ---- */
 /* World-aligned 6x7 Jacobian of the tool frame, rows [linear(3); angular(3)], row-major (J = blockdiag(R,R) * J_local,
  * robot_utils/pandaWrapper.cpp:70-75,97-101); optional tool position p[3] and rotation R[9] (row-major). */

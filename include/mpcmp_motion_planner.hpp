@@ -8,8 +8,9 @@
 //
 // With Eigen on the include path the vector/matrix arguments are Eigen types exactly as in the reference;
 // without it (this image has no Eigen) a minimal column-major fixed-size matrix with the same element access
-// stands in.  Differences that cannot be hidden: Ruckig is replaced by the built-in initialiser
-// (get_ruckig_trajectory returns that initial guess), `mpc` (the polympc object) does not exist.
+// stands in.  Differences that cannot be hidden: Ruckig is replaced by the library's own jerk-limited, time-synchronised
+// generator (same problem statement; it reproduces the reference's stored Ruckig trajectory), `mpc` (the polympc object)
+// does not exist.
 #pragma once
 #include <array>
 #include <cmath>
@@ -211,14 +212,18 @@ class MotionPlanner {
         warm_T_ = final_time; have_warm_ = true;
     }
 
-    // motionPlanner.cpp:177-208.  true: built-in initialiser (stand-in for Ruckig); false: previous solution /
-    // warm_start() guess
+    // motionPlanner.cpp:177-208.  true: jerk-limited, time-synchronised trajectory between the two states (what the
+    // reference gets from Ruckig, motionPlanner.cpp:146-175); false: previous solution / warm_start() guess
     void solve_trajectory(bool use_ruckig_as_warm_start) {
         const bool use_guess = !use_ruckig_as_warm_start && have_warm_;
         if (!use_guess) {
             guess_x_.assign((size_t)14 * N_, 0.0); guess_u_.assign((size_t)7 * N_, 0.0);
-            chk(mpcmp_warm_start_batch(ctx_, 1, current_state.data(), target_state.data(), guess_x_.data(), guess_u_.data(), &guess_T_));
-        } else { guess_x_ = warm_x_; guess_u_ = warm_u_; guess_T_ = warm_T_; }
+            double jm[7];
+            jerk_limits(jm);
+            chk(mpcmp_warm_start_jerk_batch(ctx_, 1, current_state.data(), target_state.data(), jm, guess_x_.data(), guess_u_.data(), &guess_T_));
+            guess_is_profile_ = true;
+            for (int r = 0; r < 14; r++) { guess_x0_[r] = current_state(r); guess_xf_[r] = target_state(r); }
+        } else { guess_x_ = warm_x_; guess_u_ = warm_u_; guess_T_ = warm_T_; guess_is_profile_ = false; }
         chk(mpcmp_solve_batch(ctx_, 1, current_state.data(), target_state.data(), guess_x_.data(), guess_u_.data(), &guess_T_,
                               sol_x_.data(), sol_u_.data(), &sol_T_, &last_info));
         // "Fix initial and final point at correct place" (motionPlanner.cpp:199-207)
@@ -240,13 +245,31 @@ class MotionPlanner {
         chk(mpcmp_sample_batch(ctx_, 1, sol_x_.data(), sol_u_.data(), &sol_T_, NP, out.data()));
         unpack<NP>(out, time, position_trajectory, velocity_trajectory, acceleration_trajectory, torque_trajectory);
     }
-    // motionPlanner.hpp:73-96 — the initial guess handed to the solver, resampled like the Ruckig trajectory
+    // motionPlanner.hpp:73-96 — the jerk-limited trajectory of the last solve_trajectory(true) sampled uniformly, torques by
+    // RNEA (motionPlanner.hpp:92); after a solve from another guess: that guess, resampled like the MPC solution
     template <const int NP>
     void get_ruckig_trajectory(mpcmp_shim::Mat<1, NP + 1> &time, mpcmp_shim::Mat<7, NP + 1> &position_trajectory,
                                mpcmp_shim::Mat<7, NP + 1> &velocity_trajectory, mpcmp_shim::Mat<7, NP + 1> &acceleration_trajectory,
                                mpcmp_shim::Mat<7, NP + 1> &torque_trajectory) {
         std::vector<double> out((size_t)(NP + 1) * 29);
-        chk(mpcmp_sample_batch(ctx_, 1, guess_x_.data(), guess_u_.data(), &guess_T_, NP, out.data()));
+        if (guess_is_profile_) {
+            std::vector<double> tr((size_t)(NP + 1) * 22), q((size_t)(NP + 1) * 7), v(q.size()), a(q.size()), tau(q.size());
+            double jm[7];
+            jerk_limits(jm);
+            chk(mpcmp_jerk_trajectory_batch(ctx_, 1, guess_x0_, guess_xf_, jm, NP, tr.data(), nullptr));
+            for (int i = 0; i <= NP; i++)
+                for (int j = 0; j < 7; j++) { q[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 1 + j]; v[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 8 + j]; a[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 15 + j]; }
+            chk(mpcmp_rnea_batch(ctx_, NP + 1, q.data(), v.data(), a.data(), tau.data()));
+            for (int i = 0; i <= NP; i++) {
+                out[(size_t)i * 29] = tr[(size_t)i * 22];
+                for (int j = 0; j < 7; j++) {
+                    out[(size_t)i * 29 + 1 + j] = q[(size_t)i * 7 + j]; out[(size_t)i * 29 + 8 + j] = v[(size_t)i * 7 + j];
+                    out[(size_t)i * 29 + 15 + j] = a[(size_t)i * 7 + j]; out[(size_t)i * 29 + 22 + j] = tau[(size_t)i * 7 + j];
+                }
+            }
+        } else {
+            chk(mpcmp_sample_batch(ctx_, 1, guess_x_.data(), guess_u_.data(), &guess_T_, NP, out.data()));
+        }
         unpack<NP>(out, time, position_trajectory, velocity_trajectory, acceleration_trajectory, torque_trajectory);
     }
     // motionPlanner.hpp:118-128, including its clamp: for time >= T the normalised time is set to T (not 1)
@@ -291,14 +314,16 @@ class MotionPlanner {
     // then one 162-number row per problem appended to `path` in the reference's layout (benchmark.cpp:164-194):
     //   guess min(28) max(28) | MPC min(28) max(28) | guess terminal error(14) | MPC terminal error(14) |
     //   guess flags(4: jerk, linear vel, angular vel, collision) | MPC flags(4) | target(14)
-    // ("guess" = the built-in initial trajectory standing in for Ruckig).
+    // ("guess" = the jerk-limited trajectory standing in for Ruckig, in the node form handed to the solver).
     void benchmark_batch(int B, const double *xf, const std::string &path, int n_pts = 200) {
         const size_t N = (size_t)N_;
         std::vector<double> x0((size_t)B * 14), gx(B * 14 * N), gu(B * 7 * N), gT(B), sx(B * 14 * N), su(B * 7 * N), sT(B);
         std::vector<double> sg((size_t)B * 74), sm((size_t)B * 74);
         std::vector<mpcmp_info> info(B);
         for (int b = 0; b < B; b++) for (int r = 0; r < 14; r++) x0[(size_t)b * 14 + r] = current_state(r);
-        chk(mpcmp_warm_start_batch(ctx_, B, x0.data(), xf, gx.data(), gu.data(), gT.data()));
+        double jm[7];
+        jerk_limits(jm);
+        chk(mpcmp_warm_start_jerk_batch(ctx_, B, x0.data(), xf, jm, gx.data(), gu.data(), gT.data()));     // benchmark.cpp:46-47
         chk(mpcmp_solve_batch(ctx_, B, x0.data(), xf, gx.data(), gu.data(), gT.data(), sx.data(), su.data(), sT.data(), info.data()));
         chk(mpcmp_traj_stats_batch(ctx_, B, gx.data(), gu.data(), gT.data(), xf, n_pts, sg.data()));
         chk(mpcmp_traj_stats_batch(ctx_, B, sx.data(), su.data(), sT.data(), xf, n_pts, sm.data()));
@@ -322,6 +347,9 @@ class MotionPlanner {
     int N_ = 0, max_batch_ = 0;
     std::vector<double> sol_x_, sol_u_, warm_x_, warm_u_, guess_x_, guess_u_;
     double sol_T_ = 0, warm_T_ = 0, guess_T_ = 0;
+    bool guess_is_profile_ = false;                 // the last guess came from the jerk-limited generator
+    double guess_x0_[14] = {0}, guess_xf_[14] = {0};
+    void jerk_limits(double *jm) const { for (int j = 0; j < 7; j++) jm[j] = margin_jerk_ * robot.max_jerk(j); }   // motionPlanner.cpp:86-88
     bool have_warm_ = false;
     uint64_t rng_ = 20240001ull;
 

@@ -48,7 +48,8 @@ SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_default_limits
            "mpcmp_solve_batch_device", "mpcmp_warm_start_batch", "mpcmp_rnea_batch",
            "mpcmp_eval_constraints_batch", "mpcmp_qp_batch", "mpcmp_sample_batch", "mpcmp_sample_batch_device",
            "mpcmp_kernel_timing", "mpcmp_debug_stamps", "mpcmp_rh_init", "mpcmp_rh_run", "mpcmp_rh_get", "mpcmp_traj_stats_batch",
-           "mpcmp_tool_jacobian", "mpcmp_forward_velocities", "mpcmp_inverse_velocities", "mpcmp_inverse_kinematics"]
+           "mpcmp_tool_jacobian", "mpcmp_forward_velocities", "mpcmp_inverse_velocities", "mpcmp_inverse_kinematics",
+           "mpcmp_warm_start_jerk_batch", "mpcmp_warm_start_jerk_batch_device", "mpcmp_jerk_trajectory_batch"]
 
 
 def library_path():
@@ -59,7 +60,7 @@ def build_library(force=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
     deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "qp_kernel_v2.hpp", "rbd_device.hpp", "structure.hpp",
-                                           "kinematics_host.hpp")]
+                                           "kinematics_host.hpp", "jerk_device.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "mpcmp.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         subprocess.check_call(["make", "-C", src, "-B"], stdout=subprocess.DEVNULL)

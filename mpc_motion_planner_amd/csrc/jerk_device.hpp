@@ -1,0 +1,193 @@
+// jerk_device.hpp — jerk-limited, time-synchronised state-to-state trajectories for the 7 joints of one problem: what the
+// reference obtains from Ruckig as warm start and comparison trajectory (mpc_solver/motionPlanner.cpp:146-175 warm_start_RK,
+// motionPlanner.hpp:73-96 get_ruckig_trajectory; zero boundary accelerations, motionPlanner.cpp:27-54).
+//
+// Construction (the classical double-S profile): per joint an S-curve velocity transition v0 -> vc, a cruise at vc and an
+// S-curve transition vc -> vf.  Minimum time = cruise at the velocity limit when the distance allows it, else the cruise-free
+// profile whose two transitions cover the distance exactly (bisection on vc).  The common duration is that of the slowest
+// joint; every other joint gets the profile of exactly that duration, found by scanning the cruise velocity (and, if needed,
+// scaled-down acceleration/jerk limits) for a sign change of the duration error and bisecting.  On the reference's stored
+// Ruckig trajectory this reproduces Ruckig's duration to 6 digits and all seven joint trajectories (tests/test_oracle_ocp.py
+// for the CPU restatement, tests/test_gpu_parity.py for this code against it).
+//
+// One 64-thread workgroup per problem: lanes 0..6 plan one joint each, then all lanes sample.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpcmp {
+
+struct JerkLimits { double v[7], a[7], j[7]; };
+
+struct JProf {
+    double p0, v0, vc, vf, A, J, Ta, Tc, Td, T;
+    double c[6];
+    int quintic;
+};
+
+__device__ __forceinline__ void jk_trans_times(double va, double vb, double A, double J, double &T, double &Tj, double &apk) {
+    double dv = vb - va;
+    const double s = dv >= 0 ? 1.0 : -1.0;
+    dv = fabs(dv);
+    if (dv >= A * A / J) { Tj = A / J; T = Tj + dv / A; apk = s * A; }
+    else { Tj = sqrt(dv / J); T = 2.0 * Tj; apk = s * J * Tj; }
+}
+__device__ inline void jk_trans_eval(double va, double vb, double A, double J, double t, double &p, double &v, double &a) {
+    double T, Tj, apk;
+    jk_trans_times(va, vb, A, J, T, Tj, apk);
+    if (!(T > 0.0)) { p = 0.0; v = va; a = 0.0; return; }
+    if (t < 0.0) t = 0.0;
+    if (t > T) t = T;
+    const double j = apk >= 0 ? J : -J;
+    if (t <= Tj) { a = j * t; v = va + 0.5 * j * t * t; p = va * t + j * t * t * t / 6.0; return; }
+    const double p1 = va * Tj + j * Tj * Tj * Tj / 6.0, v1 = va + 0.5 * j * Tj * Tj, T2 = T - 2.0 * Tj;
+    if (t <= Tj + T2) { const double u = t - Tj; a = apk; v = v1 + apk * u; p = p1 + v1 * u + 0.5 * apk * u * u; return; }
+    const double p2 = p1 + v1 * T2 + 0.5 * apk * T2 * T2, v2 = v1 + apk * T2, u = t - Tj - T2;
+    a = apk - j * u; v = v2 + apk * u - 0.5 * j * u * u; p = p2 + v2 * u + 0.5 * apk * u * u - j * u * u * u / 6.0;
+}
+// distance of the two transitions v0 -> vc -> vf (an S-curve covers its mean velocity times its duration)
+__device__ __forceinline__ double jk_two_trans(double v0, double vc, double vf, double A, double J, double &Ta, double &Td) {
+    double Tj, apk;
+    jk_trans_times(v0, vc, A, J, Ta, Tj, apk);
+    jk_trans_times(vc, vf, A, J, Td, Tj, apk);
+    return 0.5 * (v0 + vc) * Ta + 0.5 * (vc + vf) * Td;
+}
+__device__ inline void jk_prof_min(double dp, double v0, double vf, double V, double A, double J, JProf &o) {
+    double Ta, Td, f;
+    o.v0 = v0; o.vf = vf; o.A = A; o.J = J; o.quintic = 0;
+    f = jk_two_trans(v0, V, vf, A, J, Ta, Td);
+    if (dp >= f) { o.vc = V; o.Ta = Ta; o.Td = Td; o.Tc = (dp - f) / V; o.T = Ta + Td + o.Tc; return; }
+    f = jk_two_trans(v0, -V, vf, A, J, Ta, Td);
+    if (dp <= f) { o.vc = -V; o.Ta = Ta; o.Td = Td; o.Tc = (dp - f) / (-V); o.T = Ta + Td + o.Tc; return; }
+    double lo = -V, hi = V;
+    for (int it = 0; it < 100; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (jk_two_trans(v0, mid, vf, A, J, Ta, Td) < dp) lo = mid; else hi = mid;
+    }
+    o.vc = 0.5 * (lo + hi);
+    jk_two_trans(v0, o.vc, vf, A, J, o.Ta, o.Td);
+    o.Tc = 0.0; o.T = o.Ta + o.Td;
+}
+// duration of the profile with cruise velocity vc, or -1 when it does not exist (negative cruise time)
+__device__ __forceinline__ double jk_dur_of(double dp, double v0, double vf, double vc, double A, double J) {
+    double Ta, Td;
+    if (fabs(vc) < 1e-9) return -1.0;
+    const double f = jk_two_trans(v0, vc, vf, A, J, Ta, Td), Tc = (dp - f) / vc;
+    return Tc < 0.0 ? -1.0 : Ta + Td + Tc;
+}
+__device__ inline bool jk_prof_sync(double dp, double v0, double vf, double V, double A, double J, double T, JProf &o) {
+    double lam = 1.0;
+    for (int li = 0; li < 60; li++, lam *= 0.85) {
+        const double Al = lam * A, Jl = lam * J;
+        double pv = 0.0, pd = 0.0;
+        bool have = false;
+        for (int i = 0; i <= 64; i++) {
+            const double vc = -V + (2.0 * V) * i / 64.0;
+            const double t = jk_dur_of(dp, v0, vf, vc, Al, Jl);
+            if (t < 0.0) { have = false; continue; }
+            const double dd = t - T;
+            if (have && ((pd <= 0.0) != (dd <= 0.0)) && !(pv < 0.0 && vc > 0.0)) {
+                double lo = pv, dlo = pd, hi = vc;
+                bool ok = true;
+                for (int it = 0; it < 80; it++) {
+                    const double mid = 0.5 * (lo + hi), tm = jk_dur_of(dp, v0, vf, mid, Al, Jl);
+                    if (tm < 0.0) { ok = false; break; }
+                    if (((tm - T) <= 0.0) == (dlo <= 0.0)) { lo = mid; dlo = tm - T; } else hi = mid;
+                }
+                if (ok) {
+                    o.v0 = v0; o.vf = vf; o.A = Al; o.J = Jl; o.quintic = 0; o.vc = 0.5 * (lo + hi);
+                    const double f = jk_two_trans(v0, o.vc, vf, Al, Jl, o.Ta, o.Td);
+                    o.Tc = (dp - f) / o.vc; o.T = o.Ta + o.Td + o.Tc;
+                    return true;
+                }
+            }
+            pv = vc; pd = dd; have = true;
+        }
+    }
+    return false;
+}
+__device__ inline void jk_prof_eval(const JProf &o, double t, double &p, double &v, double &a) {
+    if (o.quintic) {
+        const double *c = o.c;
+        p = c[0] + t * (c[1] + t * (c[2] + t * (c[3] + t * (c[4] + t * c[5]))));
+        v = c[1] + t * (2 * c[2] + t * (3 * c[3] + t * (4 * c[4] + t * 5 * c[5])));
+        a = 2 * c[2] + t * (6 * c[3] + t * (12 * c[4] + t * 20 * c[5]));
+        return;
+    }
+    double pa, q, va_, aa;
+    if (t <= o.Ta) { jk_trans_eval(o.v0, o.vc, o.A, o.J, t, q, v, a); p = o.p0 + q; return; }
+    jk_trans_eval(o.v0, o.vc, o.A, o.J, o.Ta, pa, va_, aa);
+    if (t <= o.Ta + o.Tc) { p = o.p0 + pa + o.vc * (t - o.Ta); v = o.vc; a = 0.0; return; }
+    jk_trans_eval(o.vc, o.vf, o.A, o.J, t - o.Ta - o.Tc, q, v, a);
+    p = o.p0 + pa + o.vc * o.Tc + q;
+}
+
+// plans the seven joints of problem b into pr[7] (LDS) and returns the common duration; call with all 64 lanes
+__device__ inline double jk_plan(const JerkLimits &lim, const double *x0, const double *xf, JProf *pr, double *sT) {
+    const int tid = threadIdx.x;
+    if (tid < 7) {
+        JProf o;
+        jk_prof_min(xf[tid] - x0[tid], x0[7 + tid], xf[7 + tid], lim.v[tid], lim.a[tid], lim.j[tid], o);
+        o.p0 = x0[tid];
+        pr[tid] = o;
+    }
+    __syncthreads();
+    if (tid == 0) { double T = 0.0; for (int j = 0; j < 7; j++) T = pr[j].T > T ? pr[j].T : T; *sT = T; }
+    __syncthreads();
+    const double T = *sT;
+    if (tid < 7 && pr[tid].T < T * (1.0 - 1e-12)) {
+        JProf s;
+        if (jk_prof_sync(xf[tid] - x0[tid], x0[7 + tid], xf[7 + tid], lim.v[tid], lim.a[tid], lim.j[tid], T, s)) { s.p0 = x0[tid]; pr[tid] = s; }
+        else {      // fallback: quintic of the common duration (zero boundary accelerations)
+            const double h = xf[tid] - x0[tid], v0 = x0[7 + tid], v1 = xf[7 + tid], T2 = T * T, T3 = T2 * T;
+            JProf &q = pr[tid];
+            q.quintic = 1;
+            q.c[0] = x0[tid]; q.c[1] = v0; q.c[2] = 0.0;
+            q.c[3] = (20.0 * h - (8.0 * v1 + 12.0 * v0) * T) / (2.0 * T3);
+            q.c[4] = (-30.0 * h + (14.0 * v1 + 16.0 * v0) * T) / (2.0 * T3 * T);
+            q.c[5] = (12.0 * h - 6.0 * (v1 + v0) * T) / (2.0 * T3 * T2);
+            q.T = T;
+        }
+    }
+    __syncthreads();
+    return T;
+}
+
+// warm start of the OCP: node states [N][14], node controls [N][7], duration (motionPlanner.cpp:151-174, 202-203)
+__global__ __launch_bounds__(64) void k_warm_jerk(int nseg, JerkLimits lim, const double *x0, const double *xf, double *wx, double *wu, double *wT) {
+    __shared__ JProf pr[7];
+    __shared__ double sT;
+    const int b = blockIdx.x, tid = threadIdx.x, N = 3 * nseg + 1;
+    const double *a0 = x0 + 14 * (size_t)b, *af = xf + 14 * (size_t)b;
+    const double T = jk_plan(lim, a0, af, pr, &sT);
+    for (int t = tid; t < N * 7; t += 64) {
+        const int k = t / 7, j = t % 7, s = k / 3, i = k % 3;
+        const double xi = (i == 0) ? -1.0 : (i == 1 ? -0.5 : 0.5);                    // ascending cubic CGL nodes of segment s
+        const double tau = (k == N - 1) ? 1.0 : (s + 0.5 * (xi + 1.0)) / nseg;
+        double q, v, a;
+        jk_prof_eval(pr[j], tau * T, q, v, a);
+        if (k == 0) { q = a0[j]; v = a0[7 + j]; }
+        if (k == N - 1) { q = af[j]; v = af[7 + j]; }
+        wx[((size_t)b * N + k) * 14 + j] = q; wx[((size_t)b * N + k) * 14 + 7 + j] = v; wu[((size_t)b * N + k) * 7 + j] = a;
+    }
+    if (tid == 0) wT[b] = T;
+}
+
+// uniform samples [n_pts+1][22] = t, q(7), v(7), a(7) of the same trajectory (get_ruckig_trajectory, motionPlanner.hpp:73-96)
+__global__ __launch_bounds__(64) void k_jerk_traj(JerkLimits lim, const double *x0, const double *xf, int n_pts, double *out, double *Tout) {
+    __shared__ JProf pr[7];
+    __shared__ double sT;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double T = jk_plan(lim, x0 + 14 * (size_t)b, xf + 14 * (size_t)b, pr, &sT);
+    double *o = out + (size_t)b * (n_pts + 1) * 22;
+    for (int t = tid; t < (n_pts + 1) * 7; t += 64) {
+        const int i = t / 7, j = t % 7;
+        const double tt = T * i / n_pts;
+        double q, v, a;
+        jk_prof_eval(pr[j], tt, q, v, a);
+        o[(size_t)i * 22 + 1 + j] = q; o[(size_t)i * 22 + 8 + j] = v; o[(size_t)i * 22 + 15 + j] = a;
+        if (j == 0) o[(size_t)i * 22] = tt;
+    }
+    if (tid == 0 && Tout) Tout[b] = T;
+}
+
+}  // namespace mpcmp

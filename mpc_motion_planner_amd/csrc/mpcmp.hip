@@ -16,6 +16,7 @@
 #include "solver_kernels.hpp"
 #include "qp_kernel_v2.hpp"
 #include "kinematics_host.hpp"
+#include "jerk_device.hpp"
 
 using namespace mpcmp;
 
@@ -629,6 +630,71 @@ extern "C" int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, c
     return MPCMP_OK;
 }
 
+struct TmpBuf {
+    std::vector<void *> p;
+    ~TmpBuf() { for (void *q : p) (void)hipFree(q); }
+    template <typename T> T *get(size_t count) { void *q = nullptr; if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T *)q; }
+};
+
+// ---- jerk-limited, time-synchronised warm start / comparison trajectory (stands in for Ruckig) ----
+static int jerk_limits(mpcmp_ctx *ctx, const double *jmax, JerkLimits &lim) {
+    for (int j = 0; j < 7; j++) {
+        lim.v[j] = ctx->cfg.ubx[7 + j]; lim.a[j] = ctx->cfg.ubu[j]; lim.j[j] = jmax[j];
+        if (!(lim.v[j] > 0.0) || !(lim.a[j] > 0.0) || !(lim.j[j] > 0.0)) { ctx->err = "velocity, acceleration and jerk limits must be positive"; return MPCMP_EINVAL; }
+    }
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *jmax,
+                                                  double *d_wx, double *d_wu, double *d_wT, void *hip_stream) {
+    if (!ctx || !d_x0 || !d_xf || !jmax || !d_wx || !d_wu || !d_wT || B < 1) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    JerkLimits lim;
+    if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
+    hipLaunchKernelGGL(k_warm_jerk, dim3(B), dim3(64), 0, hip_stream ? (hipStream_t)hip_stream : ctx->stream, ctx->nseg, lim, d_x0, d_xf, d_wx, d_wu, d_wT);
+    HIPCHK(ctx, hipGetLastError());
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax,
+                                           double *wx, double *wu, double *wT) {
+    if (!ctx || !x0 || !xf || !jmax || !wx || !wu || !wT || B < 1) return MPCMP_EINVAL;
+    if (B > ctx->max_batch) return MPCMP_ETOOBIG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = ctx->N;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    if (int rc = mpcmp_warm_start_jerk_batch_device(ctx, B, ctx->d_x0, ctx->d_xf, jmax, ctx->d_wx, ctx->d_wu, ctx->d_wT, st)) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(wx, ctx->d_wx, sizeof(double) * 14 * N * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(wu, ctx->d_wu, sizeof(double) * 7 * N * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(wT, ctx->d_wT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, int n_pts,
+                                           double *out, double *T_out) {
+    if (!ctx || !x0 || !xf || !jmax || !out || B < 1 || n_pts < 1) return MPCMP_EINVAL;
+    if (B > ctx->max_batch) return MPCMP_ETOOBIG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    JerkLimits lim;
+    if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
+    TmpBuf tb;
+    const size_t cnt = (size_t)B * (n_pts + 1) * 22;
+    double *dout = tb.get<double>(cnt);
+    if (!dout) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_jerk_traj, dim3(B), dim3(64), 0, st, lim, ctx->d_x0, ctx->d_xf, n_pts, dout, ctx->d_wT);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, dout, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
+    if (T_out) HIPCHK(ctx, hipMemcpyAsync(T_out, ctx->d_wT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
 extern "C" int mpcmp_qp_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *xs,
                               const double *us, const double *T, double *p, double *y, int *iters) {
     if (!ctx || !x0 || !xf || !xs || !us || !T || !p || !y || B < 1) return MPCMP_EINVAL;
@@ -653,12 +719,6 @@ extern "C" int mpcmp_qp_batch(mpcmp_ctx *ctx, int B, const double *x0, const dou
 
 // ------------------------------------------------------------------------------------------------
 // leaf kernels
-struct TmpBuf {
-    std::vector<void *> p;
-    ~TmpBuf() { for (void *q : p) (void)hipFree(q); }
-    template <typename T> T *get(size_t count) { void *q = nullptr; if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T *)q; }
-};
-
 extern "C" int mpcmp_rnea_batch(mpcmp_ctx *ctx, int n, const double *q, const double *qd, const double *qdd, double *tau) {
     if (!ctx || n < 1 || !q || !qd || !qdd || !tau) return MPCMP_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));

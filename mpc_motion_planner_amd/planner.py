@@ -63,6 +63,20 @@ class Solver:
         check(lib().mpcmp_warm_start_batch(self._ctx, B, dp(x0), dp(xf), dp(wx), dp(wu), dp(wT)), self._ctx)
         return wx, wu, wT
 
+    def warm_start_jerk(self, x0, xf, jmax):
+        """Jerk-limited, time-synchronised warm start (stands in for Ruckig): (warm_x [B][N][14], warm_u [B][N][7], warm_T [B])."""
+        x0, xf, jmax = f64(x0), f64(xf), f64(jmax); B = x0.shape[0]
+        wx, wu, wT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
+        check(lib().mpcmp_warm_start_jerk_batch(self._ctx, B, dp(x0), dp(xf), dp(jmax), dp(wx), dp(wu), dp(wT)), self._ctx)
+        return wx, wu, wT
+
+    def jerk_trajectory(self, x0, xf, jmax, n_pts=200):
+        """The same trajectory sampled uniformly: out [B][n_pts+1][22] = t, q, qd, qdd, and the durations [B]."""
+        x0, xf, jmax = f64(x0), f64(xf), f64(jmax); B = x0.shape[0]
+        out, T = np.zeros((B, n_pts + 1, 22)), np.zeros(B)
+        check(lib().mpcmp_jerk_trajectory_batch(self._ctx, B, dp(x0), dp(xf), dp(jmax), int(n_pts), dp(out), dp(T)), self._ctx)
+        return out, T
+
     def rnea(self, q, qd, qdd):
         q, qd, qdd = f64(q), f64(qd), f64(qdd); tau = np.zeros_like(q)
         check(lib().mpcmp_rnea_batch(self._ctx, q.shape[0], dp(q), dp(qd), dp(qdd), dp(tau)), self._ctx)

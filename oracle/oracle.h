@@ -9,6 +9,8 @@
  *   - rigid-body layer (RNEA / FK / Jacobian):  PINNED by the reference's stored Pinocchio
  *     outputs (tests/golden/kat_rnea.csv, kat_fk_link8.csv, kat_jac.json).
  *   - RNEA derivatives / mass matrix: pinned indirectly (finite differences of the pinned RNEA).
+ *   - jerk-limited warm start (jerk.c, restating the Ruckig call): PINNED by the reference's stored Ruckig trajectory
+ *     (tests/golden/gold_traj.json: duration to 6 digits, all seven joints to the stored precision).
  *   - collocation / SQP / box-ADMM layer: "PARITY UNPINNED" at digit level. The arithmetic of
  *     that layer lives in polympc (https://gitlab.epfl.ch/listov/polympc.git, branch
  *     collocation_fix_jw, commit not recoverable), which is an empty submodule in the
@@ -106,6 +108,14 @@ void orc_diff_matrix(double *D /*4x4*/);         /* cubic CGL differentiation ma
 /* ---- warm start stand-in for Ruckig (motionPlanner.cpp:146-175) ---- */
 void orc_warm_start(const orc_config *c, const double *amax_used, const double *x0, const double *xf,
                     double *xg, double *ug, double *Tg);
+
+/* ---- jerk-limited, time-synchronised warm start (jerk.c): restatement of what Ruckig provides at motionPlanner.cpp:146-175;
+ *      pinned by the stored Ruckig trajectory (tests/golden/gold_traj.json) ---- */
+void orc_warm_start_jerk(int num_seg, const double *vmax, const double *amax, const double *jmax, const double *x0, const double *xf,
+                         double *xg, double *ug, double *Tg);
+/* out (n_pts+1) x 22 = t, q(7), v(7), a(7): get_ruckig_trajectory (motionPlanner.hpp:73-96) */
+void orc_jerk_trajectory(const double *vmax, const double *amax, const double *jmax, const double *x0, const double *xf, int n_pts,
+                         double *out, double *T_out);
 
 /* ---- the hot path: one OCP ---- */
 /* z layout: xs[N][14], us[N][7], T.  lam (optional, size m_eq+m_in+n) receives final multipliers */

