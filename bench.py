@@ -36,15 +36,19 @@ def canonical_flops(N, sqp_iters, admm_iters_total):
     return sqp_iters * (N * f_rb + f_fact) + admm_iters_total * f_iter
 
 
-def cpu_baseline(x0, xf, sample, threads):
+def cpu_baseline(x0, xf, sample, threads, warm):
     """Time the CPU oracle (same algorithm) on a bounded sample of the same workload. Checker/baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py as o
     cfg = o.default_config(NUM_SEG, SQP_ITERS, margins=MARGINS)
     N = 3 * NUM_SEG + 1
     wx = np.zeros((sample, N, 14)); wu = np.zeros((sample, N, 7)); wT = np.zeros(sample)
-    for b in range(sample):
-        wx[b], wu[b], wT[b] = o.warm_start(cfg, x0[b], xf[b])
+    lim = o.default_limits()
+    for b in range(sample):    # (warm start outside the timed part: microseconds per problem, single thread)
+        if warm == "jerk":
+            wx[b], wu[b], wT[b] = o.warm_start_jerk(NUM_SEG, MARGINS[1] * lim["vmax"], MARGINS[2] * lim["amax"], MARGINS[4] * lim["jmax"], x0[b], xf[b])
+        else:
+            wx[b], wu[b], wT[b] = o.warm_start(cfg, x0[b], xf[b])
     t0 = time.perf_counter()
     _, _, T, info = o.solve_batch(cfg, x0[:sample], xf[:sample], wx, wu, wT, threads=threads)
     dt = time.perf_counter() - t0
@@ -83,6 +87,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--warm", choices=["jerk", "quintic"], default="jerk",
+                    help="initial guess of every OCP: jerk = the jerk-limited time-synchronised trajectory the reference gets from Ruckig "
+                         "(solve_trajectory(true), motionPlanner.cpp:146-175), computed on the GPU inside the timed step; quintic = k_init's fallback")
     ap.add_argument("--workload", choices=["batch", "rh", "shipped"], default="batch",
                     help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon, extra line; "
                          "shipped: the reference-as-shipped solver depth (N=19, 2 SQP iterations; SURVEY.md 8d), extra line")
@@ -127,10 +134,18 @@ def main():
     info = torch.zeros(B, 64, dtype=torch.uint8, device=dev)               # mpcmp_info records (64 B each)
     gathered = [torch.zeros_like(sol) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream(dev)
+    jmax = MARGINS[4] * M.default_limits()["jmax"]                          # motionPlanner.cpp:86-88
+    warm_x = torch.zeros(B, N, 14, dtype=torch.float64, device=dev); warm_u = torch.zeros(B, N, 7, dtype=torch.float64, device=dev)
+    warm_T = torch.zeros(B, dtype=torch.float64, device=dev)
 
     def step():
+        warm = (0, 0, 0)
+        if args.warm == "jerk":
+            solver.warm_start_jerk_device(B, x0.data_ptr(), xf.data_ptr(), jmax, warm_x.data_ptr(), warm_u.data_ptr(), warm_T.data_ptr(),
+                                          stream=stream.cuda_stream)
+            warm = (warm_x.data_ptr(), warm_u.data_ptr(), warm_T.data_ptr())
         solver.solve_device(B, x0.data_ptr(), xf.data_ptr(), sol_x.data_ptr(), sol_u.data_ptr(), sol_T.data_ptr(),
-                            info.data_ptr(), stream=stream.cuda_stream)
+                            info.data_ptr(), warm=warm, stream=stream.cuda_stream)
         if world > 1:
             torch.cat([sol_x.reshape(B, -1), sol_u.reshape(B, -1), sol_T[:, None]], dim=1, out=sol)
             dist.gather(sol, gathered, dst=0)
@@ -183,8 +198,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d-problem random batch per GPU, 7-DoF Panda, N=%d Chebyshev nodes (cubic x %d segments), "
-                                   "%d SQP iters, <=700 ADMM iters, built-in warm start (%s)"
-                                   % (B, N, NUM_SEG, SQP_ITERS, "BASELINE.json configs[1]" if args.workload == "batch"
+                                   "%d SQP iters, <=700 ADMM iters, %s warm start computed in the timed step (%s)"
+                                   % (B, N, NUM_SEG, SQP_ITERS, "jerk-limited (Ruckig-equivalent)" if args.warm == "jerk" else "quintic",
+                                      "BASELINE.json configs[1]" if args.workload == "batch"
                                       else "reference as shipped: robot_ocp.hpp:32, motionPlanner.cpp:15"),
                        "batch_per_gpu": B, "seed": scenarios.SEED, "margins": list(MARGINS)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -203,10 +219,12 @@ def main():
         }
         if world == 1:
             # PCIe-inclusive rate through the host-buffer entry point (reported, never `value`)
-            t1 = time.perf_counter(); solver.solve(x0_h, xf_h); out["host_buffers_traj_per_s"] = B / (time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            solver.solve(x0_h, xf_h, solver.warm_start_jerk(x0_h, xf_h, jmax) if args.warm == "jerk" else None)
+            out["host_buffers_traj_per_s"] = B / (time.perf_counter() - t1)
             if not args.no_cpu_baseline:
                 threads = min(os.cpu_count() or 1, 16)
-                cb, T_cpu = cpu_baseline(x0_h, xf_h, min(args.cpu_sample, B), threads)
+                cb, T_cpu = cpu_baseline(x0_h, xf_h, min(args.cpu_sample, B), threads, args.warm)
                 out["cpu_baseline"] = cb
                 out["quality"]["max_rel_dT_vs_cpu_sample"] = float(np.max(np.abs(inf["T"][:len(T_cpu)] - T_cpu) / T_cpu))
         print(json.dumps(out))

@@ -70,6 +70,13 @@ class Solver:
         check(lib().mpcmp_warm_start_jerk_batch(self._ctx, B, dp(x0), dp(xf), dp(jmax), dp(wx), dp(wu), dp(wT)), self._ctx)
         return wx, wu, wT
 
+    def warm_start_jerk_device(self, B, x0, xf, jmax, warm_x, warm_u, warm_T, stream=0):
+        """Device-pointer form: writes the warm start where solve_device(..., warm=(warm_x, warm_u, warm_T)) reads it."""
+        vp = C.c_void_p
+        jmax = f64(jmax)
+        check(lib().mpcmp_warm_start_jerk_batch_device(self._ctx, int(B), vp(x0), vp(xf), dp(jmax), vp(warm_x), vp(warm_u), vp(warm_T),
+                                                       vp(stream or None)), self._ctx)
+
     def jerk_trajectory(self, x0, xf, jmax, n_pts=200):
         """The same trajectory sampled uniformly: out [B][n_pts+1][22] = t, q, qd, qdd, and the durations [B]."""
         x0, xf, jmax = f64(x0), f64(xf), f64(jmax); B = x0.shape[0]
