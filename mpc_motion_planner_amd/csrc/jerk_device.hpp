@@ -10,7 +10,8 @@
 // Ruckig trajectory this reproduces Ruckig's duration to 6 digits and all seven joint trajectories (tests/test_oracle_ocp.py
 // for the CPU restatement, tests/test_gpu_parity.py for this code against it).
 //
-// One 64-thread workgroup per problem: lanes 0..6 plan one joint each, then all lanes sample.
+// One 64-thread workgroup (one wave) per problem: lanes 0..6 find the minimum-time profile of one joint each, the wave then
+// re-plans the faster joints to the common duration one after the other (64 scan points at a time), then all lanes sample.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -74,33 +75,34 @@ __device__ __forceinline__ double jk_dur_of(double dp, double v0, double vf, dou
     const double f = jk_two_trans(v0, vc, vf, A, J, Ta, Td), Tc = (dp - f) / vc;
     return Tc < 0.0 ? -1.0 : Ta + Td + Tc;
 }
+// Profile of duration T (> the joint's minimum time), computed by the whole 64-lane wave: lane i tests the bracket between the
+// grid points i and i+1 of the cruise-velocity scan, the first bracket (in scan order, as a serial scan would find it) is
+// bisected.  Same result as the serial restatement in oracle/jerk.c.
 __device__ inline bool jk_prof_sync(double dp, double v0, double vf, double V, double A, double J, double T, JProf &o) {
+    const int lane = threadIdx.x & 63;
     double lam = 1.0;
     for (int li = 0; li < 60; li++, lam *= 0.85) {
         const double Al = lam * A, Jl = lam * J;
-        double pv = 0.0, pd = 0.0;
-        bool have = false;
-        for (int i = 0; i <= 64; i++) {
-            const double vc = -V + (2.0 * V) * i / 64.0;
-            const double t = jk_dur_of(dp, v0, vf, vc, Al, Jl);
-            if (t < 0.0) { have = false; continue; }
-            const double dd = t - T;
-            if (have && ((pd <= 0.0) != (dd <= 0.0)) && !(pv < 0.0 && vc > 0.0)) {
-                double lo = pv, dlo = pd, hi = vc;
-                bool ok = true;
-                for (int it = 0; it < 80; it++) {
-                    const double mid = 0.5 * (lo + hi), tm = jk_dur_of(dp, v0, vf, mid, Al, Jl);
-                    if (tm < 0.0) { ok = false; break; }
-                    if (((tm - T) <= 0.0) == (dlo <= 0.0)) { lo = mid; dlo = tm - T; } else hi = mid;
-                }
-                if (ok) {
-                    o.v0 = v0; o.vf = vf; o.A = Al; o.J = Jl; o.quintic = 0; o.vc = 0.5 * (lo + hi);
-                    const double f = jk_two_trans(v0, o.vc, vf, Al, Jl, o.Ta, o.Td);
-                    o.Tc = (dp - f) / o.vc; o.T = o.Ta + o.Td + o.Tc;
-                    return true;
-                }
+        const double va = -V + (2.0 * V) * lane / 64.0, vb = -V + (2.0 * V) * (lane + 1) / 64.0;
+        const double ta = jk_dur_of(dp, v0, vf, va, Al, Jl), tb = jk_dur_of(dp, v0, vf, vb, Al, Jl);
+        const bool cand = ta >= 0.0 && tb >= 0.0 && (((ta - T) <= 0.0) != ((tb - T) <= 0.0)) && !(va < 0.0 && vb > 0.0);
+        unsigned long long mask = __ballot(cand);
+        while (mask) {
+            const int first = __ffsll((long long)mask) - 1;
+            mask &= ~(1ull << first);
+            double lo = __shfl(va, first), dlo = __shfl(ta, first) - T, hi = __shfl(vb, first);
+            bool ok = true;
+            for (int it = 0; it < 80; it++) {
+                const double mid = 0.5 * (lo + hi), tm = jk_dur_of(dp, v0, vf, mid, Al, Jl);
+                if (tm < 0.0) { ok = false; break; }
+                if (((tm - T) <= 0.0) == (dlo <= 0.0)) { lo = mid; dlo = tm - T; } else hi = mid;
             }
-            pv = vc; pd = dd; have = true;
+            if (ok) {
+                o.v0 = v0; o.vf = vf; o.A = Al; o.J = Jl; o.quintic = 0; o.vc = 0.5 * (lo + hi);
+                const double f = jk_two_trans(v0, o.vc, vf, Al, Jl, o.Ta, o.Td);
+                o.Tc = (dp - f) / o.vc; o.T = o.Ta + o.Td + o.Tc;
+                return true;
+            }
         }
     }
     return false;
@@ -134,18 +136,23 @@ __device__ inline double jk_plan(const JerkLimits &lim, const double *x0, const 
     if (tid == 0) { double T = 0.0; for (int j = 0; j < 7; j++) T = pr[j].T > T ? pr[j].T : T; *sT = T; }
     __syncthreads();
     const double T = *sT;
-    if (tid < 7 && pr[tid].T < T * (1.0 - 1e-12)) {
+    for (int j = 0; j < 7; j++) {                      // (workgroup-uniform: the profiles live in LDS)
+        if (!(pr[j].T < T * (1.0 - 1e-12))) continue;
         JProf s;
-        if (jk_prof_sync(xf[tid] - x0[tid], x0[7 + tid], xf[7 + tid], lim.v[tid], lim.a[tid], lim.j[tid], T, s)) { s.p0 = x0[tid]; pr[tid] = s; }
-        else {      // fallback: quintic of the common duration (zero boundary accelerations)
-            const double h = xf[tid] - x0[tid], v0 = x0[7 + tid], v1 = xf[7 + tid], T2 = T * T, T3 = T2 * T;
-            JProf &q = pr[tid];
-            q.quintic = 1;
-            q.c[0] = x0[tid]; q.c[1] = v0; q.c[2] = 0.0;
-            q.c[3] = (20.0 * h - (8.0 * v1 + 12.0 * v0) * T) / (2.0 * T3);
-            q.c[4] = (-30.0 * h + (14.0 * v1 + 16.0 * v0) * T) / (2.0 * T3 * T);
-            q.c[5] = (12.0 * h - 6.0 * (v1 + v0) * T) / (2.0 * T3 * T2);
-            q.T = T;
+        const bool found = jk_prof_sync(xf[j] - x0[j], x0[7 + j], xf[7 + j], lim.v[j], lim.a[j], lim.j[j], T, s);
+        __syncthreads();
+        if (tid == 0) {
+            if (found) { s.p0 = x0[j]; pr[j] = s; }
+            else {      // fallback: quintic of the common duration (zero boundary accelerations)
+                const double h = xf[j] - x0[j], v0 = x0[7 + j], v1 = xf[7 + j], T2 = T * T, T3 = T2 * T;
+                JProf &q = pr[j];
+                q.quintic = 1;
+                q.c[0] = x0[j]; q.c[1] = v0; q.c[2] = 0.0;
+                q.c[3] = (20.0 * h - (8.0 * v1 + 12.0 * v0) * T) / (2.0 * T3);
+                q.c[4] = (-30.0 * h + (14.0 * v1 + 16.0 * v0) * T) / (2.0 * T3 * T);
+                q.c[5] = (12.0 * h - 6.0 * (v1 + v0) * T) / (2.0 * T3 * T2);
+                q.T = T;
+            }
         }
     }
     __syncthreads();
