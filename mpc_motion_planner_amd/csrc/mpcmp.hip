@@ -26,8 +26,8 @@ struct mpcmp_ctx {
     int N = 0, n = 0, meq = 0, m = 0, mn = 0;
     std::string err;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;              // second half-batch of a large solve (see solve_impl)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream_x[3] = {nullptr, nullptr, nullptr};   // further parts of a large solve (see solve_impl)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // device buffers
     mpcmp_model *d_model = nullptr;
     mpcmp_model model;             // host copy: passed by value to the kernels that run the rigid-body recursions
@@ -393,9 +393,8 @@ extern "C" int mpcmp_destroy(mpcmp_ctx *ctx) {
     for (void *p : ctx->allocs) (void)hipFree(p);
     for (auto &e : ctx->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (int k = 0; k < 3; k++) { if (ctx->stream_x[k]) (void)hipStreamDestroy(ctx->stream_x[k]); if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
     return MPCMP_OK;
 }
@@ -418,9 +417,11 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return fail(MPCMP_ERUNTIME); } } while (0)
     HIPTRY(hipSetDevice(device));
     HIPTRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPTRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (int k = 0; k < 3; k++) {
+        HIPTRY(hipStreamCreateWithFlags(&ctx->stream_x[k], hipStreamNonBlocking));
+        HIPTRY(hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
+    }
     HIPTRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     mpcmp_model mdl;
     if (model) mdl = *model; else mpcmp_default_model(&mdl);
     TRY(dalloc(ctx, &ctx->d_model, 1));
@@ -439,8 +440,8 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
     w.model = ctx->d_model; w.ext_of_int = ctx->d_ext_of_int; w.entry_ptr = ctx->d_entry_ptr; w.terms = ctx->d_terms;
     TRY(dalloc(ctx, &w.z, B * n)); TRY(dalloc(ctx, &w.lam, B * mn)); TRY(dalloc(ctx, &w.ceq, B * ctx->meq));
     TRY(dalloc(ctx, &w.g, B * 8 * N)); TRY(dalloc(ctx, &w.Gk, B * N * 176)); TRY(dalloc(ctx, &w.p, B * n));
-    TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.perm, B)); TRY(dalloc(ctx, &w.okey, B)); TRY(dalloc(ctx, &w.done, 2));
-    HIPTRY(hipMemset(w.done, 0, 2 * sizeof(int))); TRY(dalloc(ctx, &w.qp_total, B));
+    TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.perm, B)); TRY(dalloc(ctx, &w.okey, B)); TRY(dalloc(ctx, &w.done, 4));
+    HIPTRY(hipMemset(w.done, 0, 4 * sizeof(int))); TRY(dalloc(ctx, &w.qp_total, B));
     TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, (size_t)B * MPCMP_DBG_WORDS));
     TRY(dalloc(ctx, &ctx->d_x0, B * 14)); TRY(dalloc(ctx, &ctx->d_xf, B * 14));
     TRY(dalloc(ctx, &ctx->d_wx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_wu, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
@@ -510,16 +511,18 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     // half's next launch.  Replay of the bench workload's iteration counts: -5.8 % makespan.  Results are unaffected (problems
     // are independent); small batches stay on one stream.
     static const bool single_stream = std::getenv("MPCMP_SINGLE_STREAM") != nullptr;
-    const bool dual = !single_stream && !only_qp && B >= 512;      // (also under stream capture: the fork/join events carry the second stream into the graph)
-    const int nhalf = dual ? 2 : 1;
-    const int Bh[2] = {dual ? (B + 1) / 2 : B, dual ? B - (B + 1) / 2 : 0};
-    hipStream_t sh[2] = {st, ctx->stream2};
-    WS wh[2];
-    const double *hx[2] = {nullptr, nullptr}, *hu[2] = {nullptr, nullptr}, *hT[2] = {nullptr, nullptr};
-    double *ox[2], *ou[2], *oT[2];
-    mpcmp_info *oi[2];
+    static const int parts_env = std::getenv("MPCMP_STREAMS") ? std::atoi(std::getenv("MPCMP_STREAMS")) : 2;      // diagnostics: 1..4
+    const bool dual = !single_stream && !only_qp && B >= 512;      // (also under stream capture: the fork/join events carry the other streams into the graph)
+    const int nhalf = dual ? (parts_env < 1 ? 1 : (parts_env > 4 ? 4 : parts_env)) : 1;
+    int Bh[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
+    for (int h = 0, acc = 0; h < nhalf; h++) { Bh[h] = (B - acc + (nhalf - h) - 1) / (nhalf - h); boff[h] = acc; acc += Bh[h]; }
+    hipStream_t sh[4] = {st, ctx->stream_x[0], ctx->stream_x[1], ctx->stream_x[2]};
+    WS wh[4];
+    const double *hx[4] = {nullptr, nullptr, nullptr, nullptr}, *hu[4] = {nullptr, nullptr, nullptr, nullptr}, *hT[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *ox[4], *ou[4], *oT[4];
+    mpcmp_info *oi[4];
     for (int h = 0; h < nhalf; h++) {
-        const size_t b0 = h == 0 ? 0 : (size_t)Bh[0];
+        const size_t b0 = (size_t)boff[h];
         WS v = w;
         v.x0 += 14 * b0; v.xf += 14 * b0; v.z += D::n * b0; v.lam += D::mn * b0; v.ceq += D::meq * b0; v.g += 8 * D::N * b0;
         v.Gk += (size_t)D::N * 176 * b0; v.p += D::n * b0; v.y += D::mn * b0; v.qpit += b0; v.perm += b0; v.okey += b0; v.done += h;
@@ -529,7 +532,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         ox[h] = d_sx ? d_sx + 14 * D::N * b0 : nullptr; ou[h] = d_su ? d_su + 7 * D::N * b0 : nullptr;
         oT[h] = d_sT ? d_sT + b0 : nullptr; oi[h] = d_info ? d_info + b0 : nullptr;
     }
-    if (dual) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st)); HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0)); }
+    if (nhalf > 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st)); for (int h = 1; h < nhalf; h++) HIPCHK(ctx, hipStreamWaitEvent(sh[h], ctx->ev_fork, 0)); }
     for (int h = 0; h < nhalf; h++)
         hipLaunchKernelGGL(k_init<NSEG>, dim3(Bh[h]), dim3(D::NT), l_init, sh[h], ctx->cfg, ctx->model, wh[h], hx[h], hu[h], hT[h], reguess);
     const int iters = only_qp ? 1 : ctx->cfg.sqp_iters;
@@ -545,7 +548,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
                                ox[h], ou[h], oT[h], oi[h]);
         }
     }
-    if (dual) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2)); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0)); }
+    for (int h = 1; h < nhalf; h++) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[h - 1], sh[h])); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join[h - 1], 0)); }
     HIPCHK(ctx, hipGetLastError());
     return MPCMP_OK;
 }
