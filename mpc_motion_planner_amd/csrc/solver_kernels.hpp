@@ -196,7 +196,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, mpcmp_
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *zl = lds, *scr = lds + n;
     const int tid = threadIdx.x, b = blockIdx.x;
-    if (tid == 0) { ws.perm[b] = b; ws.okey[b] = 0; }     // no history yet: problems are solved in batch order
+    if (tid == 0) { ws.perm[b] = b; ws.okey[b] = 0; if (b == 0) *ws.done = 0; }     // no history yet: problems are solved in batch order
     const double *x0 = ws.x0 + 14 * b, *xf = ws.xf + 14 * b;
     if (warm_x) {
         for (int v = tid; v < n; v += D::NT) {
