@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — trajectories/s of the batched min-time OCP solver on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path (init -> 20 x [QP, line search + re-linearisation]) over one batch of
-1024 synthetic (start,target) pairs per GPU (BASELINE.json configs[1]: 7-DoF Panda, N=13 nodes, 20 SQP
-iterations, <=700 ADMM iterations).  Inputs are resident in HBM before the timed region; weak scaling: every
-rank solves its own 1024-problem shard (no data-path collective), then one RCCL gather of the solutions to
-rank 0 inside the timed region.
+A "step" = one pass of the hot path (warm start -> init -> K x [QP, line search + re-linearisation]) over one batch of
+synthetic (start,target) pairs.  Default workload = BASELINE.json configs[1]: 1024 problems per GPU, 7-DoF Panda, N=13
+nodes, 20 SQP iterations, <=700 ADMM iterations.  `value` is measured with inputs and outputs resident in HBM
+(device-pointer entry points); the host->host rate of SURVEY.md 8(d) (PCIe-inclusive, median of >=5 warm repeats) is
+reported beside it as `host_to_host`, never as `value`.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+Multi-GPU: one process per GPU; the global seeded batch is cut into contiguous slices (mpc_motion_planner_amd/sharding.py),
+no data-path collective, one RCCL gather of the solutions to rank 0 inside the timed region.
+  --scaling weak   (default)  --batch problems PER GPU          (what the driver's N=1,2,4,8 sweep measures)
+  --scaling strong            --batch problems in the WHOLE job (slice [r*B/G, (r+1)*B/G))
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scaling weak|strong] [--workload ...]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
 """
 import argparse
@@ -22,61 +27,145 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MARGINS = (0.9, 0.9, 0.5, 0.9, 0.1)      # examples/offline_trajectory.cpp:9
-NUM_SEG, SQP_ITERS = 4, 20               # BASELINE.json configs[1]
-BYTES_PER_TRAJ = 4640                    # compulsory HBM I/O per trajectory at N=13
-FP64_PEAK_TFLOPS = 78.6                  # MI355X FP64 vector peak (datasheet), SURVEY.md §8(d)
+FP64_PEAK_TFLOPS = 78.6                  # MI355X FP64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (datasheet)
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8 TB/s spec
 
+# workload -> (num_seg, sqp_iters, n_arms, compulsory HBM bytes per trajectory, metric string)
+WORKLOADS = {
+    "batch":   (4, 20, 1, 4640, "trajectories/sec, 7-DoF Panda min-time OCP, 1k batch @ 1/2/4/8 GPU"),
+    "shipped": (6, 2, 1, 6656, "trajectories/sec, 7-DoF Panda min-time OCP, reference-as-shipped depth (N=19, 2 SQP), 1k batch"),
+    "dual14":  (8, 20, 2, 17296, "trajectories/sec, 14-DoF dual-Panda min-time OCP, N=25, 4096-problem batch"),
+}
+# FP64 FMAs the dominant kernel EXECUTES (tools/isa_mix.py on the ISA of the ADMM loop / the sweeps), per ADMM iteration and
+# per factorisation; None where it has not been counted
+EXECUTED_FMA = {4: (34.0e3, 0.85e6)}
 
-def canonical_flops(N, sqp_iters, admm_iters_total):
-    """SURVEY.md §8(d) dense-equivalent FP64 flop count of one trajectory."""
-    n, m = 21 * N + 1, 14 * (N - 1) + 8 * N
-    f_rb, f_fact = 2.0e4, n ** 3 / 3.0
-    f_iter = 2.0 * n * n + 4.0 * 245 * N + 12.0 * (n + m)
+
+def canonical_flops(N, sqp_iters, admm_iters_total, narm=1):
+    """SURVEY.md 8(d) dense-equivalent FP64 flop count of one trajectory (n, m of the whole NLP)."""
+    n, m = 21 * N * narm + 1, (14 * (N - 1) + 8 * N) * narm
+    f_rb, f_fact = 2.0e4 * narm, n ** 3 / 3.0
+    f_iter = 2.0 * n * n + 4.0 * 245 * N * narm + 12.0 * (n + m)
     return sqp_iters * (N * f_rb + f_fact) + admm_iters_total * f_iter
 
 
-def cpu_baseline(x0, xf, sample, threads, warm):
-    """Time the CPU oracle (same algorithm) on a bounded sample of the same workload. Checker/baseline only."""
+def measured_fp64_peak():
+    """FP64 FMA peak measured on this pool by tools/micro/fp64_peak.hip (profiles/r02_fp64_peak.json), None if absent"""
+    try:
+        return float(json.load(open(os.path.join(ROOT, "profiles", "r02_fp64_peak.json")))["tflops"])
+    except Exception:
+        return None
+
+
+def committed_traffic(kname, problems_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json)"""
+    for f in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", f)))
+            if tj.get("kernel") == kname and tj.get("problems_per_launch") == problems_per_launch:
+                return tj["traffic_bytes_per_launch"], tj.get("mfma_busy_cycles_per_launch")
+        except Exception:
+            pass
+    return None, None
+
+
+def cpu_baseline(nseg, sqp, x0, xf, warm, n_multi, n_single):
+    """Time the CPU oracle (same algorithm, same warm start; oracle/liboracle.so, C -O3) on a bounded sample of the same
+    workload: (i) one thread = the reference's execution model (examples/benchmark.cpp:16), (ii) a pthread pool over
+    problems on the host cores this process may use.  Checker/baseline only — never the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py as o
-    cfg = o.default_config(NUM_SEG, SQP_ITERS, margins=MARGINS)
-    N = 3 * NUM_SEG + 1
-    wx = np.zeros((sample, N, 14)); wu = np.zeros((sample, N, 7)); wT = np.zeros(sample)
+    cfg = o.default_config(nseg, sqp, margins=MARGINS)
+    N = 3 * nseg + 1
+    nproc = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = nproc
+    # a container may see every host core but be throttled to a CPU quota (cgroup v2 cpu.max): size the pool by the quota
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(float(q) / float(per))))
+    except Exception:
+        quota = None
+    threads = max(1, min(usable, quota if quota else 32))
+    n_multi = min(n_multi, x0.shape[0]); n_single = min(n_single, x0.shape[0])
     lim = o.default_limits()
-    for b in range(sample):    # (warm start outside the timed part: microseconds per problem, single thread)
+    wx = np.zeros((n_multi, N, 14)); wu = np.zeros((n_multi, N, 7)); wT = np.zeros(n_multi)
+    for b in range(n_multi):    # (warm start outside the timed part: microseconds per problem)
         if warm == "jerk":
-            wx[b], wu[b], wT[b] = o.warm_start_jerk(NUM_SEG, MARGINS[1] * lim["vmax"], MARGINS[2] * lim["amax"], MARGINS[4] * lim["jmax"], x0[b], xf[b])
+            wx[b], wu[b], wT[b] = o.warm_start_jerk(nseg, MARGINS[1] * lim["vmax"], MARGINS[2] * lim["amax"], MARGINS[4] * lim["jmax"], x0[b], xf[b])
         else:
             wx[b], wu[b], wT[b] = o.warm_start(cfg, x0[b], xf[b])
     t0 = time.perf_counter()
-    _, _, T, info = o.solve_batch(cfg, x0[:sample], xf[:sample], wx, wu, wT, threads=threads)
-    dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "trajectories/s", "cores": threads, "kind": "port",
-            "sample": "%d of the batch's %d problems, oracle/liboracle.so (C, -O3), %d pthreads, %.1f s wall"
-                      % (sample, x0.shape[0], threads, dt)}, T
+    _, _, T, _ = o.solve_batch(cfg, x0[:n_multi], xf[:n_multi], wx, wu, wT, threads=threads)
+    dt_multi = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    o.solve_batch(cfg, x0[:n_single], xf[:n_single], wx[:n_single], wu[:n_single], wT[:n_single], threads=1)
+    dt_single = time.perf_counter() - t0
+    return {"value": n_multi / dt_multi, "unit": "trajectories/s", "cores": threads, "kind": "port",
+            "single_thread": n_single / dt_single, "nproc": nproc, "usable_cores": usable, "cgroup_cpu_quota": quota,
+            "sample": "oracle/liboracle.so (C, -O3): %d problems of the batch on %d pthreads in %.1f s; %d problems on 1 thread "
+                      "(the reference's execution model, examples/benchmark.cpp:16) in %.1f s; os.cpu_count() = %d"
+                      % (n_multi, threads, dt_multi, n_single, dt_single, nproc)}, T
 
 
 def bench_receding_horizon(args, M, scenarios, local):
     """BASELINE.json configs[4]: 512 parallel Panda instances x 200 warm-started re-solves, hipGraph-captured step.
     (reference-as-shipped solver depth: 2 SQP iterations per re-solve, motionPlanner.cpp:15; N = 13; dt = 10 ms)"""
+    nseg, sqp = 4, 2
     B, resolves, dt = 512, 200, 0.01
-    cfg = M.default_config(NUM_SEG, 2, margins=MARGINS)
+    cfg = M.default_config(nseg, sqp, margins=MARGINS)
     s = M.Solver(cfg, B, device=local)
     x0, xf = scenarios.make_batch(B, MARGINS)
-    out = {}
+    out, admm = {}, {}
+    kname = k_ms = k_n = None
     for graph in (False, True):
         s.rh_init(x0, xf)
         s.rh_run(2, dt, use_graph=graph)              # first (cold) solve + graph instantiation are warm-up
+        if not graph:
+            s.kernel_timing(reset=True)               # HIP events around the QP launches (eager mode only; a graph replay has none)
         t0 = time.perf_counter()
         s.rh_run(resolves, dt, use_graph=graph)
         el = time.perf_counter() - t0
+        if not graph:
+            kname, k_ms, k_n = s.kernel_timing(reset=True)
         out["graph" if graph else "eager"] = B * resolves / el
     xg, sx, su, sT, info = s.rh_get()
-    print(json.dumps({"metric": "re-solves/sec, receding-horizon MPC, 512 instances x 200 warm-started re-solves", "value": out["graph"],
-                      "unit": "re-solves/s", "n_gpus": 1, "eager_value": out["eager"], "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": "512 Panda instances x 200 re-solves, N=13, 2 SQP iters/re-solve, dt=10 ms, hipGraph replay"},
-                      "quality": {"status_ok_frac": float((info["status"] == 0).mean()), "T_mean_remaining": float(sT.mean())}}))
+    N = 3 * nseg + 1
+    admm_per_resolve = float(info["qp_iters_total"].mean())           # of the last re-solve
+    flops = canonical_flops(N, sqp, admm_per_resolve)
+    line = {"metric": "re-solves/sec, receding-horizon MPC, 512 instances x 200 warm-started re-solves", "value": out["graph"],
+            "unit": "re-solves/s", "n_gpus": 1, "steps": resolves, "warmup": 2, "ms_per_step": 1e3 * B / out["graph"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "eager_value": out["eager"], "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "512 Panda instances x 200 re-solves, N=13, 2 SQP iters/re-solve, dt=10 ms, hipGraph replay of the two-stream step "
+                                   "(BASELINE.json configs[4])"},
+            "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": out["graph"] * flops / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": out["graph"] * flops / 1e12 / FP64_PEAK_TFLOPS, "traffic": None, "mfma_busy": 0.0,
+                         "avg_launch_ms_eager": (k_ms / max(k_n, 1)) if k_n else None, "launches_eager": k_n,
+                         "admm_iters_per_resolve": admm_per_resolve, "canonical_gflop_per_resolve": flops / 1e9,
+                         "note": "whole re-solve on the wall clock (canonical dense-equivalent flops, SURVEY.md 8d); the kernel uses no MFMA"},
+            "quality": {"status_ok_frac": float((info["status"] == 0).mean()), "T_mean_remaining": float(sT.mean())}}
+    if not args.no_cpu_baseline:
+        # CPU baseline: the oracle's re-solve (2 SQP iterations from the previous solution) on a sample of the instances
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_py as o
+        ocfg = o.default_config(nseg, sqp, margins=MARGINS)
+        ns, reps = 16, 8
+        t0 = time.perf_counter()
+        for b in range(ns):
+            wx, wu, wT = o.warm_start(ocfg, x0[b], xf[b]); xc = x0[b].copy()
+            for r in range(reps):
+                xs, us, T, _ = o.solve(ocfg, xc, xf[b], wx, wu, wT)
+                xc = o.mpc_point(nseg, xs, us, T, dt)[:14]
+                wx, wu, wT = xs.copy(), us, T
+                wx[0] = xc; wx[-1] = xf[b]
+        el = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": ns * reps / el, "unit": "re-solves/s", "cores": 1, "kind": "port", "single_thread": ns * reps / el,
+                                "nproc": os.cpu_count(), "sample": "oracle, %d instances x %d re-solves, 1 thread, %.1f s" % (ns, reps, el)}
+    print(json.dumps(line))
 
 
 def main():
@@ -84,24 +173,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="problems per GPU (weak) or in the whole job (strong); default 1024 (4096 for dual14)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--cpu-sample", type=int, default=512, help="problems of the multi-thread CPU leg (single-thread leg: a quarter)")
     ap.add_argument("--warm", choices=["jerk", "quintic"], default="jerk",
                     help="initial guess of every OCP: jerk = the jerk-limited time-synchronised trajectory the reference gets from Ruckig "
                          "(solve_trajectory(true), motionPlanner.cpp:146-175), computed on the GPU inside the timed step; quintic = k_init's fallback")
-    ap.add_argument("--workload", choices=["batch", "rh", "shipped"], default="batch",
-                    help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon, extra line; "
-                         "shipped: the reference-as-shipped solver depth (N=19, 2 SQP iterations; SURVEY.md 8d), extra line")
+    ap.add_argument("--workload", choices=["batch", "rh", "shipped", "dual14"], default="batch",
+                    help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon; shipped: the reference-as-shipped "
+                         "solver depth (N=19, 2 SQP iterations; SURVEY.md 8d); dual14: configs[3], 14-DoF dual-Panda, N=25")
     args = ap.parse_args()
-    global NUM_SEG, SQP_ITERS, BYTES_PER_TRAJ
-    if args.workload == "shipped":
-        NUM_SEG, SQP_ITERS = 6, 2            # robot_ocp.hpp:32 NUM_SEG as shipped (N=19), motionPlanner.cpp:15 max_iter 2
-        BYTES_PER_TRAJ = 6656                # compulsory I/O per trajectory at N=19
 
     import torch
     import mpc_motion_planner_amd as M
-    from mpc_motion_planner_amd import scenarios
+    from mpc_motion_planner_amd import scenarios, sharding
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,19 +206,24 @@ def main():
 
     if args.workload == "rh":
         return bench_receding_horizon(args, M, scenarios, local)
-    B, N = args.batch, 3 * NUM_SEG + 1
-    cfg = M.default_config(NUM_SEG, SQP_ITERS, margins=MARGINS)
-    solver = M.Solver(cfg, B, device=local)
-    # this rank's shard of the global seeded batch: problems [rank*B, (rank+1)*B)
-    x0_h, xf_h = scenarios.make_batch(B, MARGINS, stream_offset=rank * B)
+    if args.workload == "dual14":
+        import bench_dual14
+        return bench_dual14.run(args, rank, world, local, dist)
+    nseg, sqp, narm, bytes_per_traj, metric = WORKLOADS[args.workload]
+    batch = args.batch or 1024
+    N = 3 * nseg + 1
+    total = sharding.global_total(args.scaling, batch, world)
     dev = torch.device("cuda", local)
+    sb = sharding.ShardedBatch(total, rank, world, N, dev, dist)        # this rank's slice [lo, hi) of the global seeded batch
+    B = sb.count
+    cfg = M.default_config(nseg, sqp, margins=MARGINS)
+    solver = M.Solver(cfg, max(B, 1), device=local)
+    x0_h, xf_h = scenarios.make_batch(B, MARGINS, stream_offset=sb.lo)
     x0 = torch.from_numpy(x0_h).to(dev); xf = torch.from_numpy(xf_h).to(dev)
-    sol = torch.zeros(B, 21 * N + 1, dtype=torch.float64, device=dev)      # [xs | us | T] per problem
     sol_x = torch.zeros(B, N, 14, dtype=torch.float64, device=dev)
     sol_u = torch.zeros(B, N, 7, dtype=torch.float64, device=dev)
     sol_T = torch.zeros(B, dtype=torch.float64, device=dev)
     info = torch.zeros(B, 64, dtype=torch.uint8, device=dev)               # mpcmp_info records (64 B each)
-    gathered = [torch.zeros_like(sol) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream(dev)
     jmax = MARGINS[4] * M.default_limits()["jmax"]                          # motionPlanner.cpp:86-88
     warm_x = torch.zeros(B, N, 14, dtype=torch.float64, device=dev); warm_u = torch.zeros(B, N, 7, dtype=torch.float64, device=dev)
@@ -147,8 +238,7 @@ def main():
         solver.solve_device(B, x0.data_ptr(), xf.data_ptr(), sol_x.data_ptr(), sol_u.data_ptr(), sol_T.data_ptr(),
                             info.data_ptr(), warm=warm, stream=stream.cuda_stream)
         if world > 1:
-            torch.cat([sol_x.reshape(B, -1), sol_u.reshape(B, -1), sol_T[:, None]], dim=1, out=sol)
-            dist.gather(sol, gathered, dst=0)
+            sb.pack_and_gather(sol_x, sol_u, sol_T)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -159,7 +249,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    solver.kernel_timing(reset=True)
+    solver.kernel_timing(reset=True)          # switches the HIP-event timing of the dominant kernel on
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -173,60 +263,71 @@ def main():
 
     if rank == 0:
         inf = np.frombuffer(info.cpu().numpy().tobytes(), dtype=M.INFO_DTYPE)
-        total = world * B * args.steps
-        value = total / elapsed
+        value = total * args.steps / elapsed
         admm_mean = float(inf["qp_iters_total"].mean())
-        flops_traj = canonical_flops(N, SQP_ITERS, admm_mean)
+        flops_traj = canonical_flops(N, sqp, admm_mean, narm)
+        flops_qp_traj = flops_traj - sqp * N * 2.0e4 * narm                 # the dominant kernel's share: factorisations + ADMM iterations
         k_avg_s = (k_ms / max(k_launches, 1)) * 1e-3
-        # a large batch is solved as two half-batches on two streams (mpcmp.hip: solve_impl), so a launch of the dominant kernel
-        # covers B / launches_per_sqp problems; its duration is measured with HIP events on the stream it was launched on
-        launches_per_sqp = max(1, round(k_launches / float(args.steps * SQP_ITERS)))
-        problems_per_launch = B / launches_per_sqp
-        alg_bytes_launch = problems_per_launch * BYTES_PER_TRAJ / SQP_ITERS
-        achieved_gbs = alg_bytes_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-        traffic = None
-        try:    # HBM bytes per k_qp2 launch from the committed rocprofv3 PMC passes (see profiles/r01_traffic.json)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("kernel") == kname and tj.get("problems_per_launch") == problems_per_launch:
-                traffic = tj["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        # a large batch is solved as several parts on as many streams (mpcmp.hip: solve_impl), so a launch of the dominant kernel
+        # covers B / parts problems and `parts` launches are in flight together; durations are HIP events on the launch's own stream
+        parts = max(1, round(k_launches / float(args.steps * sqp)))
+        problems_per_launch = B / parts
+        flops_launch = problems_per_launch * flops_qp_traj / sqp
+        per_gpu = value / world
+        achieved = per_gpu * flops_qp_traj / 1e12                           # on the wall clock of the timed region (includes the other kernels)
+        alg_bytes_launch = problems_per_launch * bytes_per_traj / sqp
+        traffic, mfma_busy = committed_traffic(kname, problems_per_launch)
+        peak_meas = measured_fp64_peak()
+        ex = EXECUTED_FMA.get(nseg)
+        executed = per_gpu * 2.0 * (admm_mean * ex[0] + sqp * ex[1]) / 1e12 if ex else None
+        feasible = (inf["defect_inf"] < 1e-3) & (inf["path_viol_inf"] < 1e-3) & (inf["term_err_inf"] <= 1.1e-2) & (inf["status"] == 0)
         out = {
-            "metric": "trajectories/sec, 7-DoF Panda min-time OCP, 1k batch @ 1/2/4/8 GPU" if args.workload == "batch"
-                      else "trajectories/sec, 7-DoF Panda min-time OCP, reference-as-shipped depth (N=19, 2 SQP), 1k batch",
-            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "metric": metric, "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d-problem random batch per GPU, 7-DoF Panda, N=%d Chebyshev nodes (cubic x %d segments), "
+            "config": {"workload": "%d-problem random batch %s, 7-DoF Panda, N=%d Chebyshev nodes (cubic x %d segments), "
                                    "%d SQP iters, <=700 ADMM iters, %s warm start computed in the timed step (%s)"
-                                   % (B, N, NUM_SEG, SQP_ITERS, "jerk-limited (Ruckig-equivalent)" if args.warm == "jerk" else "quintic",
-                                      "BASELINE.json configs[1]" if args.workload == "batch"
-                                      else "reference as shipped: robot_ocp.hpp:32, motionPlanner.cpp:15"),
-                       "batch_per_gpu": B, "seed": scenarios.SEED, "margins": list(MARGINS)},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "problems_per_launch": problems_per_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY.md 8d); see fp64"},
-            "fp64": {"achieved_tflops": (value / world) * flops_traj / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
-                     "frac": (value / world) * flops_traj / 1e12 / FP64_PEAK_TFLOPS,
-                     "canonical_gflop_per_traj": flops_traj / 1e9, "admm_iters_per_traj": admm_mean,
-                     "note": "whole solve on the wall clock, per GPU (canonical dense-equivalent flops, SURVEY.md 8d)"},
-            "quality": {"status_ok_frac": float((inf["status"] == 0).mean()), "T_mean": float(inf["T"].mean()),
+                                   % (batch, "per GPU" if args.scaling == "weak" else "in the whole job, sliced [r*B/G,(r+1)*B/G)", N, nseg, sqp,
+                                      "jerk-limited (Ruckig-equivalent)" if args.warm == "jerk" else "quintic",
+                                      "BASELINE.json configs[1]" if args.workload == "batch" else "reference as shipped: robot_ocp.hpp:32, motionPlanner.cpp:15"),
+                       "batch": batch, "problems_total": total, "problems_rank0": B, "rccl_world_size": world,
+                       "seed": scenarios.SEED, "margins": list(MARGINS), "timed": "device-resident inputs and outputs (value); host_to_host beside it"},
+            # the binding resource is FP64 vector issue + LDS + workgroup barriers: not HBM, not MFMA
+            "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS,
+                         "executed_frac": (executed / FP64_PEAK_TFLOPS) if executed is not None else None,
+                         "peak_measured": peak_meas, "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None,
+                         "traffic": traffic, "mfma_busy": 0.0 if mfma_busy is None else mfma_busy,
+                         "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts, "problems_per_launch": problems_per_launch,
+                         "canonical_gflop_per_launch": flops_launch / 1e9,
+                         "per_launch_tflops": flops_launch / k_avg_s / 1e12 if k_avg_s > 0 else None,
+                         "canonical_gflop_per_traj": flops_traj / 1e9, "admm_iters_per_traj": admm_mean,
+                         "hbm": {"algorithmic_bytes_per_launch": alg_bytes_launch, "achieved_gbs": alg_bytes_launch / k_avg_s / 1e9 if k_avg_s > 0 else None,
+                                 "peak_gbs": HBM_PEAK_GBS, "frac": alg_bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS if k_avg_s > 0 else None},
+                         "note": "achieved = canonical dense-equivalent FP64 flops (SURVEY.md 8d) of the QP kernel per GPU over the wall clock of the "
+                                 "timed region; `launches_in_flight` launches overlap, so avg_launch_ms is not exclusive GPU time; executed_frac counts "
+                                 "the FMAs the ISA executes; mfma_busy is 0 because the kernel issues no MFMA (one right-hand side per problem)"},
+            "quality": {"status_ok_frac": float((inf["status"] == 0).mean()), "feasible_frac": float(feasible.mean()),
+                        "T_mean": float(inf["T"].mean()),
                         "defect_inf_median": float(np.median(inf["defect_inf"])),
                         "term_err_inf_median": float(np.median(inf["term_err_inf"])),
-                        "path_viol_inf_max": float(inf["path_viol_inf"].max())},
+                        "path_viol_inf_max": float(inf["path_viol_inf"].max()),
+                        "feasible_def": "status 0, collocation defect < 1e-3, path violation < 1e-3, terminal error <= 1.1e-2"},
         }
         if world == 1:
-            # PCIe-inclusive rate through the host-buffer entry point (reported, never `value`)
-            t1 = time.perf_counter()
-            solver.solve(x0_h, xf_h, solver.warm_start_jerk(x0_h, xf_h, jmax) if args.warm == "jerk" else None)
-            out["host_buffers_traj_per_s"] = B / (time.perf_counter() - t1)
+            # host -> host (inputs and outputs in host memory, PCIe inclusive): warm, median of 5 repeats
+            ts = []
+            for _ in range(6):
+                t1 = time.perf_counter()
+                solver.solve(x0_h, xf_h, solver.warm_start_jerk(x0_h, xf_h, jmax) if args.warm == "jerk" else None)
+                ts.append(time.perf_counter() - t1)
+            ts = sorted(ts[1:])
+            out["host_to_host"] = {"trajectories_per_s": B / ts[len(ts) // 2], "repeats": len(ts), "min_ms": 1e3 * ts[0], "max_ms": 1e3 * ts[-1],
+                                   "note": "SURVEY.md 8(d) defines the metric host->host; `value` is the device-resident rate the bench contract asks for"}
             if not args.no_cpu_baseline:
-                threads = min(os.cpu_count() or 1, 16)
-                cb, T_cpu = cpu_baseline(x0_h, xf_h, min(args.cpu_sample, B), threads, args.warm)
+                cb, T_cpu = cpu_baseline(nseg, sqp, x0_h, xf_h, args.warm, args.cpu_sample, max(16, args.cpu_sample // 4))
                 out["cpu_baseline"] = cb
-                out["quality"]["max_rel_dT_vs_cpu_sample"] = float(np.max(np.abs(inf["T"][:len(T_cpu)] - T_cpu) / T_cpu))
+                out["quality"]["max_rel_dT_vs_cpu_sample"] = float(np.max(np.abs(inf["T"][:len(T_cpu)] - T_cpu) / np.abs(T_cpu)))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -3,6 +3,7 @@
 // write the 403x29 text file the reference's analysis/data_analysis.ipynb reads.
 //   g++ -O2 -std=c++17 -Iinclude examples/offline_trajectory.cpp -Lmpc_motion_planner_amd -lmpcmp
 //     -Wl,-rpath,$PWD/mpc_motion_planner_amd -o offline_trajectory
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -18,6 +19,18 @@ int main(int argc, char **argv) {
         MotionPlanner::Vec7 q0, v0, qT, vT;
         planner.sample_random_state(q0, v0);
         planner.sample_random_state(qT, vT);
+        // target task velocity inside the Cartesian limits, scaled down otherwise (reference examples/offline_trajectory.cpp:26-41)
+        auto norm3 = [](const mpcmp_shim::Mat<6, 1> &t, int o) { return std::sqrt(t(o) * t(o) + t(o + 1) * t(o + 1) + t(o + 2) * t(o + 2)); };
+        mpcmp_shim::Mat<6, 1> task_velocity = planner.robot.forward_velocities(qT, vT);
+        if (norm3(task_velocity, 0) > planner.robot.max_linear_velocity) {
+            const double f = 0.9 * planner.robot.max_linear_velocity / norm3(task_velocity, 0);
+            for (int j = 0; j < 7; j++) vT(j) *= f;
+            task_velocity = planner.robot.forward_velocities(qT, vT);
+        }
+        if (norm3(task_velocity, 3) > planner.robot.max_angular_velocity) {
+            const double f = 0.9 * planner.robot.max_angular_velocity / norm3(task_velocity, 3);
+            for (int j = 0; j < 7; j++) vT(j) *= f;
+        }
         planner.set_current_state(q0, v0);
         planner.set_target_state(qT, vT);
         if (planner.check_state_in_bounds(q0, v0) != 0 || planner.check_state_in_bounds(qT, vT) != 0)

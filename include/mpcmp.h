@@ -61,7 +61,7 @@ typedef struct {
     int    check_every;      /* ADMM termination-test interval (25)                                         */
     int    quirk_dtau_dT;    /* keep the non-physical d tau/dT column of robot_ocp.hpp:124,138 (1)          */
     double eps_abs, eps_rel; /* mpc.qp_settings().eps_*,             motionPlanner.cpp:19-20 (1e-3)        */
-    double rho, sigma, alpha, rho_eq_scale;   /* box-ADMM parameters (0.1, 1e-6, 1.6, 1e3)                  */
+    double rho, sigma, alpha, rho_eq_scale;   /* box-ADMM parameters (0.02, 1e-6, 1.4, 1e3: fitted) */
     double ls_eta, ls_tau;   /* Armijo fraction and backtracking factor (0.25, 0.5)                         */
     double hess_reg;         /* Gershgorin shift, polympc_redef.hpp:68 (1e-3)                               */
     double eps_target;       /* terminal box half-width, motionPlanner.hpp:44 (1e-2)                        */
@@ -153,6 +153,15 @@ int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0
 int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, int n_pts,
                                 double *out, double *T_out);
 
+/* MotionPlanner::get_RK_point (motionPlanner.hpp:130-142): the same trajectory at ONE physical time per problem, clamped to
+ * its duration, with the RNEA torque: out [B][28] = q(7), qd(7), qdd(7), tau(7); T_out [B] (may be NULL) = the durations. */
+int mpcmp_jerk_point_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, const double *time,
+                           double *out, double *T_out);
+/* MotionPlanner::get_MPC_point (motionPlanner.hpp:118-128): the solution at ONE physical time per problem, including the
+ * reference's clamp (time >= T: the normalised time becomes T, not 1), with the RNEA torque: out [B][28] as above. */
+int mpcmp_mpc_point_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double *sol_u, const double *sol_T, const double *time,
+                          double *out);
+
 /* ---- scenario helpers of the robot wrapper (host side, as in the reference; never called by the batched solve) ---- */
 /* World-aligned 6x7 Jacobian of the tool frame, rows [linear(3); angular(3)], row-major (J = blockdiag(R,R) * J_local,
  * robot_utils/pandaWrapper.cpp:70-75,97-101); optional tool position p[3] and rotation R[9] (row-major). */
@@ -187,7 +196,8 @@ int mpcmp_rh_get(mpcmp_ctx *ctx, double *x0_now, double *sol_x, double *sol_u, d
 
 /* ---- measurement hooks used by bench.py ---- */
 /* name and accumulated device time (ms, HIP events on the solve stream) of the dominant kernel since the
- * last reset; launches = number of launches accumulated. */
+ * last reset; launches = number of launches accumulated.  Event recording is OFF until the first call (a plain solve
+ * records nothing and allocates nothing); afterwards at most 4096 launches are held between two calls. */
 int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name, double *ms_total, int *launches);
 
 /* diagnostics: per-problem phase cycle stamps of the last k_qp launch, [B][160] (16 workgroup stamps, then

@@ -50,11 +50,67 @@ struct Mat {                                  // column-major like Eigen's defau
 
 #define NDOF 7   // robot_utils/pandaWrapper.hpp:10
 
+// Minimal stand-ins for the Pinocchio objects a reference caller touches through `planner.robot`
+// (examples/benchmark.cpp:108-110,154-156: forwardKinematics(model, data, q); updateFramePlacement(model, data, frame_id);
+//  data.oMf[frame_id].translation()[2]).  Only what those call sites use exists.
+namespace mpcmp_shim {
+struct Placement {
+    double t[3] = {0, 0, 0};
+    double Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double *translation() const { return t; }
+    const double *rotation() const { return Rm; }          // row-major
+};
+struct FrameData {
+    static constexpr int JOINT7 = 7, LINK8 = 8, TOOL = 9;  // oMf indices: joint-7 origin, panda_link8, panda_tool
+    Placement oMf[10];
+    Placement oMi[8];                                       // oMi[7]: joint-7 placement (motionPlanner.cpp:111)
+};
+}  // namespace mpcmp_shim
+#if !(defined(__has_include) && __has_include(<pinocchio/algorithm/kinematics.hpp>))
+namespace pinocchio {
+// joint placements of the chain for configuration q[7] (pinocchio::forwardKinematics)
+inline void forwardKinematicsArray(const mpcmp_model &model, mpcmp_shim::FrameData &data, const double *q) {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    for (int i = 0; i < 7; i++) {
+        for (int r = 0; r < 3; r++) p[r] += R[3 * r] * model.p[i][0] + R[3 * r + 1] * model.p[i][1] + R[3 * r + 2] * model.p[i][2];
+        const double c = std::cos(q[i]), s = std::sin(q[i]);
+        double J[9], Rn[9];
+        for (int r = 0; r < 3; r++) {
+            J[3 * r] = model.R0[i][3 * r] * c + model.R0[i][3 * r + 1] * s;
+            J[3 * r + 1] = -model.R0[i][3 * r] * s + model.R0[i][3 * r + 1] * c;
+            J[3 * r + 2] = model.R0[i][3 * r + 2];
+        }
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++)
+            Rn[3 * r + k] = R[3 * r] * J[k] + R[3 * r + 1] * J[3 + k] + R[3 * r + 2] * J[6 + k];
+        for (int k = 0; k < 9; k++) R[k] = Rn[k];
+        for (int k = 0; k < 3; k++) data.oMi[i + 1].t[k] = p[k];
+        for (int k = 0; k < 9; k++) data.oMi[i + 1].Rm[k] = R[k];
+    }
+}
+template <class V> inline void forwardKinematics(const mpcmp_model &model, mpcmp_shim::FrameData &data, const V &q) {
+    double qq[7];
+    for (int j = 0; j < 7; j++) qq[j] = q(j);
+    forwardKinematicsArray(model, data, qq);
+}
+// placement of one operational frame from the joint placements (pinocchio::updateFramePlacement)
+inline void updateFramePlacement(const mpcmp_model &model, mpcmp_shim::FrameData &data, int frame_id) {
+    const mpcmp_shim::Placement &j7 = data.oMi[7];
+    const double *off = frame_id == mpcmp_shim::FrameData::TOOL ? model.tool : (frame_id == mpcmp_shim::FrameData::LINK8 ? model.link8 : nullptr);
+    mpcmp_shim::Placement &f = data.oMf[frame_id];
+    for (int k = 0; k < 9; k++) f.Rm[k] = j7.Rm[k];
+    for (int r = 0; r < 3; r++)
+        f.t[r] = j7.t[r] + (off ? j7.Rm[3 * r] * off[0] + j7.Rm[3 * r + 1] * off[1] + j7.Rm[3 * r + 2] * off[2] : 0.0);
+}
+}  // namespace pinocchio
+#endif
+
 // limits table + model of robot_utils/pandaWrapper.hpp (Pinocchio members replaced by mpcmp_model)
 class PandaWrapper {
   public:
     using Vec7 = mpcmp_shim::Mat<NDOF, 1>;
     mpcmp_model model;
+    mpcmp_shim::FrameData data;                                   // robot_utils/pandaWrapper.hpp:19 (pinocchio::Data)
+    int frame_id = mpcmp_shim::FrameData::TOOL;                   // getFrameId("panda_tool"), pandaWrapper.cpp:11
     Vec7 min_position, max_position, max_velocity, max_acceleration, max_jerk, max_torque;
     double max_torqueDot{1000};
     double max_linear_velocity{1.7};
@@ -113,10 +169,37 @@ class PandaWrapper {
     }
 };
 
+class MotionPlanner;
+namespace mpcmp_shim {
+// What a reference caller can reach through the public member `mpc` (motionPlanner.hpp:28-29: polympc's MPC<> object),
+// reduced to the read-side calls the facade itself uses (motionPlanner.cpp:15-20,184-207; motionPlanner.hpp:106-125):
+// settings, the solution and its interpolation, and the solver info.  The polympc object itself does not exist here.
+struct MpcView {
+    struct Settings { int &max_iter; int &line_search_max_iter; };
+    struct QpSettings { int &max_iter; double &eps_rel; double &eps_abs; };
+    struct Status { int value; };
+    struct InfoView { Status status; int iter; int qp_iters_total; };
+    explicit MpcView(MotionPlanner *o) : owner(o) {}
+    Settings settings();
+    QpSettings qp_settings();
+    std::array<double, 1> solution_p() const;
+    const std::vector<double> &solution_x() const;
+    const std::vector<double> &solution_u() const;
+    Mat<2 * NDOF, 1> solution_x_at(double t) const;       // normalised time in [0,1]
+    Mat<NDOF, 1> solution_u_at(double t) const;
+    InfoView info() const;
+    std::vector<double> time_nodes() const;                // mpc.ocp().time_nodes
+  private:
+    MotionPlanner *owner;
+};
+}  // namespace mpcmp_shim
+
 class MotionPlanner {
   public:
     using Vec7 = mpcmp_shim::Mat<NDOF, 1>;
     using Vec14 = mpcmp_shim::Mat<2 * NDOF, 1>;
+    using mpc_t = mpcmp_shim::MpcView;
+    mpc_t mpc{this};                                                     // motionPlanner.hpp:28-29 (view, see MpcView)
 
     PandaWrapper robot;
     Vec14 current_state, target_state;
@@ -212,6 +295,17 @@ class MotionPlanner {
         warm_T_ = final_time; have_warm_ = true;
     }
 
+#if defined(MPCMP_USE_EIGEN) || (defined(__has_include) && __has_include(<Eigen/Dense>))
+    // the reference's own signature (motionPlanner.hpp:145): 7 x nPoint matrices, regularly time spaced
+    void warm_start(double final_time, Eigen::MatrixXd position_trajectory, Eigen::MatrixXd velocity_trajectory,
+                    Eigen::MatrixXd acceleration_trajectory) {
+        const size_t cnt = (size_t)position_trajectory.size();
+        warm_start(final_time, std::vector<double>(position_trajectory.data(), position_trajectory.data() + cnt),
+                   std::vector<double>(velocity_trajectory.data(), velocity_trajectory.data() + cnt),
+                   std::vector<double>(acceleration_trajectory.data(), acceleration_trajectory.data() + cnt));
+    }
+#endif
+
     // motionPlanner.cpp:177-208.  true: jerk-limited, time-synchronised trajectory between the two states (what the
     // reference gets from Ruckig, motionPlanner.cpp:146-175); false: previous solution / warm_start() guess
     void solve_trajectory(bool use_ruckig_as_warm_start) {
@@ -274,10 +368,17 @@ class MotionPlanner {
     }
     // motionPlanner.hpp:118-128, including its clamp: for time >= T the normalised time is set to T (not 1)
     void get_MPC_point(double time, Vec7 &position, Vec7 &velocity, Vec7 &acceleration, Vec7 &torque) {
-        if (time < sol_T_) time /= sol_T_;
-        else time = sol_T_;
-        interpolate(time, position, velocity, acceleration);
-        chk(mpcmp_rnea_batch(ctx_, 1, position.data(), velocity.data(), acceleration.data(), torque.data()));
+        double o[28];
+        chk(mpcmp_mpc_point_batch(ctx_, 1, sol_x_.data(), sol_u_.data(), &sol_T_, &time, o));       // one launch: clamp, interpolation, RNEA
+        for (int j = 0; j < 7; j++) { position(j) = o[j]; velocity(j) = o[7 + j]; acceleration(j) = o[14 + j]; torque(j) = o[21 + j]; }
+    }
+    // motionPlanner.hpp:130-142: the jerk-limited (Ruckig stand-in) trajectory of the last solve_trajectory(true) at
+    // min(time, duration), torque by RNEA
+    void get_RK_point(double time, Vec7 &position, Vec7 &velocity, Vec7 &acceleration, Vec7 &torque) {
+        double o[28], jm[7];
+        jerk_limits(jm);
+        chk(mpcmp_jerk_point_batch(ctx_, 1, guess_x0_, guess_xf_, jm, &time, o, nullptr));
+        for (int j = 0; j < 7; j++) { position(j) = o[j]; velocity(j) = o[7 + j]; acceleration(j) = o[14 + j]; torque(j) = o[21 + j]; }
     }
     double solution_T() const { return sol_T_; }
     const std::vector<double> &solution_x() const { return sol_x_; }
@@ -343,6 +444,7 @@ class MotionPlanner {
     }
 
   private:
+    friend struct mpcmp_shim::MpcView;
     mpcmp_ctx *ctx_ = nullptr;
     int N_ = 0, max_batch_ = 0;
     std::vector<double> sol_x_, sol_u_, warm_x_, warm_u_, guess_x_, guess_u_;
@@ -385,3 +487,28 @@ class MotionPlanner {
         }
     }
 };
+
+// ---- MpcView members (need the complete MotionPlanner) ----
+inline mpcmp_shim::MpcView::Settings mpcmp_shim::MpcView::settings() { return {owner->config.sqp_iters, owner->config.ls_iters}; }
+inline mpcmp_shim::MpcView::QpSettings mpcmp_shim::MpcView::qp_settings() { return {owner->config.qp_iters, owner->config.eps_rel, owner->config.eps_abs}; }
+inline std::array<double, 1> mpcmp_shim::MpcView::solution_p() const { return {owner->sol_T_}; }
+inline const std::vector<double> &mpcmp_shim::MpcView::solution_x() const { return owner->sol_x_; }
+inline const std::vector<double> &mpcmp_shim::MpcView::solution_u() const { return owner->sol_u_; }
+inline mpcmp_shim::Mat<2 * NDOF, 1> mpcmp_shim::MpcView::solution_x_at(double t) const {
+    MotionPlanner::Vec7 q, v, a; owner->interpolate(t, q, v, a);
+    Mat<2 * NDOF, 1> x;
+    for (int j = 0; j < 7; j++) { x(j) = q(j); x(7 + j) = v(j); }
+    return x;
+}
+inline mpcmp_shim::Mat<NDOF, 1> mpcmp_shim::MpcView::solution_u_at(double t) const {
+    MotionPlanner::Vec7 q, v, a; owner->interpolate(t, q, v, a);
+    return a;
+}
+inline mpcmp_shim::MpcView::InfoView mpcmp_shim::MpcView::info() const {
+    return {{owner->last_info.status}, owner->last_info.sqp_iters, owner->last_info.qp_iters_total};
+}
+inline std::vector<double> mpcmp_shim::MpcView::time_nodes() const {
+    std::vector<double> t((size_t)owner->N_);
+    mpcmp_time_nodes(owner->config.num_seg, t.data());
+    return t;
+}

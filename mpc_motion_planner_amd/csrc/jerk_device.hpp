@@ -14,6 +14,7 @@
 // re-plans the faster joints to the common duration one after the other (64 scan points at a time), then all lanes sample.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "rbd_device.hpp"
 
 namespace mpcmp {
 
@@ -195,6 +196,34 @@ __global__ __launch_bounds__(64) void k_jerk_traj(JerkLimits lim, const double *
         if (j == 0) o[(size_t)i * 22] = tt;
     }
     if (tid == 0 && Tout) Tout[b] = T;
+}
+
+// MotionPlanner::get_RK_point (motionPlanner.hpp:130-142): the same trajectory at one physical time per problem, clamped to its
+// duration (`time = std::min(time, trajectory.get_duration())`), plus the RNEA torque.  out [B][28] = q(7), v(7), a(7), tau(7).
+__global__ __launch_bounds__(64) void k_jerk_point(const mpcmp_model *mdl, JerkLimits lim, const double *x0, const double *xf, const double *time,
+                                                   double *out, double *Tout) {
+    __shared__ JProf pr[7];
+    __shared__ double sT;
+    __shared__ double pt[21];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double T = jk_plan(lim, x0 + 14 * (size_t)b, xf + 14 * (size_t)b, pr, &sT);
+    const double tt = time[b] < T ? time[b] : T;
+    if (tid < 7) {
+        double q, v, a;
+        jk_prof_eval(pr[tid], tt, q, v, a);
+        pt[tid] = q; pt[7 + tid] = v; pt[14 + tid] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sc[14], v[7], a[7], tau[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) { sincos(pt[j], &sc[2 * j], &sc[2 * j + 1]); v[j] = pt[7 + j]; a[j] = pt[14 + j]; }
+        rnea_dir<false>(mdl, sc, v, a, 0, 0, tau, nullptr);
+        double *o = out + (size_t)b * 28;
+#pragma unroll
+        for (int j = 0; j < 7; j++) { o[j] = pt[j]; o[7 + j] = v[j]; o[14 + j] = a[j]; o[21 + j] = tau[j]; }
+        if (Tout) Tout[b] = T;
+    }
 }
 
 }  // namespace mpcmp

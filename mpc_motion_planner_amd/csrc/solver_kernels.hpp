@@ -984,6 +984,47 @@ __global__ __launch_bounds__(128) void k_sample(const mpcmp_model *mdl, int nseg
 }
 
 
+// MotionPlanner::get_MPC_point (motionPlanner.hpp:118-128) for one physical time per problem, including the reference's clamp
+// (time >= T: the normalised time becomes T, not 1), plus the RNEA torque.  out [B][28] = q(7), v(7), a(7), tau(7).
+__global__ __launch_bounds__(64) void k_mpc_point(const mpcmp_model *mdl, int nseg, int B, const double *sx, const double *su, const double *sT,
+                                                  const double *time, double *out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int N = 3 * nseg + 1;
+    const double T = sT[b];
+    const double t = (time[b] < T) ? time[b] / T : T;
+    const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    int s = (int)floor(t * nseg);
+    if (s >= nseg) s = nseg - 1;
+    if (s < 0) s = 0;
+    const double xx = 2.0 * (t * nseg - s) - 1.0;
+    double Lg[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double w = 1.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k != j) w *= (xx - xi[k]) / (xi[j] - xi[k]);
+        Lg[j] = w;
+    }
+    const double *X = sx + (size_t)b * 14 * N, *U = su + (size_t)b * 7 * N;
+    double q[7], v[7], a[7], tau[7], sc[14];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        q[r] = v[r] = a[r] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            q[r] += Lg[j] * X[14 * (3 * s + j) + r];
+            v[r] += Lg[j] * X[14 * (3 * s + j) + 7 + r];
+            a[r] += Lg[j] * U[7 * (3 * s + j) + r];
+        }
+        sincos(q[r], &sc[2 * r], &sc[2 * r + 1]);
+    }
+    rnea_dir<false>(mdl, sc, v, a, 0, 0, tau, nullptr);
+    double *o = out + (size_t)b * 28;
+#pragma unroll
+    for (int r = 0; r < 7; r++) { o[r] = q[r]; o[7 + r] = v[r]; o[14 + r] = a[r]; o[21 + r] = tau[r]; }
+}
+
 // Receding horizon: x0 <- MPC solution evaluated at physical time dt (MotionPlanner::get_MPC_point, motionPlanner.hpp:118-128,
 // including its clamp: for dt >= T the normalised time is set to T, not 1).  One thread per (problem, state component).
 __global__ __launch_bounds__(256) void k_advance(int nseg, int B, double dt, const double *sx, const double *sT, double *x0) {

@@ -38,12 +38,29 @@ class Solver:
     def set_config(self, cfg):
         check(lib().mpcmp_set_config(self._ctx, C.byref(cfg)), self._ctx); self.cfg = cfg
 
+    def _states(self, x0, xf):
+        """(x0, xf) as contiguous [B][14] arrays; a shape mismatch raises instead of letting the C side read out of bounds"""
+        x0, xf = f64(x0), f64(xf)
+        if x0.ndim != 2 or x0.shape[1] != 14 or xf.shape != x0.shape:
+            raise ValueError("x0 and xf must both be [B][14] arrays, got %s and %s" % (x0.shape, xf.shape))
+        return x0, xf
+
+    def _traj(self, sx, su, sT):
+        sx, su, sT = f64(sx), f64(su), f64(sT).reshape(-1)
+        B = sT.shape[0]
+        if sx.shape != (B, self.N, 14) or su.shape != (B, self.N, 7):
+            raise ValueError("trajectory arrays must be [B][%d][14], [B][%d][7], [B]; got %s, %s, %s"
+                             % (self.N, self.N, sx.shape, su.shape, sT.shape))
+        return sx, su, sT
+
     # -- hot path, host buffers
     def solve(self, x0, xf, warm=None):
-        x0, xf = f64(x0), f64(xf); B = x0.shape[0]
+        x0, xf = self._states(x0, xf); B = x0.shape[0]
         wx = wu = wT = None
         if warm is not None:
-            wx, wu, wT = f64(warm[0]), f64(warm[1]), f64(warm[2])
+            wx, wu, wT = self._traj(*warm)
+            if wT.shape[0] != B:
+                raise ValueError("warm start is for %d problems, states for %d" % (wT.shape[0], B))
         sx, su, sT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
         info = np.zeros(B, dtype=capi.INFO_DTYPE)
         check(lib().mpcmp_solve_batch(self._ctx, B, dp(x0), dp(xf), dp(wx), dp(wu), dp(wT), dp(sx), dp(su), dp(sT),
@@ -58,14 +75,14 @@ class Solver:
                                              vp(stream or None)), self._ctx)
 
     def warm_start(self, x0, xf):
-        x0, xf = f64(x0), f64(xf); B = x0.shape[0]
+        x0, xf = self._states(x0, xf); B = x0.shape[0]
         wx, wu, wT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
         check(lib().mpcmp_warm_start_batch(self._ctx, B, dp(x0), dp(xf), dp(wx), dp(wu), dp(wT)), self._ctx)
         return wx, wu, wT
 
     def warm_start_jerk(self, x0, xf, jmax):
         """Jerk-limited, time-synchronised warm start (stands in for Ruckig): (warm_x [B][N][14], warm_u [B][N][7], warm_T [B])."""
-        x0, xf, jmax = f64(x0), f64(xf), f64(jmax); B = x0.shape[0]
+        (x0, xf), jmax = self._states(x0, xf), f64(jmax).reshape(7); B = x0.shape[0]
         wx, wu, wT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
         check(lib().mpcmp_warm_start_jerk_batch(self._ctx, B, dp(x0), dp(xf), dp(jmax), dp(wx), dp(wu), dp(wT)), self._ctx)
         return wx, wu, wT
@@ -79,10 +96,26 @@ class Solver:
 
     def jerk_trajectory(self, x0, xf, jmax, n_pts=200):
         """The same trajectory sampled uniformly: out [B][n_pts+1][22] = t, q, qd, qdd, and the durations [B]."""
-        x0, xf, jmax = f64(x0), f64(xf), f64(jmax); B = x0.shape[0]
+        (x0, xf), jmax = self._states(x0, xf), f64(jmax).reshape(7); B = x0.shape[0]
         out, T = np.zeros((B, n_pts + 1, 22)), np.zeros(B)
         check(lib().mpcmp_jerk_trajectory_batch(self._ctx, B, dp(x0), dp(xf), dp(jmax), int(n_pts), dp(out), dp(T)), self._ctx)
         return out, T
+
+    def jerk_point(self, x0, xf, jmax, time):
+        """MotionPlanner::get_RK_point: [B][28] = q, qd, qdd, tau of the jerk-limited trajectory at min(time, duration), durations [B]."""
+        (x0, xf), jmax = self._states(x0, xf), f64(jmax).reshape(7); B = x0.shape[0]
+        time = f64(np.broadcast_to(np.asarray(time, dtype=np.float64), (B,)))
+        out, T = np.zeros((B, 28)), np.zeros(B)
+        check(lib().mpcmp_jerk_point_batch(self._ctx, B, dp(x0), dp(xf), dp(jmax), dp(time), dp(out), dp(T)), self._ctx)
+        return out, T
+
+    def mpc_point(self, sx, su, sT, time):
+        """MotionPlanner::get_MPC_point (with its clamp: time >= T -> normalised time T): [B][28] = q, qd, qdd, tau."""
+        sx, su, sT = self._traj(sx, su, sT); B = sT.shape[0]
+        time = f64(np.broadcast_to(np.asarray(time, dtype=np.float64), (B,)))
+        out = np.zeros((B, 28))
+        check(lib().mpcmp_mpc_point_batch(self._ctx, B, dp(sx), dp(su), dp(sT), dp(time), dp(out)), self._ctx)
+        return out
 
     def rnea(self, q, qd, qdd):
         q, qd, qdd = f64(q), f64(qd), f64(qdd); tau = np.zeros_like(q)
@@ -96,14 +129,17 @@ class Solver:
         return g, G
 
     def qp(self, x0, xf, xs, us, T):
-        x0, xf, xs, us, T = f64(x0), f64(xf), f64(xs), f64(us), f64(T); B = x0.shape[0]
+        x0, xf = self._states(x0, xf); B = x0.shape[0]
+        xs, us, T = self._traj(xs, us, T)
+        if T.shape[0] != B:
+            raise ValueError("linearisation point is for %d problems, states for %d" % (T.shape[0], B))
         p, y = np.zeros((B, self.n)), np.zeros((B, self.m + self.n)); it = np.zeros(B, dtype=np.int32)
         check(lib().mpcmp_qp_batch(self._ctx, B, dp(x0), dp(xf), dp(xs), dp(us), dp(T), dp(p), dp(y),
                                    it.ctypes.data_as(C.c_void_p)), self._ctx)
         return p, y, it
 
     def sample(self, sx, su, sT, n_pts=200):
-        sx, su, sT = f64(sx), f64(su), f64(sT); B = sx.shape[0]
+        sx, su, sT = self._traj(sx, su, sT); B = sx.shape[0]
         out = np.zeros((B, n_pts + 1, 29))
         check(lib().mpcmp_sample_batch(self._ctx, B, dp(sx), dp(su), dp(sT), int(n_pts), dp(out)), self._ctx)
         return out
@@ -114,7 +150,9 @@ class Solver:
                                               vp(stream or None)), self._ctx)
 
     def traj_stats(self, sx, su, sT, xf, n_pts=200):
-        sx, su, sT, xf = f64(sx), f64(su), f64(sT), f64(xf); B = sx.shape[0]
+        (sx, su, sT), xf = self._traj(sx, su, sT), f64(xf); B = sx.shape[0]
+        if xf.shape != (B, 14):
+            raise ValueError("xf must be [B][14]")
         out = np.zeros((B, 74))
         check(lib().mpcmp_traj_stats_batch(self._ctx, B, dp(sx), dp(su), dp(sT), dp(xf), int(n_pts), dp(out)), self._ctx)
         return out
@@ -162,6 +200,7 @@ class BatchMotionPlanner:
         self.margin_torque_ = self.margin_jerk_ = 1.0
         self._warm = None
         self._sol = None
+        self._rk = None
 
     # motionPlanner.cpp:56-90
     def set_constraint_margins(self, margin_position, margin_velocity, margin_acceleration, margin_torque, margin_jerk):
@@ -199,14 +238,18 @@ class BatchMotionPlanner:
     def warm_start(self, final_time, position_trajectory, velocity_trajectory, acceleration_trajectory):
         q, v, a = f64(position_trajectory), f64(velocity_trajectory), f64(acceleration_trajectory)
         nP = q.shape[1]
-        idx = np.round(capi.time_nodes(self.cfg.num_seg) * (nP - 1)).astype(int)     # motionPlanner.hpp:157
+        idx = np.floor(capi.time_nodes(self.cfg.num_seg) * (nP - 1) + 0.5).astype(int)     # std::round, motionPlanner.hpp:157
         self._warm = (np.concatenate([q[:, idx], v[:, idx]], axis=-1), a[:, idx], f64(final_time).reshape(-1))
 
     # motionPlanner.cpp:177-208
     def solve_trajectory(self, use_builtin_warm_start=True):
         B = max(self.current_state.shape[0], self.target_state.shape[0])
         x0 = np.broadcast_to(self.current_state, (B, 14)); xf = np.broadcast_to(self.target_state, (B, 14))
-        warm = None if use_builtin_warm_start else self._warm
+        if use_builtin_warm_start:      # what the reference gets from Ruckig (warm_start_RK, motionPlanner.cpp:146-175)
+            self._rk = (np.array(x0), np.array(xf))
+            warm = self._solver.warm_start_jerk(x0, xf, self.margin_jerk_ * self.limits["jmax"])     # motionPlanner.cpp:86-88
+        else:
+            warm = self._warm
         sx, su, sT, info = self._solver.solve(x0, xf, warm)
         self._sol = (sx, su, sT)
         # re-guess with exact end states (motionPlanner.cpp:199-207)
@@ -217,6 +260,22 @@ class BatchMotionPlanner:
 
     def solution(self):
         return self._sol
+
+    # motionPlanner.hpp:118-128 / 130-142
+    def get_MPC_point(self, time):
+        o = self._solver.mpc_point(*self._sol, time=time)
+        return o[:, :7], o[:, 7:14], o[:, 14:21], o[:, 21:]
+
+    def get_RK_point(self, time):
+        o, _ = self._solver.jerk_point(self._rk[0], self._rk[1], self.margin_jerk_ * self.limits["jmax"], time)
+        return o[:, :7], o[:, 7:14], o[:, 14:21], o[:, 21:]
+
+    # motionPlanner.hpp:73-96
+    def get_ruckig_trajectory(self, n_pts=200):
+        out, _ = self._solver.jerk_trajectory(self._rk[0], self._rk[1], self.margin_jerk_ * self.limits["jmax"], n_pts)
+        q, v, a = out[..., 1:8], out[..., 8:15], out[..., 15:22]
+        tau = self._solver.rnea(q.reshape(-1, 7), v.reshape(-1, 7), a.reshape(-1, 7)).reshape(q.shape)
+        return out[..., 0], q, v, a, tau
 
     # motionPlanner.hpp:99-116
     def get_MPC_trajectory(self, n_pts=200):

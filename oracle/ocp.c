@@ -76,7 +76,7 @@ void orc_default_config(orc_config *c, int num_seg, int sqp_iters) {
     c->qp_iters = 700; c->ls_iters = 10;       /* motionPlanner.cpp:16-17 */
     c->check_every = 25; c->quirk_dtau_dT = 1;
     c->eps_abs = 1e-3; c->eps_rel = 1e-3;      /* motionPlanner.cpp:19-20 */
-    c->rho = 0.1; c->sigma = 1e-6; c->alpha = 1.6; c->rho_eq_scale = 1e3;
+    c->rho = 0.02; c->sigma = 1e-6; c->alpha = 1.4; c->rho_eq_scale = 1e3;   /* chosen by tools/polympc_param_fit.py on GOLD-TRAJ (profiles/r02_polympc_param_fit.json) */
     c->ls_eta = 0.25; c->ls_tau = 0.5;
     c->hess_reg = 1e-3;                        /* polympc_redef.hpp:68 */
     c->eps_target = 1e-2;                      /* motionPlanner.hpp:44 */
@@ -425,6 +425,25 @@ void orc_solve(const orc_model *mdl, const orc_config *c, const double *x0, cons
     if (info) *info = inf;
     free(z); free(lam); free(p); free(y); free(zs); free(ce); free(gg);
     work_free(w);
+}
+
+/* Collocation defects of a node trajectory at ALL four local nodes of every segment (the NLP itself only constrains the first
+   three): out[s][i][r] = sum_j D[i][j] x_{3s+j}[r] - ts*T*f_{3s+i}[r],  f = [qd; u] (robot_ocp.hpp:55-73).
+   Used by the tests to check the discretisation (differentiation matrix, time scaling, row placement) against the reference's
+   stored solve. */
+void orc_collocation_defects(int num_seg, const double *xs, const double *us, double T, double *out) {
+    double D[16];
+    orc_diff_matrix(D);
+    const double ts = 1.0 / (2.0 * num_seg);
+    for (int s = 0; s < num_seg; s++)
+        for (int i = 0; i < 4; i++)
+            for (int r = 0; r < 14; r++) {
+                double acc = 0.0;
+                for (int j = 0; j < 4; j++) acc += D[4 * i + j] * xs[14 * (3 * s + j) + r];
+                const int k = 3 * s + i;
+                const double f = (r < 7) ? xs[14 * k + 7 + r] : us[7 * k + (r - 7)];
+                out[(s * 4 + i) * 14 + r] = acc - ts * T * f;
+            }
 }
 
 int orc_debug_qp(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,

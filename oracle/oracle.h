@@ -138,6 +138,9 @@ void orc_mpc_point(const orc_model *m, int num_seg, const double *xs, const doub
 void orc_traj_stats(const orc_model *m, int num_seg, const double *xs, const double *us, double T, const double *xf,
                     int n_pts, double *out);
 
+/* collocation defects at all four local nodes of every segment: out [num_seg][4][14] (see ocp.c) */
+void orc_collocation_defects(int num_seg, const double *xs, const double *us, double T, double *out);
+
 /* ---- pieces exposed for unit tests of the QP layer ---- */
 /* Assemble the QP of one SQP iteration at (xs,us,T,lam) and run ADMM; returns iterations used. */
 int orc_debug_qp(const orc_model *m, const orc_config *c, const double *x0, const double *xf,

@@ -39,7 +39,7 @@ INFO_DTYPE = np.dtype([("T", "f8"), ("viol_l1", "f8"), ("defect_inf", "f8"), ("p
 
 
 def build(force=False):
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("rbd.c", "ocp.c", "oracle.h", "Makefile")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("rbd.c", "ocp.c", "jerk.c", "oracle.h", "Makefile")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "liboracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -173,6 +173,12 @@ def sample(num_seg, xs, us, T, n_pts=200, model=None):
     model = model or default_model(); xs, us = f64(xs), f64(us)
     out = np.zeros((n_pts + 1, 29))
     lib().orc_sample(C.byref(model), num_seg, _p(xs), _p(us), C.c_double(T), n_pts, _p(out)); return out
+
+
+def collocation_defects(num_seg, xs, us, T):
+    """defects at all four local nodes of every segment: [num_seg][4][14]"""
+    xs, us = f64(xs), f64(us); out = np.zeros((num_seg, 4, 14))
+    lib().orc_collocation_defects(int(num_seg), _p(xs), _p(us), C.c_double(T), _p(out)); return out
 
 
 def debug_qp(cfg, x0, xf, xs, us, T, lam=None, model=None):

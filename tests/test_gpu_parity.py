@@ -120,17 +120,33 @@ def test_solve_vs_oracle(M, nseg, sqp, B):
 
 
 def test_gold_traj_scenario_on_gpu(M, golden_dir):
-    """reference-as-shipped configuration on the one stored solve of the reference (regime-level parity)."""
-    from test_oracle_ocp import rk_warm_start
+    """the one stored solve of the reference (19 nodes, 1 SQP iteration, 700-iteration QP cap) through the HIP path: warm start
+    by k_warm_jerk, solve, resample; same fitted tolerances against the stored 201 x 21 MPC samples as the oracle test
+    (tests/test_oracle_ocp.py::test_gold_traj_fit), and GPU == oracle on the same guess."""
+    from test_oracle_ocp import GOLD_FIT, jerk_warm_start
     g = json.load(open(os.path.join(golden_dir, "gold_traj.json")))
     x0 = np.array(g["q0"] + g["v0"]); xf = np.array(g["qT"] + g["vT"])
-    cfg, ocfg = _cfgs(M, 6, 2)
-    xg, ug, Tg = rk_warm_start(g, x0, 6)
+    cfg, ocfg = _cfgs(M, 6, 1)
     s = M.Solver(cfg, 1)
-    sx, su, sT, info = s.solve(x0[None], xf[None], (xg[None], ug[None], np.array([Tg])))
+    jmax = g["margins"][4] * M.default_limits()["jmax"]
+    warm = s.warm_start_jerk(x0[None], xf[None], jmax)
+    sx, su, sT, info = s.solve(x0[None], xf[None], warm)
+    assert info["qp_iters_total"][0] == 700 and info["status"][0] == 0
+    gx = sx.copy(); gx[0, 0] = x0; gx[0, -1] = xf                 # the stored samples were taken after the re-guess (motionPlanner.cpp:199-207)
+    smp = s.sample(gx, su, sT, 200)[0]
+    assert abs(sT[0] - g["T_mpc"]) < GOLD_FIT["dT"]
+    assert np.abs(smp[:, 1:8] - np.array(g["q_mpc"])).max() < GOLD_FIT["dq"]
+    assert np.abs(smp[:, 8:15] - np.array(g["v_mpc"])).max() < GOLD_FIT["dv"]
+    assert np.abs(smp[:, 15:22] - np.array(g["a_mpc"])).max() < GOLD_FIT["da"]
+    xg, ug, Tg = jerk_warm_start(g, x0, xf, 6)
     xs, us, T, oi = o.solve(ocfg, x0, xf, xg, ug, Tg)
     assert abs(sT[0] - T) < 1e-6 and np.abs(sx[0] - xs).max() < 1e-6
-    assert 1.52 < sT[0] < g["T_ruckig"] and abs(sT[0] - g["T_mpc"]) < 0.03
+    # the solver depth as shipped (2 SQP iterations, motionPlanner.cpp:15)
+    cfg2, ocfg2 = _cfgs(M, 6, 2)
+    s2 = M.Solver(cfg2, 1)
+    sx2, su2, sT2, info2 = s2.solve(x0[None], xf[None], warm)
+    xs2, us2, T2, _ = o.solve(ocfg2, x0, xf, xg, ug, Tg)
+    assert abs(sT2[0] - T2) < 1e-6 and np.abs(sx2[0] - xs2).max() < 1e-6 and 1.52 < sT2[0] < sT[0]
 
 
 def test_sample_vs_oracle(M):

@@ -6,7 +6,7 @@ import sys
 
 
 def short(name):
-    for k in ("k_qp", "k_step", "k_init", "k_sample", "k_rnea_batch", "k_eval_constraints"):
+    for k in ("k_qp3", "k_qp2", "k_qp", "k_step", "k_init", "k_warm_jerk", "k_sample", "k_rnea_batch", "k_eval_constraints"):
         if k in name:
             i = name.find("ILi")
             return k + ("<%s>" % name[i + 3:name.find("E", i)] if i >= 0 else "")
@@ -33,6 +33,6 @@ for path in sys.argv[1:]:
         crow = []
     if crow:
         print("-- counters (per-dispatch average, raw units as reported by rocprofv3)")
-        for r in crow[:24]:
+        for r in crow[:40]:
             print("%-28s %-14s dispatches=%-5d avg=%-16.1f sum=%.1f" % (short(r[0]), r[1], r[2], r[3], r[4]))
     print()
