@@ -86,12 +86,13 @@ void orc_default_config(orc_config *c, int num_seg, int sqp_iters) {
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
     int N, n, meq, min, m;      /* nodes, variables, rows */
+    int narm, nq, nx, nu, ng;   /* arms; per node: positions 7*narm, states 14*narm, controls 7*narm, path rows 8*narm */
     double ts;
     double D[16];
     /* sparse general rows */
     int    *nnz; int *col; double *val;   /* m x MAXROWNZ */
     double *ceq, *g;            /* constraint values */
-    double *Gk;                 /* N x 8 x 22 path Jacobians */
+    double *Gk;                 /* N x narm x 8 x 22 path Jacobians (one evalConstraints block per arm) */
     double *hd, *ha;            /* Hessian: diagonal (n) and arrow (n, entry T unused) */
     double *l, *u, *rho;        /* QP bounds and ADMM rho, size m+n */
     double *zlb, *zub;          /* variable boxes, size n */
@@ -100,21 +101,27 @@ typedef struct {
     double *K;                  /* n x n (permuted), overwritten by L */
 } work;
 
-static inline int IX(int k, int r) { return 14 * k + r; }
-static inline int IU(const work *w, int k, int r) { return 14 * w->N + 7 * k + r; }
-static inline int IT(const work *w) { return 21 * w->N; }
+/* Multi-arm generalisation (BASELINE.json configs[3], 14-DoF dual Panda: the same OCP, robot_ocp.hpp:38,80-163, with doubled
+   sizes NX=28, NU=14, NG=16): the "robot" is narm independent 7-joint chains on one base, state x_k = [q(7 narm); qd(7 narm)],
+   control u_k = qdd(7 narm), path rows g_k = [tau(7 narm); z_tool of every arm (narm)].  narm = 1 is the reference as is. */
+static inline int IX(const work *w, int k, int r) { return w->nx * k + r; }
+static inline int IU(const work *w, int k, int r) { return w->nx * w->N + w->nu * k + r; }
+static inline int IT(const work *w) { return (w->nx + w->nu) * w->N; }
+/* component of the per-arm limit tables (lbx/ubx: [q(7); qd(7)]) that state entry r of a node refers to */
+static inline int XCOMP(const work *w, int r) { return r < w->nq ? r % 7 : 7 + (r - w->nq) % 7; }
 
-static work *work_new(const orc_config *c) {
+static work *work_new(const orc_config *c, int narm) {
     work *w = (work *)calloc(1, sizeof(work));
     int N = w->N = orc_num_nodes(c->num_seg);
-    w->n = 21 * N + 1; w->meq = 14 * (N - 1); w->min = 8 * N; w->m = w->meq + w->min;
+    w->narm = narm; w->nq = 7 * narm; w->nx = 14 * narm; w->nu = 7 * narm; w->ng = 8 * narm;
+    w->n = (w->nx + w->nu) * N + 1; w->meq = w->nx * (N - 1); w->min = w->ng * N; w->m = w->meq + w->min;
     w->ts = 1.0 / (2.0 * c->num_seg);       /* (t_f - t_0)/(2 NUM_SEG) with set_time_limits(0,1), motionPlanner.cpp:18 */
     orc_diff_matrix(w->D);
     int n = w->n, m = w->m;
     w->nnz = (int *)calloc(m, sizeof(int)); w->col = (int *)calloc((size_t)m * MAXROWNZ, sizeof(int));
     w->val = (double *)calloc((size_t)m * MAXROWNZ, sizeof(double));
     w->ceq = (double *)calloc(w->meq, sizeof(double)); w->g = (double *)calloc(w->min, sizeof(double));
-    w->Gk = (double *)calloc((size_t)N * 8 * 22, sizeof(double));
+    w->Gk = (double *)calloc((size_t)N * narm * 8 * 22, sizeof(double));
     w->hd = (double *)calloc(n, sizeof(double)); w->ha = (double *)calloc(n, sizeof(double));
     w->l = (double *)calloc(m + n, sizeof(double)); w->u = (double *)calloc(m + n, sizeof(double));
     w->rho = (double *)calloc(m + n, sizeof(double));
@@ -122,18 +129,23 @@ static work *work_new(const orc_config *c) {
     w->perm = (int *)calloc(n, sizeof(int)); w->iperm = (int *)calloc(n, sizeof(int));
     w->first = (int *)calloc(n, sizeof(int));
     w->K = (double *)calloc((size_t)n * n, sizeof(double));
-    /* chain ordering: [x_0 | u_3s, x_3s+1, u_3s+1, x_3s+2, u_3s+2, x_3s+3 | ... | u_{N-1} | T] */
+    /* chain ordering, arm after arm (the arms couple only through T):
+       [x_0 | u_3s, x_3s+1, u_3s+1, x_3s+2, u_3s+2, x_3s+3 | ... | u_{N-1}] per arm, then T;  x_k of an arm = its q then its qd */
     int p = 0;
-    for (int r = 0; r < 14; r++) w->perm[p++] = IX(0, r);
-    for (int s = 0; s < c->num_seg; s++) {
-        for (int r = 0; r < 7; r++) w->perm[p++] = IU(w, 3 * s, r);
-        for (int i = 1; i <= 2; i++) {
-            for (int r = 0; r < 14; r++) w->perm[p++] = IX(3 * s + i, r);
-            for (int r = 0; r < 7; r++) w->perm[p++] = IU(w, 3 * s + i, r);
+    for (int a = 0; a < narm; a++) {
+#define PUSH_X(k) do { for (int r = 0; r < 7; r++) w->perm[p++] = IX(w, (k), 7 * a + r); \
+                       for (int r = 0; r < 7; r++) w->perm[p++] = IX(w, (k), w->nq + 7 * a + r); } while (0)
+#define PUSH_U(k) do { for (int r = 0; r < 7; r++) w->perm[p++] = IU(w, (k), 7 * a + r); } while (0)
+        PUSH_X(0);
+        for (int s = 0; s < c->num_seg; s++) {
+            PUSH_U(3 * s);
+            for (int i = 1; i <= 2; i++) { PUSH_X(3 * s + i); PUSH_U(3 * s + i); }
+            PUSH_X(3 * s + 3);
         }
-        for (int r = 0; r < 14; r++) w->perm[p++] = IX(3 * s + 3, r);
+        PUSH_U(N - 1);
+#undef PUSH_X
+#undef PUSH_U
     }
-    for (int r = 0; r < 7; r++) w->perm[p++] = IU(w, N - 1, r);
     w->perm[p++] = IT(w);
     for (int i = 0; i < n; i++) w->iperm[w->perm[i]] = i;
     return w;
@@ -147,15 +159,23 @@ static void work_free(work *w) {
 static void set_boxes(work *w, const orc_config *c, const double *x0, const double *xf) {
     int N = w->N;
     for (int k = 0; k < N; k++) {
-        for (int r = 0; r < 14; r++) {
-            double lo = c->lbx[r], hi = c->ubx[r];
+        for (int r = 0; r < w->nx; r++) {
+            double lo = c->lbx[XCOMP(w, r)], hi = c->ubx[XCOMP(w, r)];
             if (k == 0) { lo = hi = x0[r]; }                                           /* motionPlanner.cpp:47 */
             if (k == N - 1) { lo = xf[r] - c->eps_target; hi = xf[r] + c->eps_target; } /* motionPlanner.cpp:33 */
-            w->zlb[IX(k, r)] = lo; w->zub[IX(k, r)] = hi;
+            w->zlb[IX(w, k, r)] = lo; w->zub[IX(w, k, r)] = hi;
         }
-        for (int r = 0; r < 7; r++) { w->zlb[IU(w, k, r)] = c->lbu[r]; w->zub[IU(w, k, r)] = c->ubu[r]; }
+        for (int r = 0; r < w->nu; r++) { w->zlb[IU(w, k, r)] = c->lbu[r % 7]; w->zub[IU(w, k, r)] = c->ubu[r % 7]; }
     }
     w->zlb[IT(w)] = c->lbT; w->zub[IT(w)] = c->ubT;
+}
+
+/* [q_a; qd_a] (14) and qdd_a (7) of arm a at node k */
+static void arm_state(const work *w, const double *z, int k, int a, double *xa, double *ua) {
+    for (int j = 0; j < 7; j++) {
+        xa[j] = z[IX(w, k, 7 * a + j)]; xa[7 + j] = z[IX(w, k, w->nq + 7 * a + j)];
+        ua[j] = z[IU(w, k, 7 * a + j)];
+    }
 }
 
 /* values of all constraints at z (no derivatives): used by the line search (robot_ocp.hpp:80-96) */
@@ -163,22 +183,31 @@ static void eval_values(const orc_model *mdl, const work *w, const double *z, do
     int N = w->N; double T = z[IT(w)];
     for (int k = 0; k < N - 1; k++) {
         int s = k / 3, i = k % 3;
-        for (int r = 0; r < 14; r++) {
+        for (int r = 0; r < w->nx; r++) {
             double acc = 0.0;
-            for (int j = 0; j < 4; j++) acc += w->D[4 * i + j] * z[IX(3 * s + j, r)];
-            double f = (r < 7) ? z[IX(k, 7 + r)] : z[IU(w, k, r - 7)];   /* robot_ocp.hpp:55-73 */
-            ceq[14 * k + r] = acc - w->ts * T * f;
+            for (int j = 0; j < 4; j++) acc += w->D[4 * i + j] * z[IX(w, 3 * s + j, r)];
+            double f = (r < w->nq) ? z[IX(w, k, w->nq + r)] : z[IU(w, k, r - w->nq)];   /* robot_ocp.hpp:55-73 */
+            ceq[w->nx * k + r] = acc - w->ts * T * f;
         }
     }
-    for (int k = 0; k < N; k++) orc_eval_constraints(mdl, 0, z + IX(k, 0), z + IU(w, k, 0), g + 8 * k, 0);
+    for (int k = 0; k < N; k++)
+        for (int a = 0; a < w->narm; a++) {
+            double xa[14], ua[7], ga[8];
+            arm_state(w, z, k, a, xa, ua);
+            orc_eval_constraints(mdl + a, 0, xa, ua, ga, 0);
+            for (int j = 0; j < 7; j++) g[w->ng * k + 7 * a + j] = ga[j];
+            g[w->ng * k + w->nq + a] = ga[7];
+        }
 }
 
 static double viol(double v, double lo, double hi) { return v < lo ? lo - v : (v > hi ? v - hi : 0.0); }
+/* index into the per-arm bound tables lbg/ubg ([tau(7); z_tool]) of path row r of a node */
+static inline int GCOMP(const work *w, int r) { return r < w->nq ? r % 7 : 7; }
 
 static double l1_violation(const work *w, const orc_config *c, const double *z, const double *ceq, const double *g) {
     double s = 0.0;
     for (int i = 0; i < w->meq; i++) s += fabs(ceq[i]);
-    for (int k = 0; k < w->N; k++) for (int r = 0; r < 8; r++) s += viol(g[8 * k + r], c->lbg[r], c->ubg[r]);
+    for (int k = 0; k < w->N; k++) for (int r = 0; r < w->ng; r++) s += viol(g[w->ng * k + r], c->lbg[GCOMP(w, r)], c->ubg[GCOMP(w, r)]);
     for (int i = 0; i < w->n; i++) s += viol(z[i], w->zlb[i], w->zub[i]);
     return s;
 }
@@ -190,16 +219,16 @@ static void linearise(const orc_model *mdl, const orc_config *c, work *w, const 
     memset(w->hd, 0, sizeof(double) * n); memset(w->ha, 0, sizeof(double) * n);
     for (int k = 0; k < N - 1; k++) {
         int s = k / 3, i = k % 3;
-        for (int r = 0; r < 14; r++) {
-            int row = 14 * k + r, nz = 0;
+        for (int r = 0; r < w->nx; r++) {
+            int row = w->nx * k + r, nz = 0;
             int *col = w->col + (size_t)row * MAXROWNZ; double *val = w->val + (size_t)row * MAXROWNZ;
             double acc = 0.0;
             for (int j = 0; j < 4; j++) {
                 double d = w->D[4 * i + j];
-                acc += d * z[IX(3 * s + j, r)];
-                col[nz] = IX(3 * s + j, r); val[nz++] = d;
+                acc += d * z[IX(w, 3 * s + j, r)];
+                col[nz] = IX(w, 3 * s + j, r); val[nz++] = d;
             }
-            int fcol = (r < 7) ? IX(k, 7 + r) : IU(w, k, r - 7);
+            int fcol = (r < w->nq) ? IX(w, k, w->nq + r) : IU(w, k, r - w->nq);
             double f = z[fcol];
             col[nz] = fcol; val[nz++] = -ts * T;      /* never coincides with a D column */
             col[nz] = IT(w); val[nz++] = -ts * f;
@@ -209,22 +238,28 @@ static void linearise(const orc_model *mdl, const orc_config *c, work *w, const 
             w->ha[fcol] += -ts * lam[row];
         }
     }
-    for (int k = 0; k < N; k++) {
-        double *G = w->Gk + (size_t)k * 176;
-        orc_eval_constraints(mdl, c->quirk_dtau_dT, z + IX(k, 0), z + IU(w, k, 0), w->g + 8 * k, G);
-        for (int r = 0; r < 8; r++) {
-            int row = w->meq + 8 * k + r, nz = 0;
-            int *col = w->col + (size_t)row * MAXROWNZ; double *val = w->val + (size_t)row * MAXROWNZ;
-            if (r < 7) {
-                for (int j = 0; j < 14; j++) { col[nz] = IX(k, j); val[nz++] = G[22 * r + j]; }
-                for (int j = 0; j < 7; j++) { col[nz] = IU(w, k, j); val[nz++] = G[22 * r + 14 + j]; }
-                col[nz] = IT(w); val[nz++] = G[22 * r + 21];
-            } else {
-                for (int j = 0; j < 7; j++) { col[nz] = IX(k, j); val[nz++] = G[22 * r + j]; }
+    for (int k = 0; k < N; k++)
+        for (int a = 0; a < w->narm; a++) {
+            double *G = w->Gk + ((size_t)k * w->narm + a) * 176;
+            double xa[14], ua[7], ga[8];
+            arm_state(w, z, k, a, xa, ua);
+            orc_eval_constraints(mdl + a, c->quirk_dtau_dT, xa, ua, ga, G);
+            for (int j = 0; j < 7; j++) w->g[w->ng * k + 7 * a + j] = ga[j];
+            w->g[w->ng * k + w->nq + a] = ga[7];
+            for (int r = 0; r < 8; r++) {
+                int row = w->meq + w->ng * k + (r < 7 ? 7 * a + r : w->nq + a), nz = 0;
+                int *col = w->col + (size_t)row * MAXROWNZ; double *val = w->val + (size_t)row * MAXROWNZ;
+                if (r < 7) {
+                    for (int j = 0; j < 7; j++) { col[nz] = IX(w, k, 7 * a + j); val[nz++] = G[22 * r + j]; }
+                    for (int j = 0; j < 7; j++) { col[nz] = IX(w, k, w->nq + 7 * a + j); val[nz++] = G[22 * r + 7 + j]; }
+                    for (int j = 0; j < 7; j++) { col[nz] = IU(w, k, 7 * a + j); val[nz++] = G[22 * r + 14 + j]; }
+                    col[nz] = IT(w); val[nz++] = G[22 * r + 21];
+                } else {
+                    for (int j = 0; j < 7; j++) { col[nz] = IX(w, k, 7 * a + j); val[nz++] = G[22 * r + j]; }
+                }
+                w->nnz[row] = nz;
             }
-            w->nnz[row] = nz;
         }
-    }
     /* Gershgorin regularisation, polympc_redef.hpp:57-70 (sparse variant, +hess_reg) */
     double rT = 0.0;
     for (int i = 0; i < n - 1; i++) {
@@ -235,9 +270,9 @@ static void linearise(const orc_model *mdl, const orc_config *c, work *w, const 
     w->hd[n - 1] = rT + c->hess_reg;
     /* QP bounds in the step p */
     for (int i = 0; i < w->meq; i++) { w->l[i] = w->u[i] = -w->ceq[i]; }
-    for (int k = 0; k < N; k++) for (int r = 0; r < 8; r++) {
-        w->l[w->meq + 8 * k + r] = c->lbg[r] - w->g[8 * k + r];
-        w->u[w->meq + 8 * k + r] = c->ubg[r] - w->g[8 * k + r];
+    for (int k = 0; k < N; k++) for (int r = 0; r < w->ng; r++) {
+        w->l[w->meq + w->ng * k + r] = c->lbg[GCOMP(w, r)] - w->g[w->ng * k + r];
+        w->u[w->meq + w->ng * k + r] = c->ubg[GCOMP(w, r)] - w->g[w->ng * k + r];
     }
     for (int i = 0; i < n; i++) { w->l[w->m + i] = w->zlb[i] - z[i]; w->u[w->m + i] = w->zub[i] - z[i]; }
     /* per-row rho: OSQP rule, equality rows (l==u) scaled by rho_eq_scale */
@@ -375,12 +410,14 @@ done:
 }
 
 static void pack(const work *w, const double *xs, const double *us, double T, double *z) {
-    memcpy(z, xs, sizeof(double) * 14 * w->N); memcpy(z + 14 * w->N, us, sizeof(double) * 7 * w->N); z[21 * w->N] = T;
+    memcpy(z, xs, sizeof(double) * w->nx * w->N); memcpy(z + w->nx * w->N, us, sizeof(double) * w->nu * w->N); z[IT(w)] = T;
 }
 
-void orc_solve(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,
-               const double *xg, const double *ug, double Tg, double *xs, double *us, double *Tout, orc_info *info) {
-    work *w = work_new(c);
+/* one OCP for narm arms (narm consecutive orc_model): x0, xf [14 narm] = [q(7 narm); qd(7 narm)], xg/xs [N][14 narm],
+   ug/us [N][7 narm] */
+void orc_solve_multi(const orc_model *mdl, int narm, const orc_config *c, const double *x0, const double *xf,
+                     const double *xg, const double *ug, double Tg, double *xs, double *us, double *Tout, orc_info *info) {
+    work *w = work_new(c, narm);
     int n = w->n, m = w->m, mn = m + n;
     double *z = (double *)calloc(n, sizeof(double)), *lam = (double *)calloc(mn, sizeof(double));
     double *p = (double *)calloc(n, sizeof(double)), *y = (double *)calloc(mn, sizeof(double));
@@ -416,15 +453,20 @@ void orc_solve(const orc_model *mdl, const orc_config *c, const double *x0, cons
     inf.T = z[n - 1];
     inf.viol_l1 = l1_violation(w, c, z, w->ceq, w->g);
     inf.defect_inf = inf_norm(w->ceq, w->meq);
-    for (int k = 0; k < w->N; k++) for (int r = 0; r < 8; r++) {
-        double v = viol(w->g[8 * k + r], c->lbg[r], c->ubg[r]); if (v > inf.path_viol_inf) inf.path_viol_inf = v;
+    for (int k = 0; k < w->N; k++) for (int r = 0; r < w->ng; r++) {
+        double v = viol(w->g[w->ng * k + r], c->lbg[GCOMP(w, r)], c->ubg[GCOMP(w, r)]); if (v > inf.path_viol_inf) inf.path_viol_inf = v;
     }
-    for (int r = 0; r < 14; r++) { double d = fabs(z[IX(w->N - 1, r)] - xf[r]); if (d > inf.term_err_inf) inf.term_err_inf = d; }
+    for (int r = 0; r < w->nx; r++) { double d = fabs(z[IX(w, w->N - 1, r)] - xf[r]); if (d > inf.term_err_inf) inf.term_err_inf = d; }
     for (int k = 0; k < n; k++) if (!isfinite(z[k])) inf.status |= 1;
-    memcpy(xs, z, sizeof(double) * 14 * w->N); memcpy(us, z + 14 * w->N, sizeof(double) * 7 * w->N); *Tout = z[n - 1];
+    memcpy(xs, z, sizeof(double) * w->nx * w->N); memcpy(us, z + w->nx * w->N, sizeof(double) * w->nu * w->N); *Tout = z[n - 1];
     if (info) *info = inf;
     free(z); free(lam); free(p); free(y); free(zs); free(ce); free(gg);
     work_free(w);
+}
+
+void orc_solve(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,
+               const double *xg, const double *ug, double Tg, double *xs, double *us, double *Tout, orc_info *info) {
+    orc_solve_multi(mdl, 1, c, x0, xf, xg, ug, Tg, xs, us, Tout, info);
 }
 
 /* Collocation defects of a node trajectory at ALL four local nodes of every segment (the NLP itself only constrains the first
@@ -446,9 +488,9 @@ void orc_collocation_defects(int num_seg, const double *xs, const double *us, do
             }
 }
 
-int orc_debug_qp(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,
-                 const double *xs, const double *us, double T, const double *lam, double *p, double *y) {
-    work *w = work_new(c);
+int orc_debug_qp_multi(const orc_model *mdl, int narm, const orc_config *c, const double *x0, const double *xf,
+                       const double *xs, const double *us, double T, const double *lam, double *p, double *y) {
+    work *w = work_new(c, narm);
     double *z = (double *)calloc(w->n, sizeof(double));
     double *l0 = (double *)calloc(w->m + w->n, sizeof(double));
     pack(w, xs, us, T, z);
@@ -459,28 +501,38 @@ int orc_debug_qp(const orc_model *mdl, const orc_config *c, const double *x0, co
     return st ? -it : it;
 }
 
+int orc_debug_qp(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,
+                 const double *xs, const double *us, double T, const double *lam, double *p, double *y) {
+    return orc_debug_qp_multi(mdl, 1, c, x0, xf, xs, us, T, lam, p, y);
+}
+
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { const orc_model *m; const orc_config *c; int B, t, nt; const double *x0, *xf, *xg, *ug, *Tg;
+typedef struct { const orc_model *m; const orc_config *c; int narm, B, t, nt; const double *x0, *xf, *xg, *ug, *Tg;
                  double *xs, *us, *T; orc_info *info; } job;
 static void *job_run(void *a) {
-    job *j = (job *)a; int N = orc_num_nodes(j->c->num_seg);
+    job *j = (job *)a; int N = orc_num_nodes(j->c->num_seg); const size_t nx = 14 * (size_t)j->narm, nu = 7 * (size_t)j->narm;
     for (int b = j->t; b < j->B; b += j->nt)
-        orc_solve(j->m, j->c, j->x0 + 14 * b, j->xf + 14 * b, j->xg + (size_t)14 * N * b, j->ug + (size_t)7 * N * b, j->Tg[b],
-                  j->xs + (size_t)14 * N * b, j->us + (size_t)7 * N * b, j->T + b, j->info ? j->info + b : 0);
+        orc_solve_multi(j->m, j->narm, j->c, j->x0 + nx * b, j->xf + nx * b, j->xg + nx * N * b, j->ug + nu * N * b, j->Tg[b],
+                        j->xs + nx * N * b, j->us + nu * N * b, j->T + b, j->info ? j->info + b : 0);
     return 0;
 }
-void orc_solve_batch(const orc_model *m, const orc_config *c, int B, const double *x0, const double *xf,
-                     const double *xg, const double *ug, const double *Tg, double *xs, double *us, double *T,
-                     orc_info *info, int threads) {
+void orc_solve_batch_multi(const orc_model *m, int narm, const orc_config *c, int B, const double *x0, const double *xf,
+                           const double *xg, const double *ug, const double *Tg, double *xs, double *us, double *T,
+                           orc_info *info, int threads) {
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
     pthread_t th[256]; job jb[256];
     for (int t = 0; t < threads; t++) {
-        job j = {m, c, B, t, threads, x0, xf, xg, ug, Tg, xs, us, T, info};
+        job j = {m, c, narm, B, t, threads, x0, xf, xg, ug, Tg, xs, us, T, info};
         jb[t] = j;
         if (threads == 1) job_run(&jb[0]); else pthread_create(&th[t], 0, job_run, &jb[t]);
     }
     if (threads > 1) for (int t = 0; t < threads; t++) pthread_join(th[t], 0);
+}
+void orc_solve_batch(const orc_model *m, const orc_config *c, int B, const double *x0, const double *xf,
+                     const double *xg, const double *ug, const double *Tg, double *xs, double *us, double *T,
+                     orc_info *info, int threads) {
+    orc_solve_batch_multi(m, 1, c, B, x0, xf, xg, ug, Tg, xs, us, T, info, threads);
 }
 
 /* ------------------------------------------------------------------------------------------ */

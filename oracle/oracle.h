@@ -122,6 +122,18 @@ void orc_jerk_trajectory(const double *vmax, const double *amax, const double *j
 void orc_solve(const orc_model *m, const orc_config *c, const double *x0, const double *xf,
                const double *xg, const double *ug, double Tg,
                double *xs, double *us, double *T, orc_info *info);
+/* Multi-arm form (BASELINE.json configs[3], 14-DoF dual Panda = the same OCP with doubled sizes NX=28, NU=14, NG=16):
+ * `m` points at narm consecutive models (independent 7-joint chains on one base; the base placement of a chain is folded into
+ * its first joint placement).  x0, xf [14 narm] = [q(7 narm); qd(7 narm)]; xg, xs [N][14 narm]; ug, us [N][7 narm].
+ * The per-arm limit tables of orc_config apply to every arm.  narm = 1 is orc_solve. */
+void orc_solve_multi(const orc_model *m, int narm, const orc_config *c, const double *x0, const double *xf,
+                     const double *xg, const double *ug, double Tg,
+                     double *xs, double *us, double *T, orc_info *info);
+void orc_solve_batch_multi(const orc_model *m, int narm, const orc_config *c, int B, const double *x0, const double *xf,
+                           const double *xg, const double *ug, const double *Tg,
+                           double *xs, double *us, double *T, orc_info *info, int threads);
+int orc_debug_qp_multi(const orc_model *m, int narm, const orc_config *c, const double *x0, const double *xf,
+                       const double *xs, const double *us, double T, const double *lam, double *p, double *y);
 /* batch helper used by the cpu_baseline leg: sequential loop, or `threads` std pthreads */
 void orc_solve_batch(const orc_model *m, const orc_config *c, int B, const double *x0, const double *xf,
                      const double *xg, const double *ug, const double *Tg,

@@ -169,6 +169,85 @@ def solve_batch(cfg, x0, xf, xg, ug, Tg, threads=1, model=None):
     return xs, us, T, info
 
 
+# ---- multi-arm form (BASELINE.json configs[3]: 14-DoF dual Panda, the same OCP with doubled sizes) ----
+def arm_models(bases):
+    """ctypes array of Models: the compiled-in Panda mounted at each base = (yaw about world z, [x, y, z]); the base placement
+    is folded into the first joint placement (R0[0] <- Rz(yaw) R0[0], p[0] <- base + Rz(yaw) p[0])."""
+    arr = (Model * len(bases))()
+    for a, (yaw, xyz) in enumerate(bases):
+        m = default_model()
+        c, s = np.cos(yaw), np.sin(yaw)
+        Rz = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+        R0 = np.array(m.R0).reshape(7, 3, 3); p = np.array(m.p).reshape(7, 3)
+        R0[0] = Rz @ R0[0]; p[0] = np.asarray(xyz, dtype=np.float64) + Rz @ p[0]
+        for i in range(9):
+            m.R0[0][i] = R0[0].ravel()[i]
+        for i in range(3):
+            m.p[0][i] = p[0][i]
+        arr[a] = m
+    return arr
+
+
+DUAL_BASES = ((0.0, (0.0, 0.0, 0.0)), (np.pi, (1.0, 0.0, 0.0)))      # two Pandas facing each other, 1 m apart
+
+
+def solve_multi(models, cfg, x0, xf, xg, ug, Tg):
+    narm = len(models); N = 3 * cfg.num_seg + 1
+    x0, xf, xg, ug = f64(x0), f64(xf), f64(xg), f64(ug)
+    assert x0.shape == (14 * narm,) and xg.shape == (N, 14 * narm) and ug.shape == (N, 7 * narm)
+    xs, us, T, info = np.zeros((N, 14 * narm)), np.zeros((N, 7 * narm)), C.c_double(0), Info()
+    lib().orc_solve_multi(models, narm, C.byref(cfg), _p(x0), _p(xf), _p(xg), _p(ug), C.c_double(Tg), _p(xs), _p(us), C.byref(T), C.byref(info))
+    return xs, us, T.value, info
+
+
+def solve_batch_multi(models, cfg, x0, xf, xg, ug, Tg, threads=1):
+    narm = len(models); N = 3 * cfg.num_seg + 1
+    x0, xf, xg, ug, Tg = f64(x0), f64(xf), f64(xg), f64(ug), f64(Tg)
+    B = x0.shape[0]
+    xs, us, T = np.zeros((B, N, 14 * narm)), np.zeros((B, N, 7 * narm)), np.zeros(B)
+    info = np.zeros(B, dtype=INFO_DTYPE)
+    lib().orc_solve_batch_multi(models, narm, C.byref(cfg), B, _p(x0), _p(xf), _p(xg), _p(ug), _p(Tg), _p(xs), _p(us), _p(T),
+                                info.ctypes.data_as(C.c_void_p), int(threads))
+    return xs, us, T, info
+
+
+def debug_qp_multi(models, cfg, x0, xf, xs, us, T, lam=None):
+    narm = len(models); N = 3 * cfg.num_seg + 1
+    n, m = 21 * N * narm + 1, (14 * (N - 1) + 8 * N) * narm
+    x0, xf, xs, us = f64(x0), f64(xf), f64(xs), f64(us)
+    lam = f64(lam) if lam is not None else None
+    p, y = np.zeros(n), np.zeros(m + n)
+    lib().orc_debug_qp_multi.restype = C.c_int
+    it = lib().orc_debug_qp_multi(models, narm, C.byref(cfg), _p(x0), _p(xf), _p(xs), _p(us), C.c_double(T), _p(lam), _p(p), _p(y))
+    return p, y, it
+
+
+def merge_arm_states(xa):
+    """per-arm states [narm][14] = [q(7); qd(7)] -> the multi-arm layout [q(7 narm); qd(7 narm)]"""
+    xa = np.asarray(xa, dtype=np.float64)
+    return np.concatenate([xa[:, :7].ravel(), xa[:, 7:].ravel()])
+
+
+def warm_start_jerk_multi(num_seg, vmax, amax, jmax, x0, xf):
+    """Warm start of the multi-arm OCP from the single-arm generator: every arm's jerk-limited trajectory is computed on its own,
+    the common duration is the slowest arm's, and a faster arm's trajectory is played back uniformly slower (time scaling
+    s = T_arm / T <= 1: q(t) = q_arm(s t), qd = s qd_arm, qdd = s^2 qdd_arm — all limits still hold)."""
+    x0, xf = f64(x0), f64(xf); narm = x0.shape[0] // 14; nq = 7 * narm; N = 3 * num_seg + 1
+    per = []
+    for a in range(narm):
+        xa0 = np.concatenate([x0[7 * a:7 * a + 7], x0[nq + 7 * a:nq + 7 * a + 7]])
+        xaf = np.concatenate([xf[7 * a:7 * a + 7], xf[nq + 7 * a:nq + 7 * a + 7]])
+        per.append(warm_start_jerk(num_seg, vmax, amax, jmax, xa0, xaf))
+    T = max(p[2] for p in per)
+    xg, ug = np.zeros((N, 14 * narm)), np.zeros((N, 7 * narm))
+    for a, (xa, ua, Ta) in enumerate(per):
+        s = Ta / T
+        xg[:, 7 * a:7 * a + 7] = xa[:, :7]; xg[:, nq + 7 * a:nq + 7 * a + 7] = s * xa[:, 7:]
+        ug[:, 7 * a:7 * a + 7] = s * s * ua
+    xg[0] = x0; xg[-1] = xf                     # exact end states (motionPlanner.cpp:202-203)
+    return xg, ug, T
+
+
 def sample(num_seg, xs, us, T, n_pts=200, model=None):
     model = model or default_model(); xs, us = f64(xs), f64(us)
     out = np.zeros((n_pts + 1, 29))
