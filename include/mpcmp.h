@@ -54,7 +54,7 @@ typedef struct {
 
 /* Solver settings + bounds; replaces mpc.settings()/qp_settings()/..._bounds() (motionPlanner.cpp:15-20,56-100). */
 typedef struct {
-    int    num_seg;          /* NUM_SEG, robot_ocp.hpp:32 (4 -> 13 nodes, 6 -> 19 nodes as shipped)        */
+    int    num_seg;          /* NUM_SEG, robot_ocp.hpp:32 (4 -> 13 nodes, 6 -> 19 nodes as shipped, 8 -> 25)*/
     int    sqp_iters;        /* mpc.settings().max_iter,             motionPlanner.cpp:15 (2 as shipped)   */
     int    qp_iters;         /* mpc.qp_settings().max_iter,          motionPlanner.cpp:16 (700)            */
     int    ls_iters;         /* mpc.settings().line_search_max_iter, motionPlanner.cpp:17 (10)             */
@@ -102,6 +102,13 @@ const char *mpcmp_version(void);
 /* model == NULL -> compiled-in Panda. Allocates all device workspaces for up to max_batch problems;
  * no allocation happens in the solve calls. Fails with MPCMP_ENODEVICE when no GPU is present. */
 int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, int device, int max_batch, mpcmp_ctx **out);
+/* Multi-arm robot (BASELINE.json configs[3]: 14-DoF dual Panda): `models` points at narm (1 or 2) models — independent 7-joint
+ * chains on one base; a chain's base placement is folded into its first joint placement (mpcmp_models_from_urdf).  The OCP is
+ * the reference's (robot_ocp.hpp:31-213) with doubled sizes NX = 14 narm, NU = 7 narm, NG = 8 narm; the arms couple only
+ * through the final time.  Layouts then are x0, xf [B][14 narm] = [q(7 narm); qd(7 narm)], sol_x [B][N][14 narm],
+ * sol_u [B][N][7 narm]; the per-arm limit tables of mpcmp_config apply to every arm.  narm = 2 needs num_seg 6 or 8 and a warm
+ * start (mpcmp_warm_start_jerk_batch[_device]); the leaf / resampling entry points are single-arm only. */
+int mpcmp_create_multi(const mpcmp_config *cfg, const mpcmp_model *models, int narm, int device, int max_batch, mpcmp_ctx **out);
 int mpcmp_destroy(mpcmp_ctx *ctx);
 int mpcmp_set_config(mpcmp_ctx *ctx, const mpcmp_config *cfg);             /* num_seg must not change */
 const char *mpcmp_last_error(const mpcmp_ctx *ctx);
@@ -199,6 +206,10 @@ int mpcmp_rh_get(mpcmp_ctx *ctx, double *x0_now, double *sol_x, double *sol_u, d
  * last reset; launches = number of launches accumulated.  Event recording is OFF until the first call (a plain solve
  * records nothing and allocates nothing); afterwards at most 4096 launches are held between two calls. */
 int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name, double *ms_total, int *launches);
+
+/* diagnostics: the first `count` doubles of one workspace array of the last solve (which: 0 iterate z, 1 multipliers, 2 collocation
+ * defects c_eq, 3 path constraint values g, 4 QP step p, 5 QP duals y), in the device's internal layout */
+int mpcmp_debug_fetch(mpcmp_ctx *ctx, int which, double *out, long count);
 
 /* diagnostics: per-problem phase cycle stamps of the last k_qp launch, [B][160] (16 workgroup stamps, then
  * [16 waves][8] busy cycles per ADMM phase, then 16 stamps of the step kernel); zeros unless the library was built with -DMPCMP_STAMPS (tools/stamps.py). */

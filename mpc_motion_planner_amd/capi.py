@@ -44,13 +44,13 @@ INFO_DTYPE = np.dtype([("T", "f8"), ("viol_l1", "f8"), ("defect_inf", "f8"), ("p
 # every symbol include/mpcmp.h declares (the CPU test suite checks the library exports all of them)
 SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_default_limits", "mpcmp_default_config",
            "mpcmp_set_margins", "mpcmp_set_min_height", "mpcmp_num_nodes", "mpcmp_time_nodes", "mpcmp_version",
-           "mpcmp_create", "mpcmp_destroy", "mpcmp_set_config", "mpcmp_last_error", "mpcmp_solve_batch",
+           "mpcmp_create", "mpcmp_create_multi", "mpcmp_destroy", "mpcmp_set_config", "mpcmp_last_error", "mpcmp_solve_batch",
            "mpcmp_solve_batch_device", "mpcmp_warm_start_batch", "mpcmp_rnea_batch",
            "mpcmp_eval_constraints_batch", "mpcmp_qp_batch", "mpcmp_sample_batch", "mpcmp_sample_batch_device",
            "mpcmp_kernel_timing", "mpcmp_debug_stamps", "mpcmp_rh_init", "mpcmp_rh_run", "mpcmp_rh_get", "mpcmp_traj_stats_batch",
            "mpcmp_tool_jacobian", "mpcmp_forward_velocities", "mpcmp_inverse_velocities", "mpcmp_inverse_kinematics",
            "mpcmp_warm_start_jerk_batch", "mpcmp_warm_start_jerk_batch_device", "mpcmp_jerk_trajectory_batch",
-           "mpcmp_jerk_point_batch", "mpcmp_mpc_point_batch"]
+           "mpcmp_jerk_point_batch", "mpcmp_mpc_point_batch", "mpcmp_debug_fetch"]
 
 
 def library_path():
@@ -60,7 +60,7 @@ def library_path():
 def build_library(force=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "qp_kernel_v2.hpp", "rbd_device.hpp", "structure.hpp",
+    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "qp_kernel_v2.hpp", "qp_kernel_v3.hpp", "structure3.hpp", "rbd_device.hpp", "structure.hpp", "multi_kernels.hpp",
                                            "kinematics_host.hpp", "jerk_device.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "mpcmp.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
@@ -101,6 +101,26 @@ def f64(a):
 
 def default_model():
     m = Model(); check(lib().mpcmp_default_model(C.byref(m))); return m
+
+
+def arm_models(bases, model=None):
+    """ctypes array of Models for a multi-arm robot: `model` (default: the compiled-in Panda) mounted at every base =
+    (yaw about world z, [x, y, z]); the base placement is folded into the first joint placement."""
+    arr = (Model * len(bases))()
+    for a, (yaw, xyz) in enumerate(bases):
+        m = Model.from_buffer_copy(model if model is not None else default_model())
+        c, s = np.cos(yaw), np.sin(yaw)
+        Rz = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+        R0 = Rz @ np.array(m.R0[0][:]).reshape(3, 3); p0 = np.asarray(xyz, dtype=np.float64) + Rz @ np.array(m.p[0][:])
+        for i in range(9):
+            m.R0[0][i] = R0.ravel()[i]
+        for i in range(3):
+            m.p[0][i] = p0[i]
+        arr[a] = m
+    return arr
+
+
+DUAL_BASES = ((0.0, (0.0, 0.0, 0.0)), (np.pi, (1.0, 0.0, 0.0)))      # two Pandas facing each other, 1 m apart (configs[3] stand-in)
 
 
 def model_from_urdf(path):

@@ -15,6 +15,8 @@
 #include "../../include/mpcmp.h"
 #include "solver_kernels.hpp"
 #include "qp_kernel_v2.hpp"
+#include "qp_kernel_v3.hpp"
+#include "multi_kernels.hpp"
 #include "kinematics_host.hpp"
 #include "jerk_device.hpp"
 
@@ -22,14 +24,15 @@ using namespace mpcmp;
 
 struct mpcmp_ctx {
     mpcmp_config cfg;
-    int device = 0, max_batch = 0, nseg = 0;
-    int N = 0, n = 0, meq = 0, m = 0, mn = 0;
+    int device = 0, max_batch = 0, nseg = 0, narm = 1;
+    int N = 0, n = 0, meq = 0, m = 0, mn = 0;      // of the whole OCP (all arms): n = 21 N narm + 1, meq = 14 (N-1) narm, m = meq + 8 N narm
+    int nx = 14, nu = 7;                           // state / control entries per node: 14 narm, 7 narm
     std::string err;
     hipStream_t stream = nullptr;
     hipStream_t stream_x[3] = {nullptr, nullptr, nullptr};   // further parts of a large solve (see solve_impl)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // device buffers
-    mpcmp_model *d_model = nullptr;
+    mpcmp_model *d_model = nullptr;   // [narm]
     mpcmp_model model;             // host copy: passed by value to the kernels that run the rigid-body recursions
     int *d_ext_of_int = nullptr, *d_entry_ptr = nullptr;
     uint32_t *d_terms = nullptr;
@@ -38,9 +41,12 @@ struct mpcmp_ctx {
     // host-API staging (device side)
     double *d_x0 = nullptr, *d_xf = nullptr, *d_wx = nullptr, *d_wu = nullptr, *d_wT = nullptr;
     double *d_sx = nullptr, *d_su = nullptr, *d_sT = nullptr;
+    double *d_ax0 = nullptr, *d_axf = nullptr, *d_awx = nullptr, *d_awu = nullptr, *d_awT = nullptr;   // multi-arm warm start staging
     mpcmp_info *d_info = nullptr;
     uint32_t *d_stream = nullptr;
     Qp2Streams streams{};
+    Qp3Pat pat{};                  // sparse K_JC pattern of k_qp3 (num_seg 6, 8)
+    Xch xch{nullptr};              // arm-to-arm exchange slots (multi-arm contexts)
     // timing of the dominant kernel (k_qp)
     struct EvPair { hipEvent_t e[2]; };
     std::vector<EvPair> ev;          // at most MAX_EV pairs are ever created; launches beyond that are not timed until the
@@ -381,7 +387,7 @@ static int dalloc(mpcmp_ctx *ctx, T **p, size_t count) {
 }
 
 static int validate(const mpcmp_config *c, std::string &err) {
-    if (c->num_seg != 1 && c->num_seg != 2 && c->num_seg != 4 && c->num_seg != 6) { err = "num_seg must be 1, 2, 4 or 6 on the HIP backend"; return MPCMP_EINVAL; }
+    if (c->num_seg != 1 && c->num_seg != 2 && c->num_seg != 4 && c->num_seg != 6 && c->num_seg != 8) { err = "num_seg must be 1, 2, 4, 6 or 8 on the HIP backend"; return MPCMP_EINVAL; }
     if (c->sqp_iters < 1 || c->qp_iters < 1 || c->check_every < 1) { err = "iteration counts must be >= 1"; return MPCMP_EINVAL; }
     if (c->ls_iters < 2 || c->ls_iters > 10) { err = "ls_iters must be in [2,10]"; return MPCMP_EINVAL; }
     if (!(c->rho > 0) || !(c->sigma > 0) || !(c->alpha > 0 && c->alpha < 2)) { err = "rho, sigma > 0 and 0 < alpha < 2 required"; return MPCMP_EINVAL; }
@@ -405,19 +411,38 @@ extern "C" int mpcmp_destroy(mpcmp_ctx *ctx) {
     return MPCMP_OK;
 }
 
+static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int narm, int device, int max_batch, mpcmp_ctx **out);
+
 extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, int device, int max_batch, mpcmp_ctx **out) {
+    return create_impl(cfg, model, 1, device, max_batch, out);
+}
+
+// Multi-arm robot: `models` points at narm models (independent 7-joint chains on one base; a chain's base placement is folded
+// into its first joint placement).  The OCP is the reference's (robot_ocp.hpp:31-213) with NX = 14 narm, NU = 7 narm,
+// NG = 8 narm; the arms couple only through the final time.  BASELINE.json configs[3]: narm = 2, num_seg = 8.
+extern "C" int mpcmp_create_multi(const mpcmp_config *cfg, const mpcmp_model *models, int narm, int device, int max_batch, mpcmp_ctx **out) {
+    if (narm < 1 || narm > 2 || (narm > 1 && !models)) { g_err = "narm must be 1 or 2 (with narm models)"; return MPCMP_EINVAL; }
+    return create_impl(cfg, models, narm, device, max_batch, out);
+}
+
+static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int narm, int device, int max_batch, mpcmp_ctx **out) {
     if (!cfg || !out || max_batch < 1) return MPCMP_EINVAL;
     *out = nullptr;
     if (int rc = validate(cfg, g_err)) return rc;
+    if (narm == 2) {
+        if (cfg->num_seg != 6 && cfg->num_seg != 8) { g_err = "multi-arm OCPs need num_seg 6 or 8 (k_qp3)"; return MPCMP_EINVAL; }
+        if (8 + cfg->qp_iters + 1 + 8 * (cfg->qp_iters / cfg->check_every + 1) > MPCMP_XCH_STRIDE) { g_err = "multi-arm OCPs: qp_iters too large for the exchange slots"; return MPCMP_EINVAL; }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device >= ndev) {
         g_err = "no HIP device available: the mpcmp product path has no CPU fallback";
         return MPCMP_ENODEVICE;
     }
     mpcmp_ctx *ctx = new mpcmp_ctx();
-    ctx->cfg = *cfg; ctx->device = device; ctx->max_batch = max_batch; ctx->nseg = cfg->num_seg;
-    ctx->N = 3 * cfg->num_seg + 1; ctx->n = 21 * ctx->N + 1; ctx->meq = 14 * (ctx->N - 1);
-    ctx->m = ctx->meq + 8 * ctx->N; ctx->mn = ctx->m + ctx->n;
+    ctx->cfg = *cfg; ctx->device = device; ctx->max_batch = max_batch; ctx->nseg = cfg->num_seg; ctx->narm = narm;
+    ctx->nx = 14 * narm; ctx->nu = 7 * narm;
+    ctx->N = 3 * cfg->num_seg + 1; ctx->n = 21 * ctx->N * narm + 1; ctx->meq = 14 * (ctx->N - 1) * narm;
+    ctx->m = ctx->meq + 8 * ctx->N * narm; ctx->mn = ctx->m + ctx->n;
     auto fail = [&](int rc) { g_err = ctx->err; mpcmp_destroy(ctx); return rc; };
 #define TRY(x) do { int rc_ = (x); if (rc_) return fail(rc_); } while (0)
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return fail(MPCMP_ERUNTIME); } } while (0)
@@ -428,13 +453,18 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
         HIPTRY(hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
     }
     HIPTRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    mpcmp_model mdl;
-    if (model) mdl = *model; else mpcmp_default_model(&mdl);
-    TRY(dalloc(ctx, &ctx->d_model, 1));
-    HIPTRY(hipMemcpy(ctx->d_model, &mdl, sizeof mdl, hipMemcpyHostToDevice));
-    ctx->model = mdl;
+    mpcmp_model mdl[2];
+    for (int a = 0; a < narm; a++) { if (model) mdl[a] = model[a]; else mpcmp_default_model(&mdl[a]); }
+    TRY(dalloc(ctx, &ctx->d_model, narm));
+    HIPTRY(hipMemcpy(ctx->d_model, mdl, sizeof(mpcmp_model) * narm, hipMemcpyHostToDevice));
+    ctx->model = mdl[0];
     StructureTables tab;
-    if (!build_tables(cfg->num_seg, tab)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
+    if (cfg->num_seg >= 6) {        // k_qp3: per-arm tables with T bordered out (structure3.hpp)
+        Tables3 t3;
+        if (!build_tables3(cfg->num_seg, t3)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
+        tab.nseg = t3.nseg; tab.ext_of_int = t3.ext_of_int; tab.entry_ptr = t3.entry_ptr; tab.terms = t3.terms;
+        ctx->pat = t3.pat;
+    } else if (!build_tables(cfg->num_seg, tab)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
     TRY(dalloc(ctx, &ctx->d_ext_of_int, tab.ext_of_int.size()));
     TRY(dalloc(ctx, &ctx->d_entry_ptr, tab.entry_ptr.size()));
     TRY(dalloc(ctx, &ctx->d_terms, tab.terms.size()));
@@ -445,14 +475,21 @@ extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, i
     WS &w = ctx->ws;
     w.model = ctx->d_model; w.ext_of_int = ctx->d_ext_of_int; w.entry_ptr = ctx->d_entry_ptr; w.terms = ctx->d_terms;
     TRY(dalloc(ctx, &w.z, B * n)); TRY(dalloc(ctx, &w.lam, B * mn)); TRY(dalloc(ctx, &w.ceq, B * ctx->meq));
-    TRY(dalloc(ctx, &w.g, B * 8 * N)); TRY(dalloc(ctx, &w.Gk, B * N * 176)); TRY(dalloc(ctx, &w.p, B * n));
+    TRY(dalloc(ctx, &w.g, B * 8 * N * narm)); TRY(dalloc(ctx, &w.Gk, B * N * 176 * narm)); TRY(dalloc(ctx, &w.p, B * n));
     TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.perm, B)); TRY(dalloc(ctx, &w.okey, B)); TRY(dalloc(ctx, &w.done, 4));
     HIPTRY(hipMemset(w.done, 0, 4 * sizeof(int))); TRY(dalloc(ctx, &w.qp_total, B));
     TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, (size_t)B * MPCMP_DBG_WORDS));
-    TRY(dalloc(ctx, &ctx->d_x0, B * 14)); TRY(dalloc(ctx, &ctx->d_xf, B * 14));
-    TRY(dalloc(ctx, &ctx->d_wx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_wu, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
-    TRY(dalloc(ctx, &ctx->d_sx, B * 14 * N)); TRY(dalloc(ctx, &ctx->d_su, B * 7 * N)); TRY(dalloc(ctx, &ctx->d_sT, B));
+    const size_t nx = ctx->nx, nu = ctx->nu;
+    TRY(dalloc(ctx, &ctx->d_x0, B * nx)); TRY(dalloc(ctx, &ctx->d_xf, B * nx));
+    TRY(dalloc(ctx, &ctx->d_wx, B * nx * N)); TRY(dalloc(ctx, &ctx->d_wu, B * nu * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
+    TRY(dalloc(ctx, &ctx->d_sx, B * nx * N)); TRY(dalloc(ctx, &ctx->d_su, B * nu * N)); TRY(dalloc(ctx, &ctx->d_sT, B));
     TRY(dalloc(ctx, &ctx->d_info, B));
+    if (narm == 2) {
+        TRY(dalloc(ctx, &ctx->xch.buf, B * 2 * MPCMP_XCH_STRIDE));
+        // per-arm staging of the warm-start generator: states, node trajectories, durations of B * narm arm problems
+        TRY(dalloc(ctx, &ctx->d_ax0, B * nx)); TRY(dalloc(ctx, &ctx->d_axf, B * nx));
+        TRY(dalloc(ctx, &ctx->d_awx, B * nx * N)); TRY(dalloc(ctx, &ctx->d_awu, B * nu * N)); TRY(dalloc(ctx, &ctx->d_awT, B * narm));
+    }
     if (cfg->num_seg == 2 || cfg->num_seg == 4) {
         AsmStreams as;
         const int GS = cfg->num_seg == 4 ? Qp2<4>::GS : Qp2<2>::GS, RSv = Qp2<4>::RS;
@@ -506,15 +543,18 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     using D = Dim<NSEG>;
     WS w = ctx->ws;
     w.x0 = d_x0; w.xf = d_xf;
-    const size_t l_init = InitLds<NSEG>::size * sizeof(double), l_qp = QpLds<NSEG>::size * sizeof(double),
+    const size_t l_init = InitLds<NSEG>::size * sizeof(double), l_qp = QpLds<(NSEG >= 6) ? 1 : NSEG>::size * sizeof(double),
                  l_step = StepLds<NSEG>::size * sizeof(double);
     if (int rc = set_lds(ctx, k_init<NSEG>, l_init)) return rc;
     static const bool force_v1 = std::getenv("MPCMP_FORCE_V1") != nullptr;   // diagnostics: generic kernel everywhere
     constexpr bool V2C = (NSEG == 2 || NSEG == 4);      // role-specialised 1024-thread QP kernel
+    constexpr bool V3C = (NSEG >= 6);                   // k_qp3: T bordered out, E-free interior solve (N = 19, 25)
     const bool V2 = V2C && !force_v1;
+    const size_t l_qp3 = Qp3<V3C ? NSEG : 6>::size * sizeof(double);
+    if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3C ? NSEG : 6, 1>, l_qp3)) return rc; }
     const size_t l_qp2 = Qp2<V2C ? NSEG : 4>::size * sizeof(double);
     if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
-    else if (int rc = set_lds(ctx, k_qp<NSEG>, l_qp)) return rc;
+    else if (!V3C) { if (int rc = set_lds(ctx, k_qp<V3C ? 1 : NSEG>, l_qp)) return rc; }
     if (int rc = set_lds(ctx, k_step<NSEG>, l_step)) return rc;
     // A large batch is solved as two half-batches on two streams.  Every SQP iteration is a chain of dependent launches
     // (QP -> order -> step), and a QP launch ends in a tail in which most CUs are idle (its problems run 25..700 ADMM
@@ -551,8 +591,9 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         for (int h = 0; h < nhalf; h++) {
             hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
             if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
-            if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(Bh[h]), dim3(1024), l_qp2, sh[h], ctx->cfg, wh[h], ctx->streams);
-            else hipLaunchKernelGGL(k_qp<NSEG>, dim3(Bh[h]), dim3(D::NT), l_qp, sh[h], ctx->cfg, wh[h]);
+            if (V3C) hipLaunchKernelGGL((k_qp3<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->pat, ctx->xch, Bh[h]);
+            else if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(Bh[h]), dim3(1024), l_qp2, sh[h], ctx->cfg, wh[h], ctx->streams);
+            else hipLaunchKernelGGL((k_qp<V3C ? 1 : NSEG>), dim3(Bh[h]), dim3(Dim<V3C ? 1 : NSEG>::NT), l_qp, sh[h], ctx->cfg, wh[h]);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;
             hipLaunchKernelGGL(k_step<NSEG>, dim3(Bh[h]), dim3(D::NT), l_step, sh[h], ctx->cfg, ctx->model, wh[h], it == iters - 1 ? 1 : 0, it,
@@ -560,6 +601,64 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         }
     }
     for (int h = 1; h < nhalf; h++) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[h - 1], sh[h])); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join[h - 1], 0)); }
+    HIPCHK(ctx, hipGetLastError());
+    return MPCMP_OK;
+}
+
+// N = 25 and multi-arm OCPs: k_init_m -> K x [k_qp3 (one workgroup per arm), k_step_m]
+template <int NSEG, int NARM>
+static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_wx, const double *d_wu,
+                        const double *d_wT, double *d_sx, double *d_su, double *d_sT, mpcmp_info *d_info, hipStream_t st,
+                        int only_qp, int reguess) {
+    using D = DimM<NSEG, NARM>;
+    constexpr int N = D::N;
+    WS w = ctx->ws;
+    w.x0 = d_x0; w.xf = d_xf;
+    const size_t l_m = D::size * sizeof(double), l_qp3 = Qp3<NSEG>::size * sizeof(double);
+    if (int rc = set_lds(ctx, k_init_m<NSEG, NARM>, l_m)) return rc;
+    if (int rc = set_lds(ctx, k_step_m<NSEG, NARM>, l_m)) return rc;
+    if (int rc = set_lds(ctx, k_qp3<NSEG, NARM>, l_qp3)) return rc;
+    // two parts on two streams once one part alone fills the chip (one CU per arm): see solve_impl
+    static const bool single_stream = std::getenv("MPCMP_SINGLE_STREAM") != nullptr;
+    const bool dual = !single_stream && !only_qp && B * NARM >= 512;
+    const int nhalf = dual ? 2 : 1;
+    int Bh[2] = {0, 0}, boff[2] = {0, 0};
+    for (int h = 0, acc = 0; h < nhalf; h++) { Bh[h] = (B - acc + (nhalf - h) - 1) / (nhalf - h); boff[h] = acc; acc += Bh[h]; }
+    hipStream_t sh[2] = {st, ctx->stream_x[0]};
+    WS wh[2];
+    Xch xh[2];
+    const double *hx[2] = {nullptr, nullptr}, *hu[2] = {nullptr, nullptr}, *hT[2] = {nullptr, nullptr};
+    double *ox[2], *ou[2], *oT[2];
+    mpcmp_info *oi[2];
+    for (int h = 0; h < nhalf; h++) {
+        const size_t b0 = (size_t)boff[h];
+        WS v = w;
+        v.x0 += 14 * NARM * b0; v.xf += 14 * NARM * b0; v.z += D::n * b0; v.lam += D::mn * b0; v.ceq += (size_t)NARM * D::meq * b0;
+        v.g += (size_t)NARM * 8 * N * b0; v.Gk += (size_t)NARM * N * 176 * b0; v.p += D::n * b0; v.y += D::mn * b0; v.qpit += b0; v.perm += b0;
+        v.okey += b0; v.done += h; v.qp_total += b0; v.status += b0; v.alpha += b0; v.dbg += (size_t)MPCMP_DBG_WORDS * b0;
+        wh[h] = v;
+        xh[h].buf = ctx->xch.buf ? ctx->xch.buf + (size_t)2 * MPCMP_XCH_STRIDE * b0 : nullptr;
+        if (d_wx) { hx[h] = d_wx + (size_t)14 * NARM * N * b0; hu[h] = d_wu + (size_t)7 * NARM * N * b0; hT[h] = d_wT + b0; }
+        ox[h] = d_sx ? d_sx + (size_t)14 * NARM * N * b0 : nullptr; ou[h] = d_su ? d_su + (size_t)7 * NARM * N * b0 : nullptr;
+        oT[h] = d_sT ? d_sT + b0 : nullptr; oi[h] = d_info ? d_info + b0 : nullptr;
+    }
+    if (nhalf > 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st)); HIPCHK(ctx, hipStreamWaitEvent(sh[1], ctx->ev_fork, 0)); }
+    for (int h = 0; h < nhalf; h++)
+        hipLaunchKernelGGL((k_init_m<NSEG, NARM>), dim3(Bh[h]), dim3(D::NT), l_m, sh[h], ctx->cfg, ctx->d_model, wh[h], xh[h], hx[h], hu[h], hT[h], reguess);
+    const int iters = only_qp ? 1 : ctx->cfg.sqp_iters;
+    for (int it = 0; it < iters; it++) {
+        for (int h = 0; h < nhalf; h++) {
+            hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
+            if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
+            const int grid = NARM == 1 ? Bh[h] : ((Bh[h] + 7) / 8) * 16;       // arm workgroups of one OCP are 8 apart (k_qp3)
+            hipLaunchKernelGGL((k_qp3<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->pat, xh[h], Bh[h]);
+            if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
+            if (only_qp) continue;
+            hipLaunchKernelGGL((k_step_m<NSEG, NARM>), dim3(Bh[h]), dim3(D::NT), l_m, sh[h], ctx->cfg, ctx->d_model, wh[h], xh[h],
+                               it == iters - 1 ? 1 : 0, it, ox[h], ou[h], oT[h], oi[h]);
+        }
+    }
+    if (nhalf > 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], sh[1])); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join[0], 0)); }
     HIPCHK(ctx, hipGetLastError());
     return MPCMP_OK;
 }
@@ -573,11 +672,18 @@ static int solve_dispatch(mpcmp_ctx *ctx, int B, const double *d_x0, const doubl
     if (!d_x0 || !d_xf) return MPCMP_EINVAL;
     if ((d_wx != nullptr) != (d_wu != nullptr) || (d_wx != nullptr) != (d_wT != nullptr)) { ctx->err = "warm_x, warm_u, warm_T must be all given or all NULL"; return MPCMP_EINVAL; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->narm == 2) {
+        if (only_qp) { ctx->err = "mpcmp_qp_batch is defined for single-arm contexts only"; return MPCMP_EINVAL; }
+        if (!d_wx) { ctx->err = "multi-arm solves need a warm start (mpcmp_warm_start_jerk_batch)"; return MPCMP_EINVAL; }
+        if (ctx->nseg == 6) return solve_impl_m<6, 2>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
+        return solve_impl_m<8, 2>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
+    }
     switch (ctx->nseg) {
         case 1: return solve_impl<1>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
         case 2: return solve_impl<2>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
         case 4: return solve_impl<4>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
         case 6: return solve_impl<6>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
+        case 8: return solve_impl_m<8, 1>(ctx, B, d_x0, d_xf, d_wx, d_wu, d_wT, d_sx, d_su, d_sT, d_info, st, only_qp, reguess);
     }
     return MPCMP_EINVAL;
 }
@@ -595,29 +701,32 @@ extern "C" int mpcmp_solve_batch(mpcmp_ctx *ctx, int B, const double *x0, const 
     if (B < 1) return MPCMP_EINVAL;
     if (B > ctx->max_batch) { ctx->err = "batch exceeds the context capacity"; return MPCMP_ETOOBIG; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t N = ctx->N;
+    const size_t N = ctx->N, nx = ctx->nx, nu = ctx->nu;
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * nx * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * nx * B, hipMemcpyHostToDevice, st));
     const bool warm = wx && wu && wT;
     if (warm) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_wx, wx, sizeof(double) * 14 * N * B, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_wu, wu, sizeof(double) * 7 * N * B, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_wx, wx, sizeof(double) * nx * N * B, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_wu, wu, sizeof(double) * nu * N * B, hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_wT, wT, sizeof(double) * B, hipMemcpyHostToDevice, st));
     } else if (wx || wu || wT) { ctx->err = "warm_x, warm_u, warm_T must be all given or all NULL"; return MPCMP_EINVAL; }
     if (int rc = solve_dispatch(ctx, B, ctx->d_x0, ctx->d_xf, warm ? ctx->d_wx : nullptr, warm ? ctx->d_wu : nullptr,
                                 warm ? ctx->d_wT : nullptr, ctx->d_sx, ctx->d_su, ctx->d_sT, ctx->d_info, st, 0))
         return rc;
-    HIPCHK(ctx, hipMemcpyAsync(sx, ctx->d_sx, sizeof(double) * 14 * N * B, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(su, ctx->d_su, sizeof(double) * 7 * N * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(sx, ctx->d_sx, sizeof(double) * nx * N * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(su, ctx->d_su, sizeof(double) * nu * N * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(sT, ctx->d_sT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     if (info) HIPCHK(ctx, hipMemcpyAsync(info, ctx->d_info, sizeof(mpcmp_info) * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return MPCMP_OK;
 }
 
+#define SINGLE_ARM_ONLY(ctx) do { if ((ctx)->narm != 1) { (ctx)->err = "this entry point is defined for single-arm contexts only"; return MPCMP_EINVAL; } } while (0)
+
 extern "C" int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, double *wx, double *wu, double *wT) {
     if (!ctx || !x0 || !xf || !wx || !wu || !wT || B < 1) return MPCMP_EINVAL;
+    SINGLE_ARM_ONLY(ctx);
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t N = ctx->N, n = ctx->n;
@@ -630,7 +739,9 @@ extern "C" int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, c
     int rc = MPCMP_OK;
 #define LAUNCH_INIT(NS) { size_t l = InitLds<NS>::size * sizeof(double); rc = set_lds(ctx, k_init<NS>, l); \
         if (!rc) hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, ctx->model, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); }
-    switch (ctx->nseg) { case 1: LAUNCH_INIT(1) break; case 2: LAUNCH_INIT(2) break; case 4: LAUNCH_INIT(4) break; case 6: LAUNCH_INIT(6) break; }
+    switch (ctx->nseg) { case 1: LAUNCH_INIT(1) break; case 2: LAUNCH_INIT(2) break; case 4: LAUNCH_INIT(4) break; case 6: LAUNCH_INIT(6) break;
+        case 8: { const size_t l = DimM<8, 1>::size * sizeof(double); rc = set_lds(ctx, k_init_m<8, 1>, l);
+                  if (!rc) hipLaunchKernelGGL((k_init_m<8, 1>), dim3(B), dim3(512), l, st, save, ctx->d_model, w, ctx->xch, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); } break; }
 #undef LAUNCH_INIT
     if (rc) return rc;
     HIPCHK(ctx, hipGetLastError());
@@ -686,6 +797,18 @@ extern "C" int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const d
     HIPCHK(ctx, hipSetDevice(ctx->device));
     JerkLimits lim;
     if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
+    if (ctx->narm == 2) {
+        // per-arm generator on B * narm arm problems, then the merge to the common (slowest arm's) duration: multi_kernels.hpp
+        if (B > ctx->max_batch) return MPCMP_ETOOBIG;
+        hipStream_t s2 = (hipStream_t)hip_stream;
+        const int cnt = B * 2 * 14;
+        hipLaunchKernelGGL((k_split_states<2>), dim3((cnt + 255) / 256), dim3(256), 0, s2, B, d_x0, ctx->d_ax0);
+        hipLaunchKernelGGL((k_split_states<2>), dim3((cnt + 255) / 256), dim3(256), 0, s2, B, d_xf, ctx->d_axf);
+        hipLaunchKernelGGL(k_warm_jerk, dim3(B * 2), dim3(64), 0, s2, ctx->nseg, lim, ctx->d_ax0, ctx->d_axf, ctx->d_awx, ctx->d_awu, ctx->d_awT);
+        hipLaunchKernelGGL((k_warm_merge<2>), dim3(B), dim3(256), 0, s2, ctx->N, B, ctx->d_awx, ctx->d_awu, ctx->d_awT, d_x0, d_xf, d_wx, d_wu, d_wT);
+        HIPCHK(ctx, hipGetLastError());
+        return MPCMP_OK;
+    }
     // the stream exactly as given (NULL = the legacy default stream), like the other *_device entry points: the solve that
     // consumes the warm start is enqueued on the same stream and is ordered behind this launch
     hipLaunchKernelGGL(k_warm_jerk, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, ctx->nseg, lim, d_x0, d_xf, d_wx, d_wu, d_wT);
@@ -698,13 +821,13 @@ extern "C" int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *
     if (!ctx || !x0 || !xf || !jmax || !wx || !wu || !wT || B < 1) return MPCMP_EINVAL;
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t N = ctx->N;
+    const size_t N = ctx->N, nx = ctx->nx, nu = ctx->nu;
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * nx * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * nx * B, hipMemcpyHostToDevice, st));
     if (int rc = mpcmp_warm_start_jerk_batch_device(ctx, B, ctx->d_x0, ctx->d_xf, jmax, ctx->d_wx, ctx->d_wu, ctx->d_wT, st)) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(wx, ctx->d_wx, sizeof(double) * 14 * N * B, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(wu, ctx->d_wu, sizeof(double) * 7 * N * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(wx, ctx->d_wx, sizeof(double) * nx * N * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(wu, ctx->d_wu, sizeof(double) * nu * N * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(wT, ctx->d_wT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return MPCMP_OK;
@@ -713,6 +836,7 @@ extern "C" int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *
 extern "C" int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, int n_pts,
                                            double *out, double *T_out) {
     if (!ctx || !x0 || !xf || !jmax || !out || B < 1 || n_pts < 1) return MPCMP_EINVAL;
+    SINGLE_ARM_ONLY(ctx);
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     JerkLimits lim;
@@ -736,6 +860,7 @@ extern "C" int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *
 extern "C" int mpcmp_jerk_point_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, const double *time,
                                       double *out, double *T_out) {
     if (!ctx || !x0 || !xf || !jmax || !time || !out || B < 1) return MPCMP_EINVAL;
+    SINGLE_ARM_ONLY(ctx);
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     JerkLimits lim;
@@ -759,6 +884,7 @@ extern "C" int mpcmp_jerk_point_batch(mpcmp_ctx *ctx, int B, const double *x0, c
 extern "C" int mpcmp_mpc_point_batch(mpcmp_ctx *ctx, int B, const double *sx, const double *su, const double *sT, const double *time,
                                      double *out) {
     if (!ctx || !sx || !su || !sT || !time || !out || B < 1) return MPCMP_EINVAL;
+    SINGLE_ARM_ONLY(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t N = ctx->N;
     TmpBuf tb(ctx, (21 * N + 2 + 28) * (size_t)B * sizeof(double));
@@ -780,6 +906,7 @@ extern "C" int mpcmp_mpc_point_batch(mpcmp_ctx *ctx, int B, const double *sx, co
 extern "C" int mpcmp_qp_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *xs,
                               const double *us, const double *T, double *p, double *y, int *iters) {
     if (!ctx || !x0 || !xf || !xs || !us || !T || !p || !y || B < 1) return MPCMP_EINVAL;
+    SINGLE_ARM_ONLY(ctx);
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t N = ctx->N;
@@ -842,6 +969,7 @@ extern "C" int mpcmp_eval_constraints_batch(mpcmp_ctx *ctx, int n, const double 
 extern "C" int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sx, const double *d_su, const double *d_sT,
                                          int n_pts, double *d_out, void *hip_stream) {
     if (!ctx || B < 1 || n_pts < 1 || !d_sx || !d_su || !d_sT || !d_out) return MPCMP_EINVAL;
+    SINGLE_ARM_ONLY(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const long total = (long)B * (n_pts + 1);
     hipLaunchKernelGGL(k_sample, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)hip_stream, ctx->d_model,
@@ -872,6 +1000,7 @@ extern "C" int mpcmp_sample_batch(mpcmp_ctx *ctx, int B, const double *sx, const
 extern "C" int mpcmp_traj_stats_batch(mpcmp_ctx *ctx, int B, const double *sx, const double *su, const double *sT, const double *xf,
                                       int n_pts, double *out) {
     if (!ctx || B < 1 || n_pts < 1 || !sx || !su || !sT || !xf || !out) return MPCMP_EINVAL;
+    SINGLE_ARM_ONLY(ctx);
     // the kernel keeps the n_pts+1 samples of one trajectory (28 doubles each) in LDS: 160 KB per workgroup on gfx950
     if (sizeof(double) * 28 * (size_t)(n_pts + 1) > 150 * 1024) { ctx->err = "mpcmp_traj_stats_batch: n_pts must be <= 684 (the samples of one trajectory are held in LDS)"; return MPCMP_EINVAL; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -907,8 +1036,8 @@ extern "C" int mpcmp_rh_init(mpcmp_ctx *ctx, int B, const double *x0, const doub
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * ctx->nx * B, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * ctx->nx * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     ctx->rh_B = B; ctx->rh_first = true;
     if (ctx->rh_exec) { (void)hipGraphExecDestroy(ctx->rh_exec); ctx->rh_exec = nullptr; }
@@ -922,7 +1051,7 @@ static int rh_enqueue_step(mpcmp_ctx *ctx, double dt, bool first, hipStream_t st
     if (int rc = solve_dispatch(ctx, B, ctx->d_x0, ctx->d_xf, wx, wu, wT, ctx->d_sx, ctx->d_su, ctx->d_sT, ctx->d_info, st, 0,
                                 first ? 0 : 1))
         return rc;
-    hipLaunchKernelGGL(k_advance, dim3((B * 14 + 255) / 256), dim3(256), 0, st, ctx->nseg, B, dt, ctx->d_sx, ctx->d_sT, ctx->d_x0);
+    hipLaunchKernelGGL(k_advance, dim3((B * ctx->nx + 255) / 256), dim3(256), 0, st, ctx->nseg, ctx->nx, B, dt, ctx->d_sx, ctx->d_sT, ctx->d_x0);
     HIPCHK(ctx, hipGetLastError());
     return MPCMP_OK;
 }
@@ -964,12 +1093,24 @@ extern "C" int mpcmp_rh_get(mpcmp_ctx *ctx, double *x0_now, double *sx, double *
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t B = ctx->rh_B, N = ctx->N;
     hipStream_t st = ctx->stream;
-    if (x0_now) HIPCHK(ctx, hipMemcpyAsync(x0_now, ctx->d_x0, sizeof(double) * 14 * B, hipMemcpyDeviceToHost, st));
-    if (sx) HIPCHK(ctx, hipMemcpyAsync(sx, ctx->d_sx, sizeof(double) * 14 * N * B, hipMemcpyDeviceToHost, st));
-    if (su) HIPCHK(ctx, hipMemcpyAsync(su, ctx->d_su, sizeof(double) * 7 * N * B, hipMemcpyDeviceToHost, st));
+    if (x0_now) HIPCHK(ctx, hipMemcpyAsync(x0_now, ctx->d_x0, sizeof(double) * ctx->nx * B, hipMemcpyDeviceToHost, st));
+    if (sx) HIPCHK(ctx, hipMemcpyAsync(sx, ctx->d_sx, sizeof(double) * ctx->nx * N * B, hipMemcpyDeviceToHost, st));
+    if (su) HIPCHK(ctx, hipMemcpyAsync(su, ctx->d_su, sizeof(double) * ctx->nu * N * B, hipMemcpyDeviceToHost, st));
     if (sT) HIPCHK(ctx, hipMemcpyAsync(sT, ctx->d_sT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     if (info) HIPCHK(ctx, hipMemcpyAsync(info, ctx->d_info, sizeof(mpcmp_info) * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+// diagnostics: copy one workspace array of the last solve to the host (which: 0 z, 1 lambda, 2 c_eq, 3 g, 4 p, 5 y)
+extern "C" int mpcmp_debug_fetch(mpcmp_ctx *ctx, int which, double *out, long count) {
+    if (!ctx || !out || count < 1) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const double *src = which == 0 ? ctx->ws.z : which == 1 ? ctx->ws.lam : which == 2 ? ctx->ws.ceq : which == 3 ? ctx->ws.g
+                      : which == 4 ? ctx->ws.p : which == 5 ? ctx->ws.y : nullptr;
+    if (!src) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipMemcpy(out, src, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
     return MPCMP_OK;
 }
 
@@ -992,7 +1133,7 @@ extern "C" int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name,
     }
     ctx->ev_used = 0;
     ctx->timing = true;            // event recording starts with the first call (bench.py calls it once before the timed region)
-    if (name) *name = (ctx->nseg == 2 || ctx->nseg == 4) ? "k_qp2" : "k_qp";
+    if (name) *name = ctx->nseg >= 6 ? "k_qp3" : ((ctx->nseg == 2 || ctx->nseg == 4) ? "k_qp2" : "k_qp");
     if (ms_total) *ms_total = ctx->qp_ms;
     if (launches) *launches = ctx->qp_launches;
     if (reset) { ctx->qp_ms = 0.0; ctx->qp_launches = 0; }

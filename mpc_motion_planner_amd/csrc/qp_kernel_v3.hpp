@@ -1,0 +1,823 @@
+// qp_kernel_v3.hpp — k_qp3<NSEG, NARM>: the QP kernel for the larger discretisations (N = 19, the reference as shipped,
+// robot_ocp.hpp:31-32; N = 25) and for multi-arm robots (BASELINE.json configs[3]: 14-DoF dual Panda, N = 25).
+//
+// One workgroup of 1024 threads (= one CU) per (OCP, arm).  Same arithmetic as k_qp / k_qp2 — OSQP-form ADMM on [A; I] with the
+// reduced KKT system solved by nested dissection and explicit block inverses — with two structural changes that make the
+// factor of an N = 25 arm fit one CU's registers (structure3.hpp):
+//   * the final time T, the only variable the arms share, is bordered out: every arm factorises its own K_0 and the arms of one
+//     OCP exchange ONE scalar per ADMM iteration (k_a^T K_0a^-1 b_a) through global memory (NARM = 2; nothing for NARM = 1);
+//   * E_s = G_s K_JC is never formed: the interior solve applies G_s twice around the sparse K_JC / K_CJ products, so the only
+//     dense factors are G_s (49 x 49 per segment, one ROW per lane of wave s: every lane of a wave reads the same operand, i.e.
+//     LDS broadcast reads) and S^-1 (nI x nI, four lanes per row, DPP quad reduction).
+// Waves 0..NSEG-1 hold G (lanes 49..55 of the last one hold the 7 x 7 block of u_{N-1}); waves 8..15 hold S^-1 and own the ADMM
+// state of the variables and rows.  Five workgroup barriers per iteration:
+//     A  rhs = sigma x - q + rho z - y + A^T w                   | P1  t = G b_J,  part = K_CJ t        (G waves)
+//     P3 r_I = b_I - part,  y_I = S^-1 r_I      (S waves)        | P4  x_J = G (b_J - K_JC y_I) - w x_T  (G waves)
+//     E  z~ = A x~, relaxation, projection, dual update (S waves)
+#pragma once
+#include "qp_kernel_v2.hpp"
+#include "structure3.hpp"
+
+namespace mpcmp {
+
+// inter-workgroup exchange between the two arm workgroups of one OCP (NARM = 2): 8-byte data-tagged granules, agent-scope
+// relaxed atomics on both sides (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": valid
+// form for <= 8-byte hand-offs, placement independent).  Every slot is written once per launch; k_init_m / k_step_m reset the
+// slots of their problem to XCH_EMPTY before the next QP launch.  Every spin is bounded.
+#define MPCMP_XCH_STRIDE 1024
+#define MPCMP_XCH_EMPTY 0x7FF8DEADBEEF0001ull          /* a NaN payload no arithmetic produces */
+struct Xch {
+    unsigned long long *buf;        // [B][2][MPCMP_XCH_STRIDE]
+};
+__device__ __forceinline__ void xch_post(unsigned long long *slot, double v) {
+    __hip_atomic_store(slot, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double xch_poll(const unsigned long long *slot, int &dead) {
+    unsigned long long v = MPCMP_XCH_EMPTY;
+    if (!dead) {
+        for (int spin = 0; spin < (1 << 21); spin++) {
+            v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != MPCMP_XCH_EMPTY) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (v == MPCMP_XCH_EMPTY) dead = 1;          // partner never arrived: give up on every later exchange as well
+    }
+    return dead ? 0.0 : __longlong_as_double((long long)v);
+}
+
+template <int NSEG>
+struct Qp3 {
+    using D = Dim3<NSEG>;
+    static constexpr int NT = 1024;
+    static constexpr int GS = 24;                                   // row stride of the path Jacobians in LDS
+    static constexpr int JS = 50;                                   // stride of one segment's part of rhs (49 + a zero pad)
+    static constexpr int CP = ((D::nI + 3) / 4 + 1) / 2 * 2;        // columns of S^-1 per lane (four lanes per row), even
+    static constexpr int NAP = (D::na + 2 + 1) / 2 * 2;             // na + T slot, even
+    static constexpr int MAP = (D::ma + 1) / 2 * 2;
+    static constexpr int NB = NSEG + 1;                             // blocks of the interior sweep (segments + padded K_UU)
+    static constexpr int CB = NB * 52 > 128 ? NB * 52 : 128;        // pivot-column buffer of the sweeps
+    static constexpr int e2(int x) { return (x + 1) / 2 * 2; }
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    // ---- persistent (doubles) ----
+    static constexpr int oGk = 0;                                   // [N][8][GS]    path Jacobians
+    static constexpr int oCT = oGk + D::N * 8 * GS;                 // [meq]         T coefficient -ts*f of the dynamics rows
+    static constexpr int oKJC = oCT + e2(D::meq);                   // [NSEG][49][4] sparse K_JC
+    static constexpr int oKUX = oKJC + NSEG * 196;                  // [NSEG][7][14] dense block u_3s x x_3s
+    static constexpr int oKuX = oKUX + NSEG * 98;                   // [7][14]       u_{N-1} x x_{N-1}
+    static constexpr int oGu = oKuX + 98;                           // [28]          -(K_UU^-1) packed
+    static constexpr int oKT = oGu + 32;                            // [na] T column k (internal order), [na] kappa_a
+    static constexpr int oMisc = oKT + NAP;                         // [32]  see M_* below
+    static constexpr int oCD = oMisc + 32;                          // [16]  differentiation matrix
+    static constexpr int oRedP = oCD + 16;                          // [160] workgroup reductions
+    static constexpr int oU = oRedP + 160;                          // union region
+    // ---- factor view of the union ----
+    static constexpr int fKJJ = oU;                                 // [NSEG][1225], later S packed [SP]
+    static constexpr int fKUU = fKJJ + NSEG * D::JP;                // [28]
+    static constexpr int fZ = fKUU + 32;                            // [na] iterate of this arm (assembly operands)
+    static constexpr int fCol = fZ + NAP;                           // [2][CB]
+    static constexpr int fRdv = fCol + 2 * CB;                      // [2][16]
+    static constexpr int fEnd = fRdv + 32;
+    static constexpr int fSW = fKJJ + e2(D::SP);                    // Schur phase scratch behind S: [8][64] column, [8][64] product
+    static_assert(fSW + 1024 <= fKUU, "Schur scratch must fit between S and the K_UU block");
+    // ---- loop view of the union ----
+    static constexpr int oLb = oU, oUb = oLb + NAP, oRb = oUb + NAP, oRi = oRb + NAP, oWv = oRi + NAP;     // variable constants
+    static constexpr int oLg = oWv + NAP, oUg = oLg + MAP, oRr = oUg + MAP, oRri = oRr + MAP, oCf = oRri + MAP;   // row constants
+    static constexpr int oRpos = oCf + MAP;                         // [na] ints: LDS slot of the variable's rhs entry
+    static constexpr int oRhsJ = oRpos + e2((D::na + 1) / 2);       // [NSEG][JS]
+    static constexpr int oRhsU = oRhsJ + NSEG * JS;                 // [JS] (7 used, rest zero)
+    static constexpr int oRhsI = oRhsU + JS;                        // [nI]
+    static constexpr int oTJ = oRhsI + e2(D::nI);                   // [8][128] wave-private vectors of the G waves ([64..] U block)
+    static constexpr int oPart = oTJ + 1024;                        // [NSEG][28] K_CJ t per segment, [14] of the U block
+    static constexpr int oRIw = oPart + e2(NSEG * 28 + 14);         // [8][4 CP] wave-private r_I of the S waves; y (duals) at checks
+    static constexpr int oYI = oRIw + cmax(8 * 4 * CP, MAP);        // [nI]
+    static constexpr int oXt = oYI + e2(D::nI);                     // [na + 1] x~ in external arm order, T last
+    static constexpr int oWg = oXt + NAP;                           // [ma] w = rho z - y
+    static constexpr int oRedB = oWg + MAP;                         // [8] per-wave partial sums of w^T rhs
+    static constexpr int oRedT = oRedB + 8;                         // [8] per-wave partial sums of the T column of A^T w
+    static constexpr int lEnd = oRedT + 8;
+    static constexpr int size = cmax(fEnd, lEnd);
+    static_assert(size * 8 <= 160 * 1024 - 512, "LDS budget");
+    // misc slots
+    static constexpr int M_xT = 0, M_zbT = 1, M_ybT = 2, M_baseT = 3, M_delta = 4, M_hdT = 5, M_rbT = 6, M_lbT = 7, M_ubT = 8,
+                         M_xtT = 9, M_sumha = 10, M_dl = 12, M_done = 13, M_s0 = 14, M_s1 = 15, M_c0 = 16 /* 16..31: check exchange */;
+};
+
+__device__ __forceinline__ void wave_sync() {
+    // LDS traffic of one wave is executed in order; this only keeps the compiler from moving accesses across the hand-off
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NSEG, int NARM>
+__global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pat, Xch xch, int B) {
+    using D = Dim3<NSEG>;
+    using L = Qp3<NSEG>;
+    constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = L::NT, GS = L::GS, JS = L::JS, CP = L::CP;
+    constexpr int n_tot = NARM * na + 1, mn_tot = NARM * (ma + na) + 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // workgroup -> (launch slot, arm): the two arm workgroups of an OCP are 8 apart (same XCD under round-robin placement:
+    // speed only, never correctness)
+    int slot, arm;
+    if (NARM == 1) { slot = blockIdx.x; arm = 0; }
+    else { const int bi = blockIdx.x; slot = (bi >> 4) * 8 + (bi & 7); arm = (bi >> 3) & 1; }
+    if (slot >= B) return;
+    const int b = ws.perm[slot];
+    const double ts = 1.0 / (2.0 * NSEG);
+    const double rho_in = cfg.rho, rho_eq = cfg.rho * cfg.rho_eq_scale, sigma = cfg.sigma, alpha = cfg.alpha;
+    const double *zg_ = ws.z + (size_t)b * n_tot + arm * na;                 // this arm's block of the iterate
+    const double T = ws.z[(size_t)b * n_tot + NARM * na];
+    const double tsT = ts * T;
+    const double *Gkg = ws.Gk + ((size_t)b * NARM + arm) * N * 176;
+    const double *lam_rows = ws.lam + (size_t)b * mn_tot + arm * ma;         // multipliers of this arm's general rows
+    const double *x0e = ws.x0 + (size_t)b * 14 * NARM, *xfe = ws.xf + (size_t)b * 14 * NARM;
+    auto arm_x = [&](const double *xe, int r) -> double { return r < 7 ? xe[7 * arm + r] : xe[7 * NARM + 7 * arm + (r - 7)]; };
+    double *gkl = lds + L::oGk, *misc = lds + L::oMisc, *cD = lds + L::oCD, *redp = lds + L::oRedP;
+    unsigned long long *xown = NARM == 2 ? xch.buf + ((size_t)b * 2 + arm) * MPCMP_XCH_STRIDE : nullptr;
+    const unsigned long long *xpar = NARM == 2 ? xch.buf + ((size_t)b * 2 + (1 - arm)) * MPCMP_XCH_STRIDE : nullptr;
+    int dead = 0, status = 0;
+
+    // ---------------- operands of the assembly ----------------
+    for (int i = tid; i < N * 8 * GS; i += NT) gkl[i] = (i % GS < 22) ? Gkg[(i / GS) * 22 + i % GS] : 0.0;
+    for (int r = tid; r < meq; r += NT) {
+        const int k = r / 14, rr = r % 14;
+        lds[L::oCT + r] = -ts * zg_[(rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7];
+    }
+    if (tid < 16) cD[tid] = c_D[tid];
+    if (tid < 32) misc[tid] = 0.0;
+    __syncthreads();
+    auto term_val = [&](uint32_t t) -> double {
+        const int r = t >> 16, a = (t >> 8) & 255, c = t & 255;
+        double va, vb, rho;
+        if (r < meq) {
+            const int i = (r / 14) % 3;
+            const double cT = lds[L::oCT + r];
+            va = a < 4 ? cD[4 * i + a] : (a == 4 ? -tsT : cT);
+            vb = c < 4 ? cD[4 * i + c] : (c == 4 ? -tsT : cT);
+            rho = rho_eq;
+        } else {
+            const double *row = gkl + (r - meq) * GS;
+            va = row[a]; vb = row[c];
+            const int q = (r - meq) & 7;
+            rho = (cfg.ubg[q] - cfg.lbg[q] < 1e-4) ? rho_eq : rho_in;
+        }
+        return rho * va * vb;
+    };
+    auto dst_of = [&](int e) -> double * {          // LDS home of assembled entry e
+        if (e < D::eKUU) return lds + L::fKJJ + e;
+        if (e < D::eKJC) return lds + L::fKUU + (e - D::eKUU);
+        if (e < D::eKUX) return lds + L::oKJC + (e - D::eKJC);
+        if (e < D::eKuX) return lds + L::oKUX + (e - D::eKUX);
+        if (e < D::eKT) return lds + L::oKuX + (e - D::eKuX);
+        if (e < D::EA) return lds + L::oKT + (e - D::eKT);
+        return lds + L::fKJJ + (e - D::eS);
+    };
+    auto assemble = [&](int e0, int e1) {
+        for (int e = e0 + tid; e < e1; e += NT) {
+            double acc = 0.0;
+            const int t1 = ws.entry_ptr[e + 1];
+            for (int t = ws.entry_ptr[e]; t < t1; t++) acc += term_val(ws.terms[t]);
+            *dst_of(e) = acc;
+        }
+    };
+    // Hessian arrow ha, box and rho of arm variable v (external arm order)
+    auto var_h = [&](int v, double &ha, double &rb, double &lo, double &hi) {
+        ha = 0.0;
+        if (v < 14 * N) {
+            const int k = v / 14, c = v % 14;
+            if (k == 0) { lo = hi = arm_x(x0e, c); }
+            else if (k == N - 1) { const double t = arm_x(xfe, c); lo = t - cfg.eps_target; hi = t + cfg.eps_target; }
+            else { lo = cfg.lbx[c]; hi = cfg.ubx[c]; }
+            if (c >= 7 && k <= N - 2) ha = -ts * lam_rows[14 * k + (c - 7)];
+        } else {
+            const int k = (v - 14 * N) / 7, c = (v - 14 * N) % 7;
+            lo = cfg.lbu[c]; hi = cfg.ubu[c];
+            if (k <= N - 2) ha = -ts * lam_rows[14 * k + 7 + c];
+        }
+        rb = (hi - lo < 1e-4) ? rho_eq : rho_in;
+    };
+    assemble(0, D::EA);
+    {   // sum |ha| of this arm (Gershgorin row of T, polympc_redef.hpp:57-70)
+        double s = 0.0;
+        for (int v = tid; v < na; v += NT) { double ha, rb, lo, hi; var_h(v, ha, rb, lo, hi); s += fabs(ha); }
+        double sv[1] = {s};
+        block_reduce16<1, false>(sv, redp, tid);          // (its barriers also publish the assembled entries)
+        if (tid == 0) misc[L::M_sumha] = sv[0];
+    }
+    // diagonal H + sigma I + rho_box of the interior and U blocks; Hessian arrow into the T column
+    for (int v = tid; v < na; v += NT) {
+        double ha, rb, lo, hi;
+        var_h(v, ha, rb, lo, hi);
+        const double d = (fabs(ha) + cfg.hess_reg) + sigma + rb;      // Gershgorin shift: a_ii = 0 -> |ha| + hess_reg
+        const int ip = int3_of_ext(NSEG, v);
+        if (ip < nJ) lds[L::fKJJ + (ip / 49) * D::JP + packed(ip % 49, ip % 49)] += d;
+        else if (ip < nJ + 7) lds[L::fKUU + packed(ip - nJ, ip - nJ)] += d;
+        lds[L::oKT + ip] += ha;
+    }
+    __syncthreads();
+
+    // ---------------- factorisation ----------------
+    auto tri_decode = [](int e, int &i, int &j) {
+        i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= e) i++;
+        while (i * (i + 1) / 2 > e) i--;
+        j = e - i * (i + 1) / 2;
+    };
+    // Symmetric sweep of `nblk` SPD nb x nb blocks, all pivots: A <- -(A^-1).  A thread owns one 4x4 tile of the lower block
+    // triangle in registers; per step only the pivot column and the pivot reciprocal travel through LDS (double buffered):
+    // one barrier per step (same scheme as k_qp2's sweep).
+    auto sweep = [&](int nb, int nblk, int cst, auto &&ld, auto &&st_) {
+        constexpr int CB = L::CB;
+        double *rdv = lds + L::fRdv;
+        const int nt4 = (nb + 3) >> 2, ntile = nt4 * (nt4 + 1) / 2;
+        const bool live = tid < ntile * nblk;
+        int blk = 0, Ib = 0, Jb = 0;
+        if (live) { blk = tid / ntile; tri_decode(tid % ntile, Ib, Jb); }
+        const bool diag = live && Ib == Jb;
+        double *cb0 = lds + L::fCol + blk * cst;
+        double v[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 4 * Ib + a, j = 4 * Jb + q;
+                v[a][q] = (live && i < nb && j < nb) ? (i >= j ? ld(blk, i, j) : ld(blk, j, i)) : ((live && i == j) ? 1.0 : 0.0);
+            }
+        }
+        __syncthreads();                              // (every tile is in registers before the first column is published)
+        if (live && Jb == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) cb0[4 * Ib + a] = v[a][0];
+            if (Ib == 0) { if (!(v[0][0] > 0.0)) status |= 2; rdv[blk] = pivot_rcp(v[0][0]); }
+        }
+        __syncthreads();
+        const int npad = 4 * nt4;
+        for (int kb = 0; 4 * kb < npad; kb++) {
+#pragma unroll
+            for (int ka = 0; ka < 4; ka++) {
+                const int k = 4 * kb + ka;
+                if (k < npad) {
+                    const int k1a = (ka + 1) & 3, k1b = kb + (ka == 3 ? 1 : 0);
+                    if (live) {
+                        const double *cur = cb0 + (k & 1) * CB;
+                        double *nxt = cb0 + ((k + 1) & 1) * CB;
+                        const D2 ci0 = lds2(cur + 4 * Ib), ci1 = lds2(cur + 4 * Ib + 2);
+                        const D2 cj0 = lds2(cur + 4 * Jb), cj1 = lds2(cur + 4 * Jb + 2);
+                        const double rd = rdv[(k & 1) * 16 + blk];
+                        const double cI[4] = {ci0.x, ci0.y, ci1.x, ci1.y};
+                        const double rJ[4] = {cj0.x * rd, cj0.y * rd, cj1.x * rd, cj1.y * rd};
+#pragma unroll
+                        for (int a = 0; a < 4; a++) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) v[a][q] = v[a][q] - cI[a] * rJ[q];
+                        }
+                        if (Ib == kb) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) v[ka][q] = rJ[q];
+                        }
+                        if (Jb == kb) {
+#pragma unroll
+                            for (int a = 0; a < 4; a++) v[a][ka] = cI[a] * rd;
+                            if (Ib == kb) v[ka][ka] = -rd;
+                        }
+                        if (k + 1 < npad) {
+                            if (Jb == k1b) {
+#pragma unroll
+                                for (int a = 0; a < 4; a++) nxt[4 * Ib + a] = (diag && a < k1a) ? v[k1a][a] : v[a][k1a];
+                                if (diag) {
+                                    const double pv = v[k1a][k1a];
+                                    if (!(pv > 0.0)) status |= 2;
+                                    rdv[((k + 1) & 1) * 16 + blk] = pivot_rcp(pv);
+                                }
+                            } else if (Ib == k1b) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) nxt[4 * Jb + q] = v[k1a][q];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = 4 * Ib + a, j = 4 * Jb + q;
+                    if (i < nb && j <= i) st_(blk, i, j, v[a][q]);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    // interior blocks K_JJ,s (49 x 49) and K_UU (7 x 7, padded with an identity to 49 x 49), all at once
+    sweep(49, NSEG + 1, 52,
+          [&](int blk, int i, int j) -> double {
+              if (blk < NSEG) return lds[L::fKJJ + blk * D::JP + packed(i, j)];
+              return i < 7 ? lds[L::fKUU + packed(i, j)] : (i == j ? 1.0 : 0.0);
+          },
+          [&](int blk, int i, int j, double val) {
+              if (blk < NSEG) lds[L::fKJJ + blk * D::JP + packed(i, j)] = val;
+              else if (i < 7) lds[L::fKUU + packed(i, j)] = val;
+          });
+    // factor registers: a G lane keeps its whole row of G_s, an S lane (later) its quarter row of S^-1
+    const bool isG = wave < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 49 && lane < 56;
+    double m[JS];
+#pragma unroll
+    for (int j = 0; j < JS; j++) {
+        double val = 0.0;
+        if (isG && j < 49) val = -lds[L::fKJJ + wave * D::JP + packed(lane, j)];
+        if (isGu && j < 7) val = -lds[L::fKUU + packed(lane - 49, j)];
+        m[j] = val;
+    }
+    if (tid < 28) lds[L::oGu + tid] = lds[L::fKUU + tid];           // -(K_UU^-1), for the Schur complement
+    __syncthreads();
+    // interface block K_II + its diagonal
+    assemble(D::eS, D::E);
+    __syncthreads();
+    for (int v = tid; v < na; v += NT) {
+        const int ip = int3_of_ext(NSEG, v);
+        if (ip >= nJ + 7) {
+            double ha, rb, lo, hi;
+            var_h(v, ha, rb, lo, hi);
+            const int ia = ip - nJ - 7;
+            lds[L::fKJJ + packed(ia, ia)] += (fabs(ha) + cfg.hess_reg) + sigma + rb;
+        }
+    }
+    __syncthreads();
+    // Schur complement S = K_II - sum_s K_CJ G_s K_JC - K_XU G_u K_UX: one column of K_JC at a time through the G rows in
+    // registers; even and odd segments in turn (neighbours share the diagonal block of their common interface node)
+    double *S = lds + L::fKJJ;
+    const uint32_t jcw = lane < 49 ? pat.jc[lane] : 0xFFFFFFFFu;
+    const uint32_t cjl = lane < 28 ? pat.cjl[lane] : 0xFFFFFFFFu, cjh = lane < 28 ? pat.cjh[lane] : 0xFFFFFFFFu;
+    const double *kjc = lds + L::oKJC + (wave < NSEG ? wave : 0) * 196, *kux = lds + L::oKUX + (wave < NSEG ? wave : 0) * 98;
+    auto kjc_entry = [&](int r, int c) -> double {          // K_JC[r][c] of this wave's segment (r = own lane)
+        if (r < 7 && c < 14) return kux[r * 14 + c];
+        double val = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if ((int)((jcw >> (8 * q)) & 255u) == c) val = kjc[r * 4 + q];
+        return val;
+    };
+    auto kcj_dot = [&](int c, const double *vec) -> double {  // (K_CJ vec)[c] of this wave's segment (c = own lane < 28)
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t ref = ((q < 4 ? cjl : cjh) >> (8 * (q & 3))) & 255u;
+            if (ref != 255u) acc += kjc[(ref >> 2) * 4 + (ref & 3u)] * vec[ref >> 2];
+        }
+        if (c < 14) {
+#pragma unroll
+            for (int r = 0; r < 7; r++) acc += kux[r * 14 + c] * vec[r];
+        }
+        return acc;
+    };
+    for (int ph = 0; ph < 2; ph++) {
+        if (wave < NSEG && (wave & 1) == ph) {
+            double *colb = lds + L::fSW + wave * 64, *eb = lds + L::fSW + 512 + wave * 64;
+            for (int c = 0; c < 28; c++) {
+                colb[lane] = lane < 49 ? kjc_entry(lane, c) : 0.0;
+                wave_sync();
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < JS / 2; j++) { const D2 cv = lds2(colb + 2 * j); a0 += m[2 * j] * cv.x; a1 += m[2 * j + 1] * cv.y; }
+                eb[lane] = lane < 49 ? a0 + a1 : 0.0;
+                wave_sync();
+                if (lane < 28 && lane >= c) S[packed(14 * wave + lane, 14 * wave + c)] -= kcj_dot(lane, eb);
+                wave_sync();
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 105) {
+        int a, c;
+        tri_decode(tid, a, c);
+        const double *kx = lds + L::oKuX, *gu = lds + L::oGu;
+        double acc = 0.0;
+        for (int r = 0; r < 7; r++)
+            for (int q = 0; q < 7; q++) acc += kx[r * 14 + a] * gu[packed(r, q)] * kx[q * 14 + c];
+        S[packed(14 * NSEG + a, 14 * NSEG + c)] += acc;             // gu holds -(K_UU^-1)
+    }
+    __syncthreads();
+    sweep(nI, 1, L::CB,
+          [&](int, int i, int j) -> double { return S[packed(i, j)]; },
+          [&](int, int i, int j, double val) { S[packed(i, j)] = val; });        // S <- -(S^-1)
+    const int si = tid - 512, srow = si >> 2, spart = si & 3;
+    const bool sact = si >= 0 && srow < nI;
+    if (wave >= 8) {
+#pragma unroll
+        for (int j = 0; j < JS; j++) {
+            const int col = spart * CP + j;
+            m[j] = (sact && j < CP && col < nI) ? -S[packed(srow, col)] : 0.0;
+        }
+    }
+    {
+        const int any = __syncthreads_or(status);       // (also: S consumed, the loop view may now be written)
+        if (tid == 0 && any) atomicOr(&ws.status[b], any);
+    }
+
+    // ---------------- loop-resident constants ----------------
+    int *rpos = reinterpret_cast<int *>(lds + L::oRpos);
+    auto rhs_slot = [&](int ip) -> int {
+        return ip < nJ ? L::oRhsJ + JS * (ip / 49) + ip % 49 : (ip < nJ + 7 ? L::oRhsU + (ip - nJ) : L::oRhsI + (ip - nJ - 7));
+    };
+    for (int i = tid; i < L::oRedT + 8 - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;        // vectors, pads, partial sums
+    __syncthreads();
+    for (int v = tid; v < na; v += NT) {
+        double ha, rb, lo, hi;
+        var_h(v, ha, rb, lo, hi);
+        const double zv = zg_[v];
+        lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv; lds[L::oRb + v] = rb; lds[L::oRi + v] = 1.0 / rb; lds[L::oWv + v] = 0.0;
+        rpos[v] = rhs_slot(int3_of_ext(NSEG, v));
+    }
+    for (int r = tid; r < ma; r += NT) {
+        double lg, ug, rr, cf;
+        if (r < meq) { lg = ug = -ws.ceq[((size_t)b * NARM + arm) * meq + r]; rr = rho_eq; cf = lds[L::oCT + r]; }
+        else {
+            const int q = (r - meq) & 7;
+            const double gv = ws.g[((size_t)b * NARM + arm) * 8 * N + (r - meq)];
+            lg = cfg.lbg[q] - gv; ug = cfg.ubg[q] - gv;
+            rr = (ug - lg < 1e-4) ? rho_eq : rho_in;
+            cf = gkl[(r - meq) * GS + 21];
+        }
+        lds[L::oLg + r] = lg; lds[L::oUg + r] = ug; lds[L::oRr + r] = rr; lds[L::oRri + r] = 1.0 / rr; lds[L::oCf + r] = cf;
+    }
+    if (tid == 0) {
+        misc[L::M_lbT] = cfg.lbT - T; misc[L::M_ubT] = cfg.ubT - T;
+        misc[L::M_rbT] = (cfg.ubT - cfg.lbT < 1e-4) ? rho_eq : rho_in;
+    }
+    // where the solve's outputs go (x~ in external arm order)
+    int xdst = 0;
+    if (isG) xdst = ws.ext_of_int[49 * wave + lane];
+    if (isGu) xdst = ws.ext_of_int[nJ + (lane - 49)];
+    if (sact && spart == 0) xdst = ws.ext_of_int[nJ + 7 + srow];
+    __syncthreads();
+
+    double *rhsI = lds + L::oRhsI, *part = lds + L::oPart, *partU = lds + L::oPart + NSEG * 28, *yI = lds + L::oYI, *xt = lds + L::oXt,
+           *wg = lds + L::oWg, *wvv = lds + L::oWv, *redB = lds + L::oRedB, *redT = lds + L::oRedT;
+    double *tJ = lds + L::oTJ + (wave & 7) * 128;                  // wave-private: [0..49] segment operand / result, [64..113] U block
+    const double *bj = lds + (isGu ? L::oRhsU : L::oRhsJ + JS * (wave < NSEG ? wave : 0));
+    // K_0 x = rhs by nested dissection, three barrier-separated phases.  use_xT: subtract w x~_T (the bordered T solve).
+    auto solve = [&](const bool use_xT, const int it) {
+        // ---- P1 (G waves): t = G b_J, part = K_CJ t ----
+        if (wave < 8) {
+            if (wave < NSEG) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < JS / 2; j++) { const D2 bv = lds2(bj + 2 * j); a0 += m[2 * j] * bv.x; a1 += m[2 * j + 1] * bv.y; }
+                const double t = a0 + a1;
+                if (lane < 49) tJ[lane] = t;
+                else if (isGu) tJ[64 + lane - 49] = t;
+                wave_sync();
+                if (lane < 28) part[wave * 28 + lane] = kcj_dot(lane, tJ);
+                if (wave == NSEG - 1 && lane >= 32 && lane < 46) {
+                    const int c = lane - 32;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 7; r++) acc += lds[L::oKuX + r * 14 + c] * tJ[64 + r];
+                    partU[c] = acc;
+                }
+            }
+        } else if (use_xT && tid == 512) {
+            // this arm's share of the T solve: s_a = (T column of A^T w) - w^T rhs
+            double ssum = 0.0, bsum = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; w8++) { ssum += redT[w8]; bsum += redB[w8]; }
+            const double sa = ssum - bsum;
+            misc[L::M_s0 + arm] = sa;
+            if (NARM == 2) xch_post(xown + 8 + it, sa);
+        }
+        __syncthreads();
+        // ---- P3 (S waves): r_I = b_I - part, y_I = S^-1 r_I ----
+        double yi = 0.0;
+        if (wave >= 8) {
+            double *rIw = lds + L::oRIw + (wave - 8) * 4 * CP;
+            for (int i = lane; i < 4 * CP; i += 64) {
+                double r = 0.0;
+                if (i < nI) {
+                    const int sN = i / 14, c = i % 14;
+                    r = rhsI[i];
+                    if (sN > 0) r -= part[(sN - 1) * 28 + 14 + c];
+                    if (sN < NSEG) r -= part[sN * 28 + c];
+                    else r -= partU[c];
+                }
+                rIw[i] = r;
+            }
+            wave_sync();
+            const double *rv = rIw + spart * CP;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < CP / 2; j++) { const D2 r2 = lds2(rv + 2 * j); a0 += m[2 * j] * r2.x; a1 += m[2 * j + 1] * r2.y; }
+            yi = sum4(a0 + a1);
+            if (sact && spart == 0) yI[srow] = yi;
+        }
+        __syncthreads();
+        // ---- P4: x_J = G (b_J - K_JC y_I); x~ = y - w x~_T ----
+        double xT = 0.0;
+        if (use_xT) {
+            double s0 = misc[L::M_s0], s1 = NARM == 2 ? misc[L::M_s1] : 0.0;
+            if (NARM == 2) {
+                double sp = 0.0;
+                if (lane == 0) sp = xch_poll(xpar + 8 + it, dead);
+                sp = read_lane(sp, 0);
+                dead = __builtin_amdgcn_readfirstlane(dead);
+                if (arm == 0) s1 = sp; else s0 = sp;
+            }
+            xT = (misc[L::M_baseT] + (s0 + s1)) / misc[L::M_delta];
+        }
+        if (wave < NSEG) {
+            double cr = 0.0;
+            if (lane < 49) {
+                cr = bj[lane];
+                const double *yc = yI + 14 * wave;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t c = (jcw >> (8 * q)) & 255u;
+                    if (c != 255u) cr -= kjc[lane * 4 + q] * yc[c];
+                }
+                if (lane < 7) {
+#pragma unroll
+                    for (int c = 0; c < 14; c++) cr -= kux[lane * 14 + c] * yc[c];
+                }
+                tJ[lane] = cr;
+            } else if (isGu) {
+                cr = bj[lane - 49];
+#pragma unroll
+                for (int c = 0; c < 14; c++) cr -= lds[L::oKuX + (lane - 49) * 14 + c] * yI[14 * NSEG + c];
+                tJ[64 + lane - 49] = cr;
+            }
+            wave_sync();
+            const double *cv = isGu ? tJ + 64 : tJ;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < JS / 2; j++) { const D2 c2 = lds2(cv + 2 * j); a0 += m[2 * j] * c2.x; a1 += m[2 * j + 1] * c2.y; }
+            if (isG || isGu) xt[xdst] = (a0 + a1) - wvv[xdst] * xT;
+        } else if (wave >= 8) {
+            if (sact && spart == 0) xt[xdst] = yi - wvv[xdst] * xT;
+            if (tid == 512) xt[na] = xT;
+        }
+        __syncthreads();
+    };
+
+    // ---------------- w = K_0^-1 k, delta ----------------
+    for (int ip = tid; ip < na; ip += NT) lds[rhs_slot(ip)] = lds[L::oKT + ip];
+    __syncthreads();
+    solve(false, 0);
+    {
+        double s = 0.0;
+        for (int v = tid; v < na; v += NT) s += lds[L::oKT + int3_of_ext(NSEG, v)] * xt[v];
+        double sv[1] = {s};
+        block_reduce16<1, false>(sv, redp, tid);
+        for (int v = tid; v < na; v += NT) wvv[v] = xt[v];
+        if (tid == 0) {
+            double kap[2] = {0.0, 0.0}, sh[2] = {0.0, 0.0}, dl[2] = {0.0, 0.0};
+            kap[arm] = lds[L::oKT + na]; sh[arm] = misc[L::M_sumha]; dl[arm] = sv[0];
+            if (NARM == 2) {
+                xch_post(xown + 0, kap[arm]); xch_post(xown + 1, sh[arm]); xch_post(xown + 2, dl[arm]);
+                kap[1 - arm] = xch_poll(xpar + 0, dead); sh[1 - arm] = xch_poll(xpar + 1, dead); dl[1 - arm] = xch_poll(xpar + 2, dead);
+            }
+            const double hdT = (sh[0] + sh[1]) + cfg.hess_reg;
+            misc[L::M_hdT] = hdT;
+            misc[L::M_delta] = ((kap[0] + kap[1]) + (hdT + sigma + misc[L::M_rbT])) - (dl[0] + dl[1]);
+            misc[L::M_baseT] = -1.0;                              // sigma x_T - q_T + rho_T z_T - y_T with x = z = y = 0, q_T = 1 (cost = T)
+            if (!(misc[L::M_delta] > 0.0)) atomicOr(&ws.status[b], 2);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- ADMM (OSQP form on [A; I]) ----------------
+    // S lane si owns arm variables si, si + 512 and general rows si, si + 512 (state in registers m[32..], constants in LDS)
+    constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
+    static_assert(NV <= 2 && NR <= 2 && CP + 5 * 2 <= JS, "role registers");
+    double &xv0 = m[CP], &zb0 = m[CP + 1], &yb0 = m[CP + 2], &xv1 = m[CP + 3], &zb1 = m[CP + 4], &yb1 = m[CP + 5];
+    double &zg0 = m[CP + 6], &yg0 = m[CP + 7], &zg1 = m[CP + 8], &yg1 = m[CP + 9];
+    if (wave >= 8) { xv0 = zb0 = yb0 = xv1 = zb1 = yb1 = zg0 = yg0 = zg1 = yg1 = 0.0; }
+    auto col_gather = [&](const double *w, int v) -> double {      // (A^T w)[v] without the T row
+        double s = 0.0;
+        int k, gcol;
+        if (v < 14 * N) {
+            k = v / 14; const int c = v % 14;
+            if (k % 3 != 0) {
+                const int j = k % 3, rA = 14 * 3 * (k / 3) + c;
+                s += cD[j] * w[rA] + cD[4 + j] * w[rA + 14] + cD[8 + j] * w[rA + 28];
+            } else {
+                if (k < N - 1) { const int rA = 14 * k + c; s += cD[0] * w[rA] + cD[4] * w[rA + 14] + cD[8] * w[rA + 28]; }
+                if (k > 0) { const int rB = 14 * (k - 3) + c; s += cD[3] * w[rB] + cD[7] * w[rB + 14] + cD[11] * w[rB + 28]; }
+            }
+            if (c >= 7 && k <= N - 2) s -= tsT * w[14 * k + c - 7];
+            gcol = k * 8 * GS + c;
+        } else {
+            k = (v - 14 * N) / 7; const int c = (v - 14 * N) % 7;
+            if (k <= N - 2) s -= tsT * w[14 * k + 7 + c];
+            gcol = k * 8 * GS + 14 + c;
+        }
+        const double *gc = gkl + gcol, *wp = w + meq + 8 * k;
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += gc[q * GS] * wp[q];
+        return s;
+    };
+    auto row_dot = [&](const double *xe, int r) -> double {         // (A x)[r]; xe: external arm order, T at [na]
+        double s;
+        if (r < meq) {
+            const int k = r / 14, rr = r % 14, i = k % 3, ix0 = 14 * 3 * (k / 3) + rr;
+            const int ixf = (rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7;
+            s = cD[4 * i] * xe[ix0] + cD[4 * i + 1] * xe[ix0 + 14] + cD[4 * i + 2] * xe[ix0 + 28] + cD[4 * i + 3] * xe[ix0 + 42] -
+                tsT * xe[ixf] + lds[L::oCf + r] * xe[na];
+        } else {
+            const int k = (r - meq) >> 3;
+            const double *gr = gkl + (r - meq) * GS, *xk = xe + 14 * k, *uk = xe + 14 * N + 7 * k;
+            s = gr[21] * xe[na];
+#pragma unroll
+            for (int c = 0; c < 14; c++) s += gr[c] * xk[c];
+#pragma unroll
+            for (int c = 0; c < 7; c++) s += gr[14 + c] * uk[c];
+        }
+        return s;
+    };
+    auto wave_total = [&](double x) -> double {                     // sum over the 64 lanes, valid in every lane
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        return x;
+    };
+    double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests
+    const unsigned chk_base = 8 + cfg.qp_iters + 1;
+    int it = 0, done = 0, until_check = cfg.check_every, nchk = 0;
+    for (it = 1; it <= cfg.qp_iters; it++) {
+        // ---- A: rhs = sigma x - q + rho_b z_b - y_b + A^T w ----
+        if (wave >= 8) {
+            double bp = 0.0;
+#pragma unroll
+            for (int h = 0; h < NV; h++) {
+                const int v = si + 512 * h;
+                if (v < na) {
+                    const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
+                    const double r = (sigma * xx + (lds[L::oRb + v] * zz - yy)) + col_gather(wg, v);
+                    lds[rpos[v]] = r;
+                    bp += wvv[v] * r;
+                }
+            }
+            bp = wave_total(bp);
+            if (lane == 0) redB[wave - 8] = bp;
+        }
+        __syncthreads();
+        solve(true, it);
+        // ---- E: z~ = A x~, relaxation, projection, dual update ----
+        const bool check = (--until_check == 0);
+        if (check) until_check = cfg.check_every;
+        if (wave >= 8) {
+            double tp = 0.0;
+#pragma unroll
+            for (int h = 0; h < NR; h++) {
+                const int r = si + 512 * h;
+                if (r < ma) {
+                    double &zg = h ? zg1 : zg0, &yg = h ? yg1 : yg0;
+                    const double rr = lds[L::oRr + r];
+                    const double zt = row_dot(xt, r);
+                    const double zr = alpha * zt + (1.0 - alpha) * zg;
+                    const double zn = clip(zr + yg * lds[L::oRri + r], lds[L::oLg + r], lds[L::oUg + r]);
+                    yg += rr * (zr - zn);
+                    zg = zn;
+                    const double w = rr * zg - yg;
+                    wg[r] = w;
+                    tp += lds[L::oCf + r] * w;
+                }
+            }
+            tp = wave_total(tp);
+            if (lane == 0) redT[wave - 8] = tp;       // (read by the next iteration's P1 window: two barriers away)
+#pragma unroll
+            for (int h = 0; h < NV; h++) {
+                const int v = si + 512 * h;
+                if (v < na) {
+                    double &xx = h ? xv1 : xv0, &zz = h ? zb1 : zb0, &yy = h ? yb1 : yb0;
+                    const double xtv = xt[v], rb = lds[L::oRb + v];
+                    xx = alpha * xtv + (1.0 - alpha) * xx;
+                    const double zr = alpha * xtv + (1.0 - alpha) * zz;
+                    const double zn = clip(zr + yy * lds[L::oRi + v], lds[L::oLb + v], lds[L::oUb + v]);
+                    yy += rb * (zr - zn);
+                    zz = zn;
+                }
+            }
+            if (tid == 512) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
+                const double xtv = xt[na], rb = misc[L::M_rbT];
+                double xx = misc[L::M_xT], zz = misc[L::M_zbT], yy = misc[L::M_ybT];
+                xx = alpha * xtv + (1.0 - alpha) * xx;
+                const double zr = alpha * xtv + (1.0 - alpha) * zz;
+                const double zn = clip(zr + yy / rb, misc[L::M_lbT], misc[L::M_ubT]);
+                yy += rb * (zr - zn);
+                zz = zn;
+                misc[L::M_xT] = xx; misc[L::M_zbT] = zz; misc[L::M_ybT] = yy;
+                misc[L::M_baseT] = (sigma * xx - 1.0) + (rb * zz - yy);
+            }
+        }
+        __syncthreads();
+        if (check) {
+            // ---- termination test: r_prim = ||[A;I]x - z||inf, r_dual = ||Hx + q + [A;I]^T y||inf (oracle/ocp.c admm) ----
+            double sums[2] = {0.0, 0.0};              // T row: sum coefT_r y_r, sum ha_i x_i of this arm
+            if (wave >= 8) {
+#pragma unroll
+                for (int h = 0; h < NR; h++) {
+                    const int r = si + 512 * h;
+                    if (r < ma) { const double yg = h ? yg1 : yg0; ys[r] = yg; sums[0] += lds[L::oCf + r] * yg; }
+                }
+#pragma unroll
+                for (int h = 0; h < NV; h++) {
+                    const int v = si + 512 * h;
+                    if (v < na) {
+                        const double xx = h ? xv1 : xv0;
+                        double ha, rb, lo, hi;
+                        var_h(v, ha, rb, lo, hi);
+                        xt[v] = xx; sums[1] += ha * xx;
+                    }
+                }
+                if (tid == 512) xt[na] = misc[L::M_xT];
+            }
+            block_reduce16<2, false>(sums, redp, tid);           // (its barriers publish xt / ys)
+            double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
+            if (wave >= 8) {
+                const double xTc = xt[na];
+#pragma unroll
+                for (int h = 0; h < NR; h++) {
+                    const int r = si + 512 * h;
+                    if (r < ma) {
+                        const double zg = h ? zg1 : zg0, ax = row_dot(xt, r);
+                        mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < NV; h++) {
+                    const int v = si + 512 * h;
+                    if (v < na) {
+                        const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
+                        double ha, rb, lo, hi;
+                        var_h(v, ha, rb, lo, hi);
+                        const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, v) + yy;
+                        mx[0] = fmax(mx[0], fabs(xx - zz)); mx[1] = fmax(mx[1], fabs(xx)); mx[2] = fmax(mx[2], fabs(zz));
+                        mx[3] = fmax(mx[3], fabs(hx + aty)); mx[4] = fmax(mx[4], fabs(hx)); mx[5] = fmax(mx[5], fabs(aty));
+                    }
+                }
+            }
+            block_reduce16<6, true>(mx, redp, tid);
+            // combine the arms and add the row / column of T (identical arithmetic in both arm workgroups)
+            double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+            s1[arm] = sums[0]; s2[arm] = sums[1];
+            if (NARM == 2) {
+                if (tid == 0) {
+                    unsigned long long *po = xown + chk_base + 8 * nchk;
+                    const unsigned long long *pp = xpar + chk_base + 8 * nchk;
+                    xch_post(po + 0, sums[0]); xch_post(po + 1, sums[1]);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) xch_post(po + 2 + q, mx[q]);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) misc[L::M_c0 + q] = xch_poll(pp + q, dead);
+                }
+                __syncthreads();
+                s1[1 - arm] = misc[L::M_c0]; s2[1 - arm] = misc[L::M_c0 + 1];
+#pragma unroll
+                for (int q = 0; q < 6; q++) mx[q] = fmax(mx[q], misc[L::M_c0 + 2 + q]);
+                __syncthreads();
+            }
+            nchk++;
+            {
+                const double xTc = misc[L::M_xT], zT = misc[L::M_zbT], yT = misc[L::M_ybT];
+                const double hxT = misc[L::M_hdT] * xTc + (s2[0] + s2[1]), atyT = (s1[0] + s1[1]) + yT;
+                mx[0] = fmax(mx[0], fabs(xTc - zT)); mx[1] = fmax(mx[1], fabs(xTc)); mx[2] = fmax(mx[2], fabs(zT));
+                mx[3] = fmax(mx[3], fabs(hxT + atyT + 1.0)); mx[4] = fmax(mx[4], fabs(hxT)); mx[5] = fmax(mx[5], fabs(atyT));
+            }
+            const double ep = cfg.eps_abs + cfg.eps_rel * fmax(mx[1], mx[2]);
+            const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);      // ||q||_inf = 1
+            if (mx[0] <= ep && mx[3] <= ed) done = 1;
+        }
+        if (done) break;
+    }
+    if (it > cfg.qp_iters) it = cfg.qp_iters;
+    // ---------------- results ----------------
+    if (wave >= 8) {
+#pragma unroll
+        for (int h = 0; h < NV; h++) {
+            const int v = si + 512 * h;
+            if (v < na) {
+                ws.p[(size_t)b * n_tot + arm * na + v] = h ? xv1 : xv0;
+                ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? yb1 : yb0;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NR; h++) {
+            const int r = si + 512 * h;
+            if (r < ma) ws.y[(size_t)b * mn_tot + arm * ma + r] = h ? yg1 : yg0;
+        }
+        if (tid == 512 && arm == 0) {
+            ws.p[(size_t)b * n_tot + NARM * na] = misc[L::M_xT];
+            ws.y[(size_t)b * mn_tot + mn_tot - 1] = misc[L::M_ybT];
+        }
+    }
+    {
+        const int any = __syncthreads_or(dead ? 4 : 0);         // bit 2: the partner workgroup never answered
+        if (tid == 0) {
+            if (arm == 0) { ws.qpit[b] = it; ws.qp_total[b] += it; }
+            if (any) atomicOr(&ws.status[b], any);
+        }
+    }
+}
+
+}  // namespace mpcmp

@@ -1027,10 +1027,10 @@ __global__ __launch_bounds__(64) void k_mpc_point(const mpcmp_model *mdl, int ns
 
 // Receding horizon: x0 <- MPC solution evaluated at physical time dt (MotionPlanner::get_MPC_point, motionPlanner.hpp:118-128,
 // including its clamp: for dt >= T the normalised time is set to T, not 1).  One thread per (problem, state component).
-__global__ __launch_bounds__(256) void k_advance(int nseg, int B, double dt, const double *sx, const double *sT, double *x0) {
+__global__ __launch_bounds__(256) void k_advance(int nseg, int nx, int B, double dt, const double *sx, const double *sT, double *x0) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= B * 14) return;
-    const int b = gid / 14, r = gid % 14, N = 3 * nseg + 1;
+    if (gid >= B * nx) return;
+    const int b = gid / nx, r = gid % nx, N = 3 * nseg + 1;
     const double T = sT[b];
     const double t = (dt < T) ? dt / T : T;
     const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_advance(int nseg, int B, double dt, con
         double w = 1.0;
 #pragma unroll
         for (int k = 0; k < 4; k++) if (k != j) w *= (xx - xi[k]) / (xi[j] - xi[k]);
-        acc += w * sx[(size_t)b * 14 * N + 14 * (3 * s + j) + r];
+        acc += w * sx[((size_t)b * N + 3 * s + j) * nx + r];
     }
     x0[gid] = acc;
 }

@@ -14,15 +14,21 @@ from .capi import check, dp, f64, lib
 class Solver:
     """mpcmp_ctx wrapper. Host-buffer calls take numpy arrays; *_device calls take raw device pointers."""
 
-    def __init__(self, cfg, max_batch, device=0, model=None):
+    def __init__(self, cfg, max_batch, device=0, model=None, models=None):
+        """models: a ctypes array of `narm` Models (multi-arm robot, mpcmp_create_multi); model: one Model; neither: the Panda"""
         self.cfg = cfg
+        self.narm = len(models) if models is not None else 1
+        self.nx, self.nu = 14 * self.narm, 7 * self.narm
         self.N = 3 * cfg.num_seg + 1
-        self.n = 21 * self.N + 1
-        self.m = 14 * (self.N - 1) + 8 * self.N
+        self.n = 21 * self.N * self.narm + 1
+        self.m = (14 * (self.N - 1) + 8 * self.N) * self.narm
         self.max_batch = int(max_batch)
         self._ctx = C.c_void_p()
-        rc = lib().mpcmp_create(C.byref(cfg), C.byref(model) if model is not None else None, int(device),
-                                int(max_batch), C.byref(self._ctx))
+        if models is not None:
+            rc = lib().mpcmp_create_multi(C.byref(cfg), models, self.narm, int(device), int(max_batch), C.byref(self._ctx))
+        else:
+            rc = lib().mpcmp_create(C.byref(cfg), C.byref(model) if model is not None else None, int(device),
+                                    int(max_batch), C.byref(self._ctx))
         check(rc)
 
     def close(self):
@@ -41,16 +47,16 @@ class Solver:
     def _states(self, x0, xf):
         """(x0, xf) as contiguous [B][14] arrays; a shape mismatch raises instead of letting the C side read out of bounds"""
         x0, xf = f64(x0), f64(xf)
-        if x0.ndim != 2 or x0.shape[1] != 14 or xf.shape != x0.shape:
-            raise ValueError("x0 and xf must both be [B][14] arrays, got %s and %s" % (x0.shape, xf.shape))
+        if x0.ndim != 2 or x0.shape[1] != self.nx or xf.shape != x0.shape:
+            raise ValueError("x0 and xf must both be [B][%d] arrays, got %s and %s" % (self.nx, x0.shape, xf.shape))
         return x0, xf
 
     def _traj(self, sx, su, sT):
         sx, su, sT = f64(sx), f64(su), f64(sT).reshape(-1)
         B = sT.shape[0]
-        if sx.shape != (B, self.N, 14) or su.shape != (B, self.N, 7):
-            raise ValueError("trajectory arrays must be [B][%d][14], [B][%d][7], [B]; got %s, %s, %s"
-                             % (self.N, self.N, sx.shape, su.shape, sT.shape))
+        if sx.shape != (B, self.N, self.nx) or su.shape != (B, self.N, self.nu):
+            raise ValueError("trajectory arrays must be [B][%d][%d], [B][%d][%d], [B]; got %s, %s, %s"
+                             % (self.N, self.nx, self.N, self.nu, sx.shape, su.shape, sT.shape))
         return sx, su, sT
 
     # -- hot path, host buffers
@@ -61,7 +67,7 @@ class Solver:
             wx, wu, wT = self._traj(*warm)
             if wT.shape[0] != B:
                 raise ValueError("warm start is for %d problems, states for %d" % (wT.shape[0], B))
-        sx, su, sT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
+        sx, su, sT = np.zeros((B, self.N, self.nx)), np.zeros((B, self.N, self.nu)), np.zeros(B)
         info = np.zeros(B, dtype=capi.INFO_DTYPE)
         check(lib().mpcmp_solve_batch(self._ctx, B, dp(x0), dp(xf), dp(wx), dp(wu), dp(wT), dp(sx), dp(su), dp(sT),
                                       info.ctypes.data_as(C.c_void_p)), self._ctx)
@@ -83,7 +89,7 @@ class Solver:
     def warm_start_jerk(self, x0, xf, jmax):
         """Jerk-limited, time-synchronised warm start (stands in for Ruckig): (warm_x [B][N][14], warm_u [B][N][7], warm_T [B])."""
         (x0, xf), jmax = self._states(x0, xf), f64(jmax).reshape(7); B = x0.shape[0]
-        wx, wu, wT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
+        wx, wu, wT = np.zeros((B, self.N, self.nx)), np.zeros((B, self.N, self.nu)), np.zeros(B)
         check(lib().mpcmp_warm_start_jerk_batch(self._ctx, B, dp(x0), dp(xf), dp(jmax), dp(wx), dp(wu), dp(wT)), self._ctx)
         return wx, wu, wT
 
@@ -159,7 +165,7 @@ class Solver:
 
     # -- receding horizon (BASELINE config #5)
     def rh_init(self, x0, xf):
-        x0, xf = f64(x0), f64(xf)
+        x0, xf = self._states(x0, xf)
         self._rh_B = x0.shape[0]
         check(lib().mpcmp_rh_init(self._ctx, self._rh_B, dp(x0), dp(xf)), self._ctx)
 
@@ -168,10 +174,16 @@ class Solver:
 
     def rh_get(self):
         B = self._rh_B
-        x0 = np.zeros((B, 14)); sx, su, sT = np.zeros((B, self.N, 14)), np.zeros((B, self.N, 7)), np.zeros(B)
+        x0 = np.zeros((B, self.nx)); sx, su, sT = np.zeros((B, self.N, self.nx)), np.zeros((B, self.N, self.nu)), np.zeros(B)
         info = np.zeros(B, dtype=capi.INFO_DTYPE)
         check(lib().mpcmp_rh_get(self._ctx, dp(x0), dp(sx), dp(su), dp(sT), info.ctypes.data_as(C.c_void_p)), self._ctx)
         return x0, sx, su, sT, info
+
+    def debug_fetch(self, which, count):
+        """diagnostics: first `count` doubles of a workspace array (0 z, 1 lambda, 2 c_eq, 3 g, 4 p, 5 y), device layout"""
+        out = np.zeros(int(count))
+        check(lib().mpcmp_debug_fetch(self._ctx, int(which), dp(out), C.c_long(int(count))), self._ctx)
+        return out
 
     def kernel_timing(self, reset=False):
         name = C.c_char_p(); ms = C.c_double(); nl = C.c_int()

@@ -1,0 +1,112 @@
+"""GPU parity of the N = 25 discretisation and of the multi-arm OCP (BASELINE.json configs[3]: 14-DoF dual Panda, N = 25,
+4,096 problems) against the CPU oracle's multi-arm form (oracle/ocp.c: orc_solve_multi).  Run with -m gpu."""
+import numpy as np
+import pytest
+
+import oracle_py as o
+
+pytestmark = pytest.mark.gpu
+
+MARGINS = (0.9, 0.9, 0.5, 0.9, 0.1)
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mpc_motion_planner_amd as M
+    return M
+
+
+def _limits():
+    lim = o.default_limits()
+    return MARGINS[1] * lim["vmax"], MARGINS[2] * lim["amax"], MARGINS[4] * lim["jmax"]
+
+
+def dual_states(B, off=0):
+    from mpc_motion_planner_amd import scenarios
+    a0, af = scenarios.make_batch(B, MARGINS, stream_offset=off)
+    b0, bf = scenarios.make_batch(B, MARGINS, stream_offset=off + 7919)
+    x0 = np.stack([o.merge_arm_states([a0[b], b0[b]]) for b in range(B)])
+    xf = np.stack([o.merge_arm_states([af[b], bf[b]]) for b in range(B)])
+    return x0, xf
+
+
+def test_dual_models_identical(M):
+    a, b = M.arm_models(M.DUAL_BASES), o.arm_models(o.DUAL_BASES)
+    for k in range(2):
+        for f in ["R0", "p", "mass", "com", "I", "tool", "link8", "gravity"]:
+            assert np.array_equal(np.array(getattr(a[k], f)), np.array(getattr(b[k], f))), (k, f)
+
+
+def test_dual_warm_start_vs_oracle(M):
+    cfg = M.default_config(6, 1, margins=MARGINS)
+    B = 5
+    x0, xf = dual_states(B)
+    s = M.Solver(cfg, B, models=M.arm_models(M.DUAL_BASES))
+    jmax = MARGINS[4] * M.default_limits()["jmax"]
+    wx, wu, wT = s.warm_start_jerk(x0, xf, jmax)
+    for b in range(B):
+        xg, ug, Tg = o.warm_start_jerk_multi(6, *_limits(), x0[b], xf[b])
+        assert abs(wT[b] - Tg) <= 1e-9 * Tg and np.abs(wx[b] - xg).max() <= 1e-8 and np.abs(wu[b] - ug).max() <= 1e-6
+
+
+@pytest.mark.parametrize("nseg,sqp,B", [(6, 1, 2), (6, 3, 3), (8, 2, 2), (8, 20, 2)])
+def test_dual_arm_solve_vs_oracle(M, nseg, sqp, B):
+    """two arm workgroups per OCP, one scalar exchanged per ADMM iteration: |dT| <= 1e-6 T, states <= 1e-6, identical ADMM
+    iteration counts and step lengths against orc_solve_multi"""
+    cfg = M.default_config(nseg, sqp, margins=MARGINS); ocfg = o.default_config(nseg, sqp, margins=MARGINS)
+    x0, xf = dual_states(B, off=50)
+    s = M.Solver(cfg, B, models=M.arm_models(M.DUAL_BASES))
+    N = 3 * nseg + 1
+    wx = np.zeros((B, N, 28)); wu = np.zeros((B, N, 14)); wT = np.zeros(B)
+    for b in range(B):
+        wx[b], wu[b], wT[b] = o.warm_start_jerk_multi(nseg, *_limits(), x0[b], xf[b])
+    sx, su, sT, info = s.solve(x0, xf, (wx, wu, wT))
+    models = o.arm_models(o.DUAL_BASES)
+    for b in range(B):
+        xs, us, T, oi = o.solve_multi(models, ocfg, x0[b], xf[b], wx[b], wu[b], wT[b])
+        assert info["status"][b] == oi.status == 0
+        assert abs(sT[b] - T) <= 1e-6 * T, (b, sT[b], T)
+        assert np.abs(sx[b] - xs).max() <= 1e-6 and np.abs(su[b] - us).max() <= 1e-5
+        assert info["qp_iters_total"][b] == oi.qp_iters_total and info["last_alpha"][b] == oi.last_alpha
+        assert abs(info["viol_l1"][b] - oi.viol_l1) < 1e-6 and abs(info["defect_inf"][b] - oi.defect_inf) < 1e-6
+        assert abs(info["term_err_inf"][b] - oi.term_err_inf) < 1e-6
+
+
+def test_single_arm_n25_builtin_warm_start_and_reguess(M):
+    """N = 25 single arm runs on the same kernels (k_init_m / k_qp3 / k_step_m): built-in quintic initialiser, receding horizon"""
+    cfg = M.default_config(8, 2, margins=MARGINS); ocfg = o.default_config(8, 2, margins=MARGINS)
+    from mpc_motion_planner_amd import scenarios
+    x0, xf = scenarios.make_batch(3, MARGINS, stream_offset=77)
+    s = M.Solver(cfg, 3)
+    wx, wu, wT = s.warm_start(x0, xf)
+    sx, su, sT, info = s.solve(x0, xf)
+    for b in range(3):
+        xg, ug, Tg = o.warm_start(ocfg, x0[b], xf[b])
+        assert abs(wT[b] - Tg) < 1e-12 * Tg and np.abs(wx[b] - xg).max() < 1e-10
+        xs, us, T, oi = o.solve(ocfg, x0[b], xf[b], xg, ug, Tg)
+        assert abs(sT[b] - T) <= 1e-6 * T and np.abs(sx[b] - xs).max() <= 1e-6 and info["qp_iters_total"][b] == oi.qp_iters_total
+        assert abs(info["viol_l1"][b] - oi.viol_l1) < 1e-6
+
+
+def test_config4_full_size_properties(M):
+    """BASELINE.json configs[3] at full size: 4,096 dual-arm OCPs, N = 25.  Size-independent properties with a reduced
+    solver depth (4 SQP iterations: the full 20 is the bench's job): every problem reported ok (no exchange time-out),
+    bitwise reproducible, a problem's result independent of the batch it travels in, oracle parity on a sample."""
+    cfg = M.default_config(8, 4, margins=MARGINS); ocfg = o.default_config(8, 4, margins=MARGINS)
+    B = 4096
+    x0, xf = dual_states(B, off=9000)
+    s = M.Solver(cfg, B, models=M.arm_models(M.DUAL_BASES))
+    jmax = MARGINS[4] * M.default_limits()["jmax"]
+    warm = s.warm_start_jerk(x0, xf, jmax)
+    sx, su, sT, info = s.solve(x0, xf, warm)
+    assert np.all(info["status"] == 0) and np.all(np.isfinite(sT)) and np.all(np.isfinite(sx)) and np.all(info["sqp_iters"] == 4)
+    sx2, su2, sT2, info2 = s.solve(x0, xf, warm)
+    assert np.array_equal(sT, sT2) and np.array_equal(sx, sx2) and np.array_equal(info["qp_iters_total"], info2["qp_iters_total"])
+    sub = slice(1000, 1000 + 96)
+    sxs, _, sTs, _ = s.solve(x0[sub], xf[sub], tuple(w[sub] for w in warm))
+    assert np.array_equal(sTs, sT[sub]) and np.array_equal(sxs, sx[sub])
+    models = o.arm_models(o.DUAL_BASES)
+    for b in (0, 2047, 4095):
+        xg, ug, Tg = o.warm_start_jerk_multi(8, *_limits(), x0[b], xf[b])
+        xs, us, T, oi = o.solve_multi(models, ocfg, x0[b], xf[b], xg, ug, Tg)
+        assert abs(sT[b] - T) <= 1e-6 * T and np.abs(sx[b] - xs).max() <= 1e-6 and info["qp_iters_total"][b] == oi.qp_iters_total

@@ -96,7 +96,13 @@ def test_qp_full_vs_oracle(M):
     _qp_case(M, 4, 4, 700)       # includes termination tests every 25 iterations
 
 
-@pytest.mark.parametrize("nseg,sqp,B", [(4, 2, 4), (4, 20, 3), (6, 2, 3), (2, 3, 2), (1, 3, 2)])
+@pytest.mark.parametrize("nseg,B,iters", [(6, 2, 5), (6, 3, 700), (8, 2, 5), (8, 3, 700)])
+def test_qp3_vs_oracle(M, nseg, B, iters):
+    """k_qp3 (N = 19 as shipped, N = 25): T bordered out, E-free interior solve — one QP against the oracle's skyline Cholesky"""
+    _qp_case(M, nseg, B, iters)
+
+
+@pytest.mark.parametrize("nseg,sqp,B", [(4, 2, 4), (4, 20, 3), (6, 2, 3), (6, 20, 2), (8, 2, 3), (8, 20, 2), (2, 3, 2), (1, 3, 2)])
 def test_solve_vs_oracle(M, nseg, sqp, B):
     cfg, ocfg = _cfgs(M, nseg, sqp)
     from mpc_motion_planner_amd import scenarios
