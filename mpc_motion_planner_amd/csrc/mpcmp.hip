@@ -45,7 +45,8 @@ struct mpcmp_ctx {
     mpcmp_info *d_info = nullptr;
     uint32_t *d_stream = nullptr;
     Qp2Streams streams{};
-    Qp3Pat pat{};                  // sparse K_JC pattern of k_qp3 (num_seg 6, 8)
+    Qp3Pat *d_pat = nullptr;       // sparse K_JC pattern of k_qp3 (num_seg 6, 8), device copy
+    double *d_fac = nullptr;       // factor workspace of k_qp3f -> k_qp3: [max_batch][narm][Qp3::FAC]
     Xch xch{nullptr};              // arm-to-arm exchange slots (multi-arm contexts)
     // timing of the dominant kernel (k_qp)
     struct EvPair { hipEvent_t e[2]; };
@@ -463,7 +464,9 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
         Tables3 t3;
         if (!build_tables3(cfg->num_seg, t3)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
         tab.nseg = t3.nseg; tab.ext_of_int = t3.ext_of_int; tab.entry_ptr = t3.entry_ptr; tab.terms = t3.terms;
-        ctx->pat = t3.pat;
+        TRY(dalloc(ctx, &ctx->d_fac, (size_t)max_batch * narm * (cfg->num_seg == 6 ? Qp3<6>::FAC : Qp3<8>::FAC)));
+        TRY(dalloc(ctx, &ctx->d_pat, 1));
+        HIPTRY(hipMemcpy(ctx->d_pat, &t3.pat, sizeof(Qp3Pat), hipMemcpyHostToDevice));
     } else if (!build_tables(cfg->num_seg, tab)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
     TRY(dalloc(ctx, &ctx->d_ext_of_int, tab.ext_of_int.size()));
     TRY(dalloc(ctx, &ctx->d_entry_ptr, tab.entry_ptr.size()));
@@ -551,7 +554,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     constexpr bool V3C = (NSEG >= 6);                   // k_qp3: T bordered out, E-free interior solve (N = 19, 25)
     const bool V2 = V2C && !force_v1;
     const size_t l_qp3 = Qp3<V3C ? NSEG : 6>::size * sizeof(double);
-    if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3C ? NSEG : 6, 1>, l_qp3)) return rc; }
+    if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3C ? NSEG : 6, 1>, l_qp3)) return rc; if (int rc = set_lds(ctx, k_qp3f<V3C ? NSEG : 6, 1>, l_qp3)) return rc; }
     const size_t l_qp2 = Qp2<V2C ? NSEG : 4>::size * sizeof(double);
     if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
     else if (!V3C) { if (int rc = set_lds(ctx, k_qp<V3C ? 1 : NSEG>, l_qp)) return rc; }
@@ -591,7 +594,11 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         for (int h = 0; h < nhalf; h++) {
             hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
             if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
-            if (V3C) hipLaunchKernelGGL((k_qp3<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->pat, ctx->xch, Bh[h]);
+            if (V3C) {
+                double *fh = ctx->d_fac + (size_t)boff[h] * Qp3<V3C ? NSEG : 6>::FAC;
+                hipLaunchKernelGGL((k_qp3f<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);
+                hipLaunchKernelGGL((k_qp3<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
+            }
             else if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(Bh[h]), dim3(1024), l_qp2, sh[h], ctx->cfg, wh[h], ctx->streams);
             else hipLaunchKernelGGL((k_qp<V3C ? 1 : NSEG>), dim3(Bh[h]), dim3(Dim<V3C ? 1 : NSEG>::NT), l_qp, sh[h], ctx->cfg, wh[h]);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
@@ -618,6 +625,7 @@ static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double 
     if (int rc = set_lds(ctx, k_init_m<NSEG, NARM>, l_m)) return rc;
     if (int rc = set_lds(ctx, k_step_m<NSEG, NARM>, l_m)) return rc;
     if (int rc = set_lds(ctx, k_qp3<NSEG, NARM>, l_qp3)) return rc;
+    if (int rc = set_lds(ctx, k_qp3f<NSEG, NARM>, l_qp3)) return rc;
     // two parts on two streams once one part alone fills the chip (one CU per arm): see solve_impl
     static const bool single_stream = std::getenv("MPCMP_SINGLE_STREAM") != nullptr;
     const bool dual = !single_stream && !only_qp && B * NARM >= 512;
@@ -651,7 +659,9 @@ static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double 
             hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
             if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
             const int grid = NARM == 1 ? Bh[h] : ((Bh[h] + 7) / 8) * 16;       // arm workgroups of one OCP are 8 apart (k_qp3)
-            hipLaunchKernelGGL((k_qp3<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->pat, xh[h], Bh[h]);
+            double *fh = ctx->d_fac + (size_t)boff[h] * NARM * Qp3<NSEG>::FAC;
+            hipLaunchKernelGGL((k_qp3f<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], fh);
+            hipLaunchKernelGGL((k_qp3<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], (const double *)fh);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;
             hipLaunchKernelGGL((k_step_m<NSEG, NARM>), dim3(Bh[h]), dim3(D::NT), l_m, sh[h], ctx->cfg, ctx->d_model, wh[h], xh[h],

@@ -1,7 +1,7 @@
 // qp_kernel_v3.hpp — k_qp3<NSEG, NARM>: the QP kernel for the larger discretisations (N = 19, the reference as shipped,
 // robot_ocp.hpp:31-32; N = 25) and for multi-arm robots (BASELINE.json configs[3]: 14-DoF dual Panda, N = 25).
 //
-// One workgroup of 1024 threads (= one CU) per (OCP, arm).  Same arithmetic as k_qp / k_qp2 — OSQP-form ADMM on [A; I] with the
+// One workgroup of 1024 threads (= one CU: 16 waves, 128 VGPRs each) per (OCP, arm).  Same arithmetic as k_qp / k_qp2 — OSQP-form ADMM on [A; I] with the
 // reduced KKT system solved by nested dissection and explicit block inverses — with two structural changes that make the
 // factor of an N = 25 arm fit one CU's registers (structure3.hpp):
 //   * the final time T, the only variable the arms share, is bordered out: every arm factorises its own K_0 and the arms of one
@@ -9,11 +9,13 @@
 //   * E_s = G_s K_JC is never formed: the interior solve applies G_s twice around the sparse K_JC / K_CJ products, so the only
 //     dense factors are G_s (49 x 49 per segment, one ROW per lane of wave s: every lane of a wave reads the same operand, i.e.
 //     LDS broadcast reads) and S^-1 (nI x nI, four lanes per row, DPP quad reduction).
-// Waves 0..NSEG-1 hold G (lanes 49..55 of the last one hold the 7 x 7 block of u_{N-1}); waves 8..15 hold S^-1 and own the ADMM
-// state of the variables and rows.  Five workgroup barriers per iteration:
-//     A  rhs = sigma x - q + rho z - y + A^T w                   | P1  t = G b_J,  part = K_CJ t        (G waves)
-//     P3 r_I = b_I - part,  y_I = S^-1 r_I      (S waves)        | P4  x_J = G (b_J - K_JC y_I) - w x_T  (G waves)
-//     E  z~ = A x~, relaxation, projection, dual update (S waves)
+// Waves 0..7 are the G role: wave s holds G_s, one ROW per lane (98 of the lane's 128 VGPRs; lanes 49..55 of the last G wave hold
+// the 7 x 7 block of u_{N-1}).  Waves 8..15 are the S role: a quarter row of S^-1 per lane and the ADMM state of up to two
+// variables and two rows.  The roles run separate code (own register arrays) with the same barrier sequence, five workgroup
+// barriers per iteration:
+//     A  rhs = sigma x - q + rho z - y + A^T w         (S)       | P1  t = G b_J,  part = K_CJ t               (G)
+//     P3 r_I = b_I - part,  y_I = S^-1 r_I             (S)       | P4  x_J = G (b_J - K_JC y_I) - w x_T        (G)
+//     E  z~ = A x~, relaxation, projection, dual update (S)
 #pragma once
 #include "qp_kernel_v2.hpp"
 #include "structure3.hpp"
@@ -69,7 +71,10 @@ struct Qp3 {
     static constexpr int oMisc = oKT + NAP;                         // [32]  see M_* below
     static constexpr int oCD = oMisc + 32;                          // [16]  differentiation matrix
     static constexpr int oRedP = oCD + 16;                          // [160] workgroup reductions
-    static constexpr int oU = oRedP + 160;                          // union region
+    static constexpr int oCfg = oRedP + 160;                        // [64] bound tables of the configuration: lbx 0, ubx 14, lbu 28, ubu 35, lbg 42, ubg 50
+    static constexpr int oPat = oCfg + 64;                          // [49 + 28 + 28] ints: sparse K_JC pattern words (jc | cjl | cjh)
+    static constexpr int oXdG = oPat + 54;                          // [8][64] ints: where the G lanes' x~ entries go (external arm order)
+    static constexpr int oU = oXdG + 256;                           // union region
     // ---- factor view of the union ----
     static constexpr int fKJJ = oU;                                 // [NSEG][1225], later S packed [SP]
     static constexpr int fKUU = fKJJ + NSEG * D::JP;                // [28]
@@ -88,7 +93,7 @@ struct Qp3 {
     static constexpr int oRhsI = oRhsU + JS;                        // [nI]
     static constexpr int oTJ = oRhsI + e2(D::nI);                   // [8][128] wave-private vectors of the G waves ([64..] U block)
     static constexpr int oPart = oTJ + 1024;                        // [NSEG][28] K_CJ t per segment, [14] of the U block
-    static constexpr int oRIw = oPart + e2(NSEG * 28 + 14);         // [8][4 CP] wave-private r_I of the S waves; y (duals) at checks
+    static constexpr int oRIw = oPart + e2(NSEG * 28 + 16);         // [8][4 CP] wave-private r_I of the S waves; y (duals) at checks
     static constexpr int oYI = oRIw + cmax(8 * 4 * CP, MAP);        // [nI]
     static constexpr int oXt = oYI + e2(D::nI);                     // [na + 1] x~ in external arm order, T last
     static constexpr int oWg = oXt + NAP;                           // [ma] w = rho z - y
@@ -97,6 +102,9 @@ struct Qp3 {
     static constexpr int lEnd = oRedT + 8;
     static constexpr int size = cmax(fEnd, lEnd);
     static_assert(size * 8 <= 160 * 1024 - 512, "LDS budget");
+    // factor workspace (doubles per arm): aux = LDS [oKJC, oMisc) + sum|ha|, then G rows [8][49][64], then S^-1 [CP][512]
+    static constexpr int AUX = oMisc - oKJC + 8;
+    static constexpr int FAC = AUX + 8 * 49 * 64 + CP * 512;
     // misc slots
     static constexpr int M_xT = 0, M_zbT = 1, M_ybT = 2, M_baseT = 3, M_delta = 4, M_hdT = 5, M_rbT = 6, M_lbT = 7, M_ubT = 8,
                          M_xtT = 9, M_sumha = 10, M_dl = 12, M_done = 13, M_s0 = 14, M_s1 = 15, M_c0 = 16 /* 16..31: check exchange */;
@@ -109,100 +117,138 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NSEG, int NARM>
-__global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pat, Xch xch, int B) {
-    using D = Dim3<NSEG>;
-    using L = Qp3<NSEG>;
-    constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = L::NT, GS = L::GS, JS = L::JS, CP = L::CP;
-    constexpr int n_tot = NARM * na + 1, mn_tot = NARM * (ma + na) + 1;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // workgroup -> (launch slot, arm): the two arm workgroups of an OCP are 8 apart (same XCD under round-robin placement:
-    // speed only, never correctness)
-    int slot, arm;
-    if (NARM == 1) { slot = blockIdx.x; arm = 0; }
-    else { const int bi = blockIdx.x; slot = (bi >> 4) * 8 + (bi & 7); arm = (bi >> 3) & 1; }
-    if (slot >= B) return;
-    const int b = ws.perm[slot];
-    const double ts = 1.0 / (2.0 * NSEG);
-    const double rho_in = cfg.rho, rho_eq = cfg.rho * cfg.rho_eq_scale, sigma = cfg.sigma, alpha = cfg.alpha;
-    const double *zg_ = ws.z + (size_t)b * n_tot + arm * na;                 // this arm's block of the iterate
-    const double T = ws.z[(size_t)b * n_tot + NARM * na];
-    const double tsT = ts * T;
-    const double *Gkg = ws.Gk + ((size_t)b * NARM + arm) * N * 176;
-    const double *lam_rows = ws.lam + (size_t)b * mn_tot + arm * ma;         // multipliers of this arm's general rows
-    const double *x0e = ws.x0 + (size_t)b * 14 * NARM, *xfe = ws.xf + (size_t)b * 14 * NARM;
-    auto arm_x = [&](const double *xe, int r) -> double { return r < 7 ? xe[7 * arm + r] : xe[7 * NARM + 7 * arm + (r - 7)]; };
-    double *gkl = lds + L::oGk, *misc = lds + L::oMisc, *cD = lds + L::oCD, *redp = lds + L::oRedP;
-    unsigned long long *xown = NARM == 2 ? xch.buf + ((size_t)b * 2 + arm) * MPCMP_XCH_STRIDE : nullptr;
-    const unsigned long long *xpar = NARM == 2 ? xch.buf + ((size_t)b * 2 + (1 - arm)) * MPCMP_XCH_STRIDE : nullptr;
-    int dead = 0, status = 0;
-
-    // ---------------- operands of the assembly ----------------
-    for (int i = tid; i < N * 8 * GS; i += NT) gkl[i] = (i % GS < 22) ? Gkg[(i / GS) * 22 + i % GS] : 0.0;
-    for (int r = tid; r < meq; r += NT) {
-        const int k = r / 14, rr = r % 14;
-        lds[L::oCT + r] = -ts * zg_[(rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7];
+// row . operand for a G lane: broadcast LDS reads of the operand in chunks of three 16-byte pairs, so that the scheduler cannot
+// hoist all 25 reads in front of the FMAs (the row itself already takes 98 of the 128 VGPRs)
+__device__ __forceinline__ double g_dot(const double (&m)[49], const double *op) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j0 = 0; j0 < 24; j0 += 3) {
+        D2 v4[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) v4[q] = lds2(op + 2 * (j0 + q));
+#pragma unroll
+        for (int q = 0; q < 3; q++) { a0 += m[2 * (j0 + q)] * v4[q].x; a1 += m[2 * (j0 + q) + 1] * v4[q].y; }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (tid < 16) cD[tid] = c_D[tid];
-    if (tid < 32) misc[tid] = 0.0;
-    __syncthreads();
-    auto term_val = [&](uint32_t t) -> double {
-        const int r = t >> 16, a = (t >> 8) & 255, c = t & 255;
-        double va, vb, rho;
-        if (r < meq) {
-            const int i = (r / 14) % 3;
-            const double cT = lds[L::oCT + r];
-            va = a < 4 ? cD[4 * i + a] : (a == 4 ? -tsT : cT);
-            vb = c < 4 ? cD[4 * i + c] : (c == 4 ? -tsT : cT);
-            rho = rho_eq;
-        } else {
-            const double *row = gkl + (r - meq) * GS;
-            va = row[a]; vb = row[c];
-            const int q = (r - meq) & 7;
-            rho = (cfg.ubg[q] - cfg.lbg[q] < 1e-4) ? rho_eq : rho_in;
-        }
-        return rho * va * vb;
+    a0 += m[48] * op[48];
+    return a0 + a1;
+}
+
+#define QP3_PROLOGUE \
+    using D = Dim3<NSEG>; \
+    using L = Qp3<NSEG>; \
+    constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = L::NT, GS = L::GS, JS = L::JS, CP = L::CP; \
+    constexpr int n_tot = NARM * na + 1, mn_tot = NARM * (ma + na) + 1; \
+    extern __shared__ __attribute__((aligned(16))) double lds[]; \
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = tid & 63; \
+    int slot, arm; \
+    if (NARM == 1) { slot = blockIdx.x; arm = 0; } \
+    else { const int bi = blockIdx.x; slot = (bi >> 4) * 8 + (bi & 7); arm = (bi >> 3) & 1; } \
+    if (slot >= B) return; \
+    const int b = ws.perm[slot]; \
+    const double ts = 1.0 / (2.0 * NSEG); \
+    const double rho_in = cfg.rho, rho_eq = cfg.rho * cfg.rho_eq_scale, sigma = cfg.sigma, alpha = cfg.alpha; \
+    const double *zg_ = ws.z + (size_t)b * n_tot + arm * na; \
+    const double T = ws.z[(size_t)b * n_tot + NARM * na]; \
+    const double tsT = ts * T; \
+    const double *Gkg = ws.Gk + ((size_t)b * NARM + arm) * N * 176; \
+    const double *lam_rows = ws.lam + (size_t)b * mn_tot + arm * ma; \
+    const double *x0e = ws.x0 + (size_t)b * 14 * NARM, *xfe = ws.xf + (size_t)b * 14 * NARM; \
+    auto arm_x = [&](const double *xe, int r) -> double { return r < 7 ? xe[7 * arm + r] : xe[7 * NARM + 7 * arm + (r - 7)]; }; \
+    double *gkl = lds + L::oGk, *misc = lds + L::oMisc, *cD = lds + L::oCD, *redp = lds + L::oRedP; \
+    unsigned long long *xown = NARM == 2 ? xch.buf + ((size_t)b * 2 + arm) * MPCMP_XCH_STRIDE : nullptr; \
+    const unsigned long long *xpar = NARM == 2 ? xch.buf + ((size_t)b * 2 + (1 - arm)) * MPCMP_XCH_STRIDE : nullptr; \
+    int dead = 0, status = 0; \
+    for (int i = tid; i < N * 8 * GS; i += NT) gkl[i] = (i % GS < 22) ? Gkg[(i / GS) * 22 + i % GS] : 0.0; \
+    for (int r = tid; r < meq; r += NT) { \
+        const int k = r / 14, rr = r % 14; \
+        lds[L::oCT + r] = -ts * zg_[(rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7]; \
+    } \
+    if (tid < 16) cD[tid] = c_D[tid]; \
+    if (tid < 32) misc[tid] = 0.0; \
+    double *cfl = lds + L::oCfg; \
+    if (tid < 14) { cfl[tid] = cfg.lbx[tid]; cfl[14 + tid] = cfg.ubx[tid]; } \
+    else if (tid < 21) { cfl[28 + tid - 14] = cfg.lbu[tid - 14]; cfl[35 + tid - 14] = cfg.ubu[tid - 14]; } \
+    else if (tid < 29) { cfl[42 + tid - 21] = cfg.lbg[tid - 21]; cfl[50 + tid - 21] = cfg.ubg[tid - 21]; } \
+    { \
+        int *pt = reinterpret_cast<int *>(lds + L::oPat), *xg = reinterpret_cast<int *>(lds + L::oXdG); \
+        if (tid < 49) pt[tid] = (int)pat->jc[tid]; \
+        else if (tid < 77) pt[tid] = (int)pat->cjl[tid - 49]; \
+        else if (tid < 105) pt[tid] = (int)pat->cjh[tid - 77]; \
+        if (tid < 512) { \
+            const int wv = tid >> 6, ln = tid & 63; \
+            int xd = na + 1; \
+            if (wv < NSEG && ln < 49) xd = ws.ext_of_int[49 * wv + ln]; \
+            if (wv == NSEG - 1 && ln >= 49 && ln < 56) xd = ws.ext_of_int[nJ + (ln - 49)]; \
+            xg[tid] = xd; \
+        } \
+    } \
+    __syncthreads(); \
+    const double *c_lbx = cfl, *c_ubx = cfl + 14, *c_lbu = cfl + 28, *c_ubu = cfl + 35, *c_lbg = cfl + 42, *c_ubg = cfl + 50; \
+    auto term_val = [&](uint32_t t) -> double { \
+        const int r = t >> 16, a = (t >> 8) & 255, c = t & 255; \
+        double va, vb, rho; \
+        if (r < meq) { \
+            const int i = (r / 14) % 3; \
+            const double cT = lds[L::oCT + r]; \
+            va = a < 4 ? cD[4 * i + a] : (a == 4 ? -tsT : cT); \
+            vb = c < 4 ? cD[4 * i + c] : (c == 4 ? -tsT : cT); \
+            rho = rho_eq; \
+        } else { \
+            const double *row = gkl + (r - meq) * GS; \
+            va = row[a]; vb = row[c]; \
+            const int q = (r - meq) & 7; \
+            rho = (c_ubg[q] - c_lbg[q] < 1e-4) ? rho_eq : rho_in; \
+        } \
+        return rho * va * vb; \
+    }; \
+    auto dst_of = [&](int e) -> double * { \
+        if (e < D::eKUU) return lds + L::fKJJ + e; \
+        if (e < D::eKJC) return lds + L::fKUU + (e - D::eKUU); \
+        if (e < D::eKUX) return lds + L::oKJC + (e - D::eKJC); \
+        if (e < D::eKuX) return lds + L::oKUX + (e - D::eKUX); \
+        if (e < D::eKT) return lds + L::oKuX + (e - D::eKuX); \
+        if (e < D::EA) return lds + L::oKT + (e - D::eKT); \
+        return lds + L::fKJJ + (e - D::eS); \
+    }; \
+    auto assemble = [&](int e0, int e1) { \
+        for (int e = e0 + tid; e < e1; e += NT) { \
+            double acc = 0.0; \
+            const int t1 = ws.entry_ptr[e + 1]; \
+            for (int t = ws.entry_ptr[e]; t < t1; t++) acc += term_val(ws.terms[t]); \
+            *dst_of(e) = acc; \
+        } \
+    }; \
+    auto var_h = [&](int v, double &ha, double &rb, double &lo, double &hi) { \
+        ha = 0.0; \
+        if (v < 14 * N) { \
+            const int k = v / 14, c = v % 14; \
+            if (k == 0) { lo = hi = arm_x(x0e, c); } \
+            else if (k == N - 1) { const double t = arm_x(xfe, c); lo = t - cfg.eps_target; hi = t + cfg.eps_target; } \
+            else { lo = c_lbx[c]; hi = c_ubx[c]; } \
+            if (c >= 7 && k <= N - 2) ha = -ts * lam_rows[14 * k + (c - 7)]; \
+        } else { \
+            const int k = (v - 14 * N) / 7, c = (v - 14 * N) % 7; \
+            lo = c_lbu[c]; hi = c_ubu[c]; \
+            if (k <= N - 2) ha = -ts * lam_rows[14 * k + 7 + c]; \
+        } \
+        rb = (hi - lo < 1e-4) ? rho_eq : rho_in; \
     };
-    auto dst_of = [&](int e) -> double * {          // LDS home of assembled entry e
-        if (e < D::eKUU) return lds + L::fKJJ + e;
-        if (e < D::eKJC) return lds + L::fKUU + (e - D::eKUU);
-        if (e < D::eKUX) return lds + L::oKJC + (e - D::eKJC);
-        if (e < D::eKuX) return lds + L::oKUX + (e - D::eKUX);
-        if (e < D::eKT) return lds + L::oKuX + (e - D::eKuX);
-        if (e < D::EA) return lds + L::oKT + (e - D::eKT);
-        return lds + L::fKJJ + (e - D::eS);
-    };
-    auto assemble = [&](int e0, int e1) {
-        for (int e = e0 + tid; e < e1; e += NT) {
-            double acc = 0.0;
-            const int t1 = ws.entry_ptr[e + 1];
-            for (int t = ws.entry_ptr[e]; t < t1; t++) acc += term_val(ws.terms[t]);
-            *dst_of(e) = acc;
-        }
-    };
-    // Hessian arrow ha, box and rho of arm variable v (external arm order)
-    auto var_h = [&](int v, double &ha, double &rb, double &lo, double &hi) {
-        ha = 0.0;
-        if (v < 14 * N) {
-            const int k = v / 14, c = v % 14;
-            if (k == 0) { lo = hi = arm_x(x0e, c); }
-            else if (k == N - 1) { const double t = arm_x(xfe, c); lo = t - cfg.eps_target; hi = t + cfg.eps_target; }
-            else { lo = cfg.lbx[c]; hi = cfg.ubx[c]; }
-            if (c >= 7 && k <= N - 2) ha = -ts * lam_rows[14 * k + (c - 7)];
-        } else {
-            const int k = (v - 14 * N) / 7, c = (v - 14 * N) % 7;
-            lo = cfg.lbu[c]; hi = cfg.ubu[c];
-            if (k <= N - 2) ha = -ts * lam_rows[14 * k + 7 + c];
-        }
-        rb = (hi - lo < 1e-4) ? rho_eq : rho_in;
-    };
+
+// Factorisation half of the QP: assemble K_0 of one arm, invert the interior blocks and the interface Schur complement, and
+// leave the factor (one row of G_s per G lane, a quarter row of S^-1 per S lane, the sparse coupling blocks, the T column) in
+// the factor workspace `fac` [B][NARM][Qp3::FAC].  A kernel of its own so that the ADMM loop kernel's register allocation is
+// not entangled with the sweeps' (with both in one kernel the compiler kept the factor rows in scratch: 45 serialised scratch
+// reloads per matrix-vector product).
+template <int NSEG, int NARM>
+__global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, double *__restrict__ fac) {
+    QP3_PROLOGUE
     assemble(0, D::EA);
     {   // sum |ha| of this arm (Gershgorin row of T, polympc_redef.hpp:57-70)
         double s = 0.0;
         for (int v = tid; v < na; v += NT) { double ha, rb, lo, hi; var_h(v, ha, rb, lo, hi); s += fabs(ha); }
         double sv[1] = {s};
-        block_reduce16<1, false>(sv, redp, tid);          // (its barriers also publish the assembled entries)
+        block_reduce<16, 1, false>(sv, redp, tid);        // (its barriers also publish the assembled entries)
         if (tid == 0) misc[L::M_sumha] = sv[0];
     }
     // diagonal H + sigma I + rho_box of the interior and U blocks; Hessian arrow into the T column
@@ -231,25 +277,36 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
         constexpr int CB = L::CB;
         double *rdv = lds + L::fRdv;
         const int nt4 = (nb + 3) >> 2, ntile = nt4 * (nt4 + 1) / 2;
-        const bool live = tid < ntile * nblk;
-        int blk = 0, Ib = 0, Jb = 0;
-        if (live) { blk = tid / ntile; tri_decode(tid % ntile, Ib, Jb); }
-        const bool diag = live && Ib == Jb;
-        double *cb0 = lds + L::fCol + blk * cst;
-        double v[4][4];
+        // up to two tiles per thread (tile ids tid and tid + NT)
+        bool live[2], diag[2];
+        int blk[2], Ib[2], Jb[2];
+        double *cb0[2];
+        double v[2][4][4];
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
+        for (int h = 0; h < 2; h++) {
+            const int t = tid + h * NT;
+            live[h] = t < ntile * nblk;
+            blk[h] = 0; Ib[h] = 0; Jb[h] = 0;
+            if (live[h]) { blk[h] = t / ntile; tri_decode(t % ntile, Ib[h], Jb[h]); }
+            diag[h] = live[h] && Ib[h] == Jb[h];
+            cb0[h] = lds + L::fCol + blk[h] * cst;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int i = 4 * Ib + a, j = 4 * Jb + q;
-                v[a][q] = (live && i < nb && j < nb) ? (i >= j ? ld(blk, i, j) : ld(blk, j, i)) : ((live && i == j) ? 1.0 : 0.0);
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = 4 * Ib[h] + a, j = 4 * Jb[h] + q;
+                    v[h][a][q] = (live[h] && i < nb && j < nb) ? (i >= j ? ld(blk[h], i, j) : ld(blk[h], j, i)) : ((live[h] && i == j) ? 1.0 : 0.0);
+                }
             }
         }
         __syncthreads();                              // (every tile is in registers before the first column is published)
-        if (live && Jb == 0) {
 #pragma unroll
-            for (int a = 0; a < 4; a++) cb0[4 * Ib + a] = v[a][0];
-            if (Ib == 0) { if (!(v[0][0] > 0.0)) status |= 2; rdv[blk] = pivot_rcp(v[0][0]); }
+        for (int h = 0; h < 2; h++) {
+            if (live[h] && Jb[h] == 0) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) cb0[h][4 * Ib[h] + a] = v[h][a][0];
+                if (Ib[h] == 0) { if (!(v[h][0][0] > 0.0)) status |= 2; rdv[blk[h]] = pivot_rcp(v[h][0][0]); }
+            }
         }
         __syncthreads();
         const int npad = 4 * nt4;
@@ -259,40 +316,43 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
                 const int k = 4 * kb + ka;
                 if (k < npad) {
                     const int k1a = (ka + 1) & 3, k1b = kb + (ka == 3 ? 1 : 0);
-                    if (live) {
-                        const double *cur = cb0 + (k & 1) * CB;
-                        double *nxt = cb0 + ((k + 1) & 1) * CB;
-                        const D2 ci0 = lds2(cur + 4 * Ib), ci1 = lds2(cur + 4 * Ib + 2);
-                        const D2 cj0 = lds2(cur + 4 * Jb), cj1 = lds2(cur + 4 * Jb + 2);
-                        const double rd = rdv[(k & 1) * 16 + blk];
-                        const double cI[4] = {ci0.x, ci0.y, ci1.x, ci1.y};
-                        const double rJ[4] = {cj0.x * rd, cj0.y * rd, cj1.x * rd, cj1.y * rd};
 #pragma unroll
-                        for (int a = 0; a < 4; a++) {
+                    for (int h = 0; h < 2; h++) {
+                        if (live[h]) {
+                            const double *cur = cb0[h] + (k & 1) * CB;
+                            double *nxt = cb0[h] + ((k + 1) & 1) * CB;
+                            const D2 ci0 = lds2(cur + 4 * Ib[h]), ci1 = lds2(cur + 4 * Ib[h] + 2);
+                            const D2 cj0 = lds2(cur + 4 * Jb[h]), cj1 = lds2(cur + 4 * Jb[h] + 2);
+                            const double rd = rdv[(k & 1) * 16 + blk[h]];
+                            const double cI[4] = {ci0.x, ci0.y, ci1.x, ci1.y};
+                            const double rJ[4] = {cj0.x * rd, cj0.y * rd, cj1.x * rd, cj1.y * rd};
 #pragma unroll
-                            for (int q = 0; q < 4; q++) v[a][q] = v[a][q] - cI[a] * rJ[q];
-                        }
-                        if (Ib == kb) {
+                            for (int a = 0; a < 4; a++) {
 #pragma unroll
-                            for (int q = 0; q < 4; q++) v[ka][q] = rJ[q];
-                        }
-                        if (Jb == kb) {
+                                for (int q = 0; q < 4; q++) v[h][a][q] = v[h][a][q] - cI[a] * rJ[q];
+                            }
+                            if (Ib[h] == kb) {
 #pragma unroll
-                            for (int a = 0; a < 4; a++) v[a][ka] = cI[a] * rd;
-                            if (Ib == kb) v[ka][ka] = -rd;
-                        }
-                        if (k + 1 < npad) {
-                            if (Jb == k1b) {
+                                for (int q = 0; q < 4; q++) v[h][ka][q] = rJ[q];
+                            }
+                            if (Jb[h] == kb) {
 #pragma unroll
-                                for (int a = 0; a < 4; a++) nxt[4 * Ib + a] = (diag && a < k1a) ? v[k1a][a] : v[a][k1a];
-                                if (diag) {
-                                    const double pv = v[k1a][k1a];
-                                    if (!(pv > 0.0)) status |= 2;
-                                    rdv[((k + 1) & 1) * 16 + blk] = pivot_rcp(pv);
+                                for (int a = 0; a < 4; a++) v[h][a][ka] = cI[a] * rd;
+                                if (Ib[h] == kb) v[h][ka][ka] = -rd;
+                            }
+                            if (k + 1 < npad) {
+                                if (Jb[h] == k1b) {
+#pragma unroll
+                                    for (int a = 0; a < 4; a++) nxt[4 * Ib[h] + a] = (diag[h] && a < k1a) ? v[h][k1a][a] : v[h][a][k1a];
+                                    if (diag[h]) {
+                                        const double pv = v[h][k1a][k1a];
+                                        if (!(pv > 0.0)) status |= 2;
+                                        rdv[((k + 1) & 1) * 16 + blk[h]] = pivot_rcp(pv);
+                                    }
+                                } else if (Ib[h] == k1b) {
+#pragma unroll
+                                    for (int q = 0; q < 4; q++) nxt[4 * Jb[h] + q] = v[h][k1a][q];
                                 }
-                            } else if (Ib == k1b) {
-#pragma unroll
-                                for (int q = 0; q < 4; q++) nxt[4 * Jb + q] = v[k1a][q];
                             }
                         }
                     }
@@ -300,13 +360,16 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
                 }
             }
         }
-        if (live) {
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+        for (int h = 0; h < 2; h++) {
+            if (live[h]) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int i = 4 * Ib + a, j = 4 * Jb + q;
-                    if (i < nb && j <= i) st_(blk, i, j, v[a][q]);
+                for (int a = 0; a < 4; a++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = 4 * Ib[h] + a, j = 4 * Jb[h] + q;
+                        if (i < nb && j <= i) st_(blk[h], i, j, v[h][a][q]);
+                    }
                 }
             }
         }
@@ -324,14 +387,16 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
           });
     // factor registers: a G lane keeps its whole row of G_s, an S lane (later) its quarter row of S^-1
     const bool isG = wave < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 49 && lane < 56;
-    double m[JS];
+    double m[49];
 #pragma unroll
-    for (int j = 0; j < JS; j++) {
+    for (int j = 0; j < 49; j++) {
         double val = 0.0;
-        if (isG && j < 49) val = -lds[L::fKJJ + wave * D::JP + packed(lane, j)];
+        if (isG) val = -lds[L::fKJJ + wave * D::JP + packed(lane, j)];
         if (isGu && j < 7) val = -lds[L::fKUU + packed(lane - 49, j)];
         m[j] = val;
+        if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);          // one-time loads: keep the address temporaries few
     }
+
     if (tid < 28) lds[L::oGu + tid] = lds[L::fKUU + tid];           // -(K_UU^-1), for the Schur complement
     __syncthreads();
     // interface block K_II + its diagonal
@@ -350,8 +415,11 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
     // Schur complement S = K_II - sum_s K_CJ G_s K_JC - K_XU G_u K_UX: one column of K_JC at a time through the G rows in
     // registers; even and odd segments in turn (neighbours share the diagonal block of their common interface node)
     double *S = lds + L::fKJJ;
-    const uint32_t jcw = lane < 49 ? pat.jc[lane] : 0xFFFFFFFFu;
-    const uint32_t cjl = lane < 28 ? pat.cjl[lane] : 0xFFFFFFFFu, cjh = lane < 28 ? pat.cjh[lane] : 0xFFFFFFFFu;
+    const uint32_t jcw = lane < 49 ? pat->jc[lane] : 0xFFFFFFFFu;
+    const uint32_t cjl = lane < 28 ? pat->cjl[lane] : 0xFFFFFFFFu, cjh = lane < 28 ? pat->cjh[lane] : 0xFFFFFFFFu;
+    // Per-iteration opaque copies of the lane-dependent constants: everything derived from them (LDS addresses of the sparse K_JC
+    // entries, of the operands, ...) is loop invariant, and hoisted out of the ADMM loop it takes > 150 VGPRs and evicts the
+    // factor rows to scratch.  The copies are re-made by an empty asm at the top of every iteration.
     const double *kjc = lds + L::oKJC + (wave < NSEG ? wave : 0) * 196, *kux = lds + L::oKUX + (wave < NSEG ? wave : 0) * 98;
     auto kjc_entry = [&](int r, int c) -> double {          // K_JC[r][c] of this wave's segment (r = own lane)
         if (r < 7 && c < 14) return kux[r * 14 + c];
@@ -379,10 +447,8 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
             for (int c = 0; c < 28; c++) {
                 colb[lane] = lane < 49 ? kjc_entry(lane, c) : 0.0;
                 wave_sync();
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int j = 0; j < JS / 2; j++) { const D2 cv = lds2(colb + 2 * j); a0 += m[2 * j] * cv.x; a1 += m[2 * j + 1] * cv.y; }
-                eb[lane] = lane < 49 ? a0 + a1 : 0.0;
+                const double ev = g_dot(m, colb);
+                eb[lane] = lane < 49 ? ev : 0.0;
                 wave_sync();
                 if (lane < 28 && lane >= c) S[packed(14 * wave + lane, 14 * wave + c)] -= kcj_dot(lane, eb);
                 wave_sync();
@@ -403,172 +469,90 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
     sweep(nI, 1, L::CB,
           [&](int, int i, int j) -> double { return S[packed(i, j)]; },
           [&](int, int i, int j, double val) { S[packed(i, j)] = val; });        // S <- -(S^-1)
-    const int si = tid - 512, srow = si >> 2, spart = si & 3;
-    const bool sact = si >= 0 && srow < nI;
-    if (wave >= 8) {
-#pragma unroll
-        for (int j = 0; j < JS; j++) {
-            const int col = spart * CP + j;
-            m[j] = (sact && j < CP && col < nI) ? -S[packed(srow, col)] : 0.0;
-        }
-    }
+    // ---------------- hand the factor to the loop kernel (once per QP: ~45k doubles per arm) ----------------
     {
-        const int any = __syncthreads_or(status);       // (also: S consumed, the loop view may now be written)
+        const int any = __syncthreads_or(status);
         if (tid == 0 && any) atomicOr(&ws.status[b], any);
     }
+    double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
+    for (int i = tid; i < L::AUX - 8; i += NT) fa[i] = lds[L::oKJC + i];            // sparse K_JC, dense blocks, -(K_UU^-1), T column, kappa
+    if (tid == 0) fa[L::AUX - 8] = misc[L::M_sumha];
+    if (wave < 8) {
+#pragma unroll
+        for (int j = 0; j < 49; j++) fa[L::AUX + (wave * 49 + j) * 64 + lane] = m[j];
+    } else {
+        const int si = tid - 512, srow = si >> 2, spart = si & 3;
+#pragma unroll 4
+        for (int j = 0; j < CP; j++) {
+            const int col = spart * CP + j;
+            fa[L::AUX + 8 * 49 * 64 + j * 512 + si] = (srow < nI && col < nI) ? -S[packed(srow, col)] : 0.0;
+        }
+    }
+}
 
-    // ---------------- loop-resident constants ----------------
+// ADMM half of the QP (see the header comment).
+template <int NSEG, int NARM>
+__global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, const double *__restrict__ fac) {
+    QP3_PROLOGUE
+    // ---------------- the factor, as the factorisation kernel left it ----------------
+    const double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
+    for (int i = tid; i < L::AUX - 8; i += NT) lds[L::oKJC + i] = fa[i];
+    if (tid == 0) misc[L::M_sumha] = fa[L::AUX - 8];
+    const bool isG = wave < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 49 && lane < 56;
+    const uint32_t jcw = lane < 49 ? pat->jc[lane] : 0xFFFFFFFFu;
+    const uint32_t cjl = lane < 28 ? pat->cjl[lane] : 0xFFFFFFFFu, cjh = lane < 28 ? pat->cjh[lane] : 0xFFFFFFFFu;
+    (void)isG; (void)isGu;
+    __syncthreads();
+    // ---------------- role-independent pieces of the loop set-up ----------------
+    const int si = tid - 512, srow = si >> 2, spart = si & 3;      // S role: four lanes per row of S^-1, CP columns each
+    const bool sact = si >= 0 && srow < nI;
     int *rpos = reinterpret_cast<int *>(lds + L::oRpos);
     auto rhs_slot = [&](int ip) -> int {
         return ip < nJ ? L::oRhsJ + JS * (ip / 49) + ip % 49 : (ip < nJ + 7 ? L::oRhsU + (ip - nJ) : L::oRhsI + (ip - nJ - 7));
     };
-    for (int i = tid; i < L::oRedT + 8 - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;        // vectors, pads, partial sums
-    __syncthreads();
-    for (int v = tid; v < na; v += NT) {
-        double ha, rb, lo, hi;
-        var_h(v, ha, rb, lo, hi);
-        const double zv = zg_[v];
-        lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv; lds[L::oRb + v] = rb; lds[L::oRi + v] = 1.0 / rb; lds[L::oWv + v] = 0.0;
-        rpos[v] = rhs_slot(int3_of_ext(NSEG, v));
-    }
-    for (int r = tid; r < ma; r += NT) {
-        double lg, ug, rr, cf;
-        if (r < meq) { lg = ug = -ws.ceq[((size_t)b * NARM + arm) * meq + r]; rr = rho_eq; cf = lds[L::oCT + r]; }
-        else {
-            const int q = (r - meq) & 7;
-            const double gv = ws.g[((size_t)b * NARM + arm) * 8 * N + (r - meq)];
-            lg = cfg.lbg[q] - gv; ug = cfg.ubg[q] - gv;
-            rr = (ug - lg < 1e-4) ? rho_eq : rho_in;
-            cf = gkl[(r - meq) * GS + 21];
-        }
-        lds[L::oLg + r] = lg; lds[L::oUg + r] = ug; lds[L::oRr + r] = rr; lds[L::oRri + r] = 1.0 / rr; lds[L::oCf + r] = cf;
-    }
-    if (tid == 0) {
-        misc[L::M_lbT] = cfg.lbT - T; misc[L::M_ubT] = cfg.ubT - T;
-        misc[L::M_rbT] = (cfg.ubT - cfg.lbT < 1e-4) ? rho_eq : rho_in;
-    }
-    // where the solve's outputs go (x~ in external arm order)
-    int xdst = 0;
-    if (isG) xdst = ws.ext_of_int[49 * wave + lane];
-    if (isGu) xdst = ws.ext_of_int[nJ + (lane - 49)];
-    if (sact && spart == 0) xdst = ws.ext_of_int[nJ + 7 + srow];
-    __syncthreads();
-
     double *rhsI = lds + L::oRhsI, *part = lds + L::oPart, *partU = lds + L::oPart + NSEG * 28, *yI = lds + L::oYI, *xt = lds + L::oXt,
            *wg = lds + L::oWg, *wvv = lds + L::oWv, *redB = lds + L::oRedB, *redT = lds + L::oRedT;
-    double *tJ = lds + L::oTJ + (wave & 7) * 128;                  // wave-private: [0..49] segment operand / result, [64..113] U block
-    const double *bj = lds + (isGu ? L::oRhsU : L::oRhsJ + JS * (wave < NSEG ? wave : 0));
-    // K_0 x = rhs by nested dissection, three barrier-separated phases.  use_xT: subtract w x~_T (the bordered T solve).
-    auto solve = [&](const bool use_xT, const int it) {
-        // ---- P1 (G waves): t = G b_J, part = K_CJ t ----
-        if (wave < 8) {
-            if (wave < NSEG) {
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int j = 0; j < JS / 2; j++) { const D2 bv = lds2(bj + 2 * j); a0 += m[2 * j] * bv.x; a1 += m[2 * j + 1] * bv.y; }
-                const double t = a0 + a1;
-                if (lane < 49) tJ[lane] = t;
-                else if (isGu) tJ[64 + lane - 49] = t;
-                wave_sync();
-                if (lane < 28) part[wave * 28 + lane] = kcj_dot(lane, tJ);
-                if (wave == NSEG - 1 && lane >= 32 && lane < 46) {
-                    const int c = lane - 32;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int r = 0; r < 7; r++) acc += lds[L::oKuX + r * 14 + c] * tJ[64 + r];
-                    partU[c] = acc;
-                }
+    // loop-resident constants (written by every thread once the factor area has been consumed) and the rhs of K_0 w = k
+    auto init_consts = [&]() {
+        {
+            const int any = __syncthreads_or(status);       // (also: S consumed, the loop view may now be written)
+            if (tid == 0 && any) atomicOr(&ws.status[b], any);
+        }
+        for (int i = tid; i < L::oRedT + 8 - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;        // vectors, pads, partial sums
+        __syncthreads();
+        for (int v = tid; v < na; v += NT) {
+            double ha, rb, lo, hi;
+            var_h(v, ha, rb, lo, hi);
+            const double zv = zg_[v];
+            lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv; lds[L::oRb + v] = rb; lds[L::oRi + v] = 1.0 / rb; lds[L::oWv + v] = 0.0;
+            rpos[v] = rhs_slot(int3_of_ext(NSEG, v));
+        }
+        for (int r = tid; r < ma; r += NT) {
+            double lg, ug, rr, cf;
+            if (r < meq) { lg = ug = -ws.ceq[((size_t)b * NARM + arm) * meq + r]; rr = rho_eq; cf = lds[L::oCT + r]; }
+            else {
+                const int q = (r - meq) & 7;
+                const double gv = ws.g[((size_t)b * NARM + arm) * 8 * N + (r - meq)];
+                lg = c_lbg[q] - gv; ug = c_ubg[q] - gv;
+                rr = (ug - lg < 1e-4) ? rho_eq : rho_in;
+                cf = gkl[(r - meq) * GS + 21];
             }
-        } else if (use_xT && tid == 512) {
-            // this arm's share of the T solve: s_a = (T column of A^T w) - w^T rhs
-            double ssum = 0.0, bsum = 0.0;
-#pragma unroll
-            for (int w8 = 0; w8 < 8; w8++) { ssum += redT[w8]; bsum += redB[w8]; }
-            const double sa = ssum - bsum;
-            misc[L::M_s0 + arm] = sa;
-            if (NARM == 2) xch_post(xown + 8 + it, sa);
+            lds[L::oLg + r] = lg; lds[L::oUg + r] = ug; lds[L::oRr + r] = rr; lds[L::oRri + r] = 1.0 / rr; lds[L::oCf + r] = cf;
+        }
+        if (tid == 0) {
+            misc[L::M_lbT] = cfg.lbT - T; misc[L::M_ubT] = cfg.ubT - T;
+            misc[L::M_rbT] = (cfg.ubT - cfg.lbT < 1e-4) ? rho_eq : rho_in;
         }
         __syncthreads();
-        // ---- P3 (S waves): r_I = b_I - part, y_I = S^-1 r_I ----
-        double yi = 0.0;
-        if (wave >= 8) {
-            double *rIw = lds + L::oRIw + (wave - 8) * 4 * CP;
-            for (int i = lane; i < 4 * CP; i += 64) {
-                double r = 0.0;
-                if (i < nI) {
-                    const int sN = i / 14, c = i % 14;
-                    r = rhsI[i];
-                    if (sN > 0) r -= part[(sN - 1) * 28 + 14 + c];
-                    if (sN < NSEG) r -= part[sN * 28 + c];
-                    else r -= partU[c];
-                }
-                rIw[i] = r;
-            }
-            wave_sync();
-            const double *rv = rIw + spart * CP;
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int j = 0; j < CP / 2; j++) { const D2 r2 = lds2(rv + 2 * j); a0 += m[2 * j] * r2.x; a1 += m[2 * j + 1] * r2.y; }
-            yi = sum4(a0 + a1);
-            if (sact && spart == 0) yI[srow] = yi;
-        }
-        __syncthreads();
-        // ---- P4: x_J = G (b_J - K_JC y_I); x~ = y - w x~_T ----
-        double xT = 0.0;
-        if (use_xT) {
-            double s0 = misc[L::M_s0], s1 = NARM == 2 ? misc[L::M_s1] : 0.0;
-            if (NARM == 2) {
-                double sp = 0.0;
-                if (lane == 0) sp = xch_poll(xpar + 8 + it, dead);
-                sp = read_lane(sp, 0);
-                dead = __builtin_amdgcn_readfirstlane(dead);
-                if (arm == 0) s1 = sp; else s0 = sp;
-            }
-            xT = (misc[L::M_baseT] + (s0 + s1)) / misc[L::M_delta];
-        }
-        if (wave < NSEG) {
-            double cr = 0.0;
-            if (lane < 49) {
-                cr = bj[lane];
-                const double *yc = yI + 14 * wave;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t c = (jcw >> (8 * q)) & 255u;
-                    if (c != 255u) cr -= kjc[lane * 4 + q] * yc[c];
-                }
-                if (lane < 7) {
-#pragma unroll
-                    for (int c = 0; c < 14; c++) cr -= kux[lane * 14 + c] * yc[c];
-                }
-                tJ[lane] = cr;
-            } else if (isGu) {
-                cr = bj[lane - 49];
-#pragma unroll
-                for (int c = 0; c < 14; c++) cr -= lds[L::oKuX + (lane - 49) * 14 + c] * yI[14 * NSEG + c];
-                tJ[64 + lane - 49] = cr;
-            }
-            wave_sync();
-            const double *cv = isGu ? tJ + 64 : tJ;
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int j = 0; j < JS / 2; j++) { const D2 c2 = lds2(cv + 2 * j); a0 += m[2 * j] * c2.x; a1 += m[2 * j + 1] * c2.y; }
-            if (isG || isGu) xt[xdst] = (a0 + a1) - wvv[xdst] * xT;
-        } else if (wave >= 8) {
-            if (sact && spart == 0) xt[xdst] = yi - wvv[xdst] * xT;
-            if (tid == 512) xt[na] = xT;
-        }
+        for (int ip = tid; ip < na; ip += NT) lds[rhs_slot(ip)] = lds[L::oKT + ip];
         __syncthreads();
     };
-
-    // ---------------- w = K_0^-1 k, delta ----------------
-    for (int ip = tid; ip < na; ip += NT) lds[rhs_slot(ip)] = lds[L::oKT + ip];
-    __syncthreads();
-    solve(false, 0);
-    {
-        double s = 0.0;
-        for (int v = tid; v < na; v += NT) s += lds[L::oKT + int3_of_ext(NSEG, v)] * xt[v];
-        double sv[1] = {s};
-        block_reduce16<1, false>(sv, redp, tid);
+    // after the solve of K_0 w = k: w and delta of the T border (all threads; one exchange between the arm workgroups)
+    auto finish_border = [&]() {
+        double sacc = 0.0;
+        for (int v = tid; v < na; v += NT) sacc += lds[L::oKT + int3_of_ext(NSEG, v)] * xt[v];
+        double sv[1] = {sacc};
+        block_reduce<16, 1, false>(sv, redp, tid);
         for (int v = tid; v < na; v += NT) wvv[v] = xt[v];
         if (tid == 0) {
             double kap[2] = {0.0, 0.0}, sh[2] = {0.0, 0.0}, dl[2] = {0.0, 0.0};
@@ -583,216 +567,423 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
             misc[L::M_baseT] = -1.0;                              // sigma x_T - q_T + rho_T z_T - y_T with x = z = y = 0, q_T = 1 (cost = T)
             if (!(misc[L::M_delta] > 0.0)) atomicOr(&ws.status[b], 2);
         }
-    }
-    __syncthreads();
-
-    // ---------------- ADMM (OSQP form on [A; I]) ----------------
-    // S lane si owns arm variables si, si + 512 and general rows si, si + 512 (state in registers m[32..], constants in LDS)
-    constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
-    static_assert(NV <= 2 && NR <= 2 && CP + 5 * 2 <= JS, "role registers");
-    double &xv0 = m[CP], &zb0 = m[CP + 1], &yb0 = m[CP + 2], &xv1 = m[CP + 3], &zb1 = m[CP + 4], &yb1 = m[CP + 5];
-    double &zg0 = m[CP + 6], &yg0 = m[CP + 7], &zg1 = m[CP + 8], &yg1 = m[CP + 9];
-    if (wave >= 8) { xv0 = zb0 = yb0 = xv1 = zb1 = yb1 = zg0 = yg0 = zg1 = yg1 = 0.0; }
-    auto col_gather = [&](const double *w, int v) -> double {      // (A^T w)[v] without the T row
-        double s = 0.0;
-        int k, gcol;
-        if (v < 14 * N) {
-            k = v / 14; const int c = v % 14;
-            if (k % 3 != 0) {
-                const int j = k % 3, rA = 14 * 3 * (k / 3) + c;
-                s += cD[j] * w[rA] + cD[4 + j] * w[rA + 14] + cD[8 + j] * w[rA + 28];
-            } else {
-                if (k < N - 1) { const int rA = 14 * k + c; s += cD[0] * w[rA] + cD[4] * w[rA + 14] + cD[8] * w[rA + 28]; }
-                if (k > 0) { const int rB = 14 * (k - 3) + c; s += cD[3] * w[rB] + cD[7] * w[rB + 14] + cD[11] * w[rB + 28]; }
-            }
-            if (c >= 7 && k <= N - 2) s -= tsT * w[14 * k + c - 7];
-            gcol = k * 8 * GS + c;
-        } else {
-            k = (v - 14 * N) / 7; const int c = (v - 14 * N) % 7;
-            if (k <= N - 2) s -= tsT * w[14 * k + 7 + c];
-            gcol = k * 8 * GS + 14 + c;
+        __syncthreads();
+    };
+    // x~_T of the bordered solve (every wave for itself: LDS reads, and for two arms one poll of the partner's share)
+    auto border_xT = [&](int it, int ln) -> double {
+        double s0 = misc[L::M_s0], s1 = NARM == 2 ? misc[L::M_s1] : 0.0;
+        if (NARM == 2) {
+            double sp = 0.0;
+            if (ln == 0) sp = xch_poll(xpar + 8 + it, dead);
+            sp = read_lane(sp, 0);
+            dead = __builtin_amdgcn_readfirstlane(dead);
+            if (arm == 0) s1 = sp; else s0 = sp;
         }
-        const double *gc = gkl + gcol, *wp = w + meq + 8 * k;
-#pragma unroll
-        for (int q = 0; q < 8; q++) s += gc[q * GS] * wp[q];
-        return s;
+        return (misc[L::M_baseT] + (s0 + s1)) / misc[L::M_delta];
     };
-    auto row_dot = [&](const double *xe, int r) -> double {         // (A x)[r]; xe: external arm order, T at [na]
-        double s;
-        if (r < meq) {
-            const int k = r / 14, rr = r % 14, i = k % 3, ix0 = 14 * 3 * (k / 3) + rr;
-            const int ixf = (rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7;
-            s = cD[4 * i] * xe[ix0] + cD[4 * i + 1] * xe[ix0 + 14] + cD[4 * i + 2] * xe[ix0 + 28] + cD[4 * i + 3] * xe[ix0 + 42] -
-                tsT * xe[ixf] + lds[L::oCf + r] * xe[na];
-        } else {
-            const int k = (r - meq) >> 3;
-            const double *gr = gkl + (r - meq) * GS, *xk = xe + 14 * k, *uk = xe + 14 * N + 7 * k;
-            s = gr[21] * xe[na];
-#pragma unroll
-            for (int c = 0; c < 14; c++) s += gr[c] * xk[c];
-#pragma unroll
-            for (int c = 0; c < 7; c++) s += gr[14 + c] * uk[c];
-        }
-        return s;
-    };
-    auto wave_total = [&](double x) -> double {                     // sum over the 64 lanes, valid in every lane
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-        return x;
-    };
-    double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests
+    // termination test, common tail (all threads): combine the arms, add the row / column of T, decide
     const unsigned chk_base = 8 + cfg.qp_iters + 1;
-    int it = 0, done = 0, until_check = cfg.check_every, nchk = 0;
-    for (it = 1; it <= cfg.qp_iters; it++) {
-        // ---- A: rhs = sigma x - q + rho_b z_b - y_b + A^T w ----
-        if (wave >= 8) {
-            double bp = 0.0;
+    auto check_tail = [&](double (&sums)[2], double (&mx)[6], int nchk) -> int {
+        block_reduce<16, 6, true>(mx, redp, tid);
+        double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+        s1[arm] = sums[0]; s2[arm] = sums[1];
+        if (NARM == 2) {
+            if (tid == 0) {
+                unsigned long long *po = xown + chk_base + 8 * nchk;
+                const unsigned long long *pp = xpar + chk_base + 8 * nchk;
+                xch_post(po + 0, sums[0]); xch_post(po + 1, sums[1]);
 #pragma unroll
-            for (int h = 0; h < NV; h++) {
-                const int v = si + 512 * h;
-                if (v < na) {
-                    const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
-                    const double r = (sigma * xx + (lds[L::oRb + v] * zz - yy)) + col_gather(wg, v);
-                    lds[rpos[v]] = r;
-                    bp += wvv[v] * r;
-                }
+                for (int q = 0; q < 6; q++) xch_post(po + 2 + q, mx[q]);
+#pragma unroll
+                for (int q = 0; q < 8; q++) misc[L::M_c0 + q] = xch_poll(pp + q, dead);
             }
-            bp = wave_total(bp);
-            if (lane == 0) redB[wave - 8] = bp;
+            __syncthreads();
+            s1[1 - arm] = misc[L::M_c0]; s2[1 - arm] = misc[L::M_c0 + 1];
+#pragma unroll
+            for (int q = 0; q < 6; q++) mx[q] = fmax(mx[q], misc[L::M_c0 + 2 + q]);
+            __syncthreads();
         }
-        __syncthreads();
-        solve(true, it);
-        // ---- E: z~ = A x~, relaxation, projection, dual update ----
-        const bool check = (--until_check == 0);
-        if (check) until_check = cfg.check_every;
-        if (wave >= 8) {
-            double tp = 0.0;
+        const double xTv = misc[L::M_xT], zT = misc[L::M_zbT], yT = misc[L::M_ybT];
+        const double hxT = misc[L::M_hdT] * xTv + (s2[0] + s2[1]), atyT = (s1[0] + s1[1]) + yT;
+        mx[0] = fmax(mx[0], fabs(xTv - zT)); mx[1] = fmax(mx[1], fabs(xTv)); mx[2] = fmax(mx[2], fabs(zT));
+        mx[3] = fmax(mx[3], fabs(hxT + atyT + 1.0)); mx[4] = fmax(mx[4], fabs(hxT)); mx[5] = fmax(mx[5], fabs(atyT));
+        const double ep = cfg.eps_abs + cfg.eps_rel * fmax(mx[1], mx[2]);
+        const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);      // ||q||_inf = 1
+        return (mx[0] <= ep && mx[3] <= ed) ? 1 : 0;
+    };
+    // per-lane constants of the solve; the ADMM loop works on an opaque copy re-made every iteration: everything derived from
+    // them (LDS addresses of the sparse K_JC entries, of the operands, ...) is loop invariant, and hoisted out of the loop it would
+    // occupy > 100 VGPRs and evict the factor rows to scratch
+    struct LaneC { int lane, wave, srow, spart, xdst; uint32_t jcw, cjl, cjh; };
+    LaneC lc0;
+    lc0.lane = lane; lc0.wave = wave; lc0.srow = srow; lc0.spart = spart; lc0.xdst = 0; lc0.jcw = jcw; lc0.cjl = cjl; lc0.cjh = cjh;
+
+    int it_done = 0;
+    if (wave < 8) {
+        // =============================== G role ===============================
+        init_consts();
+        // lane constants of the G role, rebuilt from LDS tables on demand (nothing but the row itself stays in VGPRs across the loop)
+        const int *patw = reinterpret_cast<const int *>(lds + L::oPat), *xdg = reinterpret_cast<const int *>(lds + L::oXdG);
+        auto lane_consts = [&](int t) -> LaneC {
+            LaneC c;
+            c.lane = t & 63; c.wave = wave; c.srow = 0; c.spart = 0; c.xdst = xdg[t];
+            c.jcw = c.lane < 49 ? (uint32_t)patw[c.lane] : 0xFFFFFFFFu;
+            c.cjl = c.lane < 28 ? (uint32_t)patw[49 + c.lane] : 0xFFFFFFFFu;
+            c.cjh = c.lane < 28 ? (uint32_t)patw[77 + c.lane] : 0xFFFFFFFFu;
+            return c;
+        };
+        // this lane's row of G_s (k_qp3f left it in the factor workspace)
+        double mm[49];
+        // (Re-)load the row from the factor workspace (L2 resident) through an opaque pointer.  It is loaded again at the top of every
+        // termination-test period: a value defined right in front of the hot loop and dead after it is kept in VGPRs by the register
+        // allocator, whereas one that is live across the whole kernel was assigned a stack slot with a scratch reload folded into
+        // every use (49 serialised scratch loads per matrix-vector product), although the loop leaves 100 VGPRs free.
+        auto load_row = [&]() {
+            const double *fo = fa + L::AUX + (size_t)(wave * 49) * 64 + lane;
+            asm volatile("" : "+v"(fo));
 #pragma unroll
-            for (int h = 0; h < NR; h++) {
-                const int r = si + 512 * h;
-                if (r < ma) {
-                    double &zg = h ? zg1 : zg0, &yg = h ? yg1 : yg0;
-                    const double rr = lds[L::oRr + r];
-                    const double zt = row_dot(xt, r);
-                    const double zr = alpha * zt + (1.0 - alpha) * zg;
-                    const double zn = clip(zr + yg * lds[L::oRri + r], lds[L::oLg + r], lds[L::oUg + r]);
-                    yg += rr * (zr - zn);
-                    zg = zn;
-                    const double w = rr * zg - yg;
-                    wg[r] = w;
-                    tp += lds[L::oCf + r] * w;
-                }
-            }
-            tp = wave_total(tp);
-            if (lane == 0) redT[wave - 8] = tp;       // (read by the next iteration's P1 window: two barriers away)
-#pragma unroll
-            for (int h = 0; h < NV; h++) {
-                const int v = si + 512 * h;
-                if (v < na) {
-                    double &xx = h ? xv1 : xv0, &zz = h ? zb1 : zb0, &yy = h ? yb1 : yb0;
-                    const double xtv = xt[v], rb = lds[L::oRb + v];
-                    xx = alpha * xtv + (1.0 - alpha) * xx;
-                    const double zr = alpha * xtv + (1.0 - alpha) * zz;
-                    const double zn = clip(zr + yy * lds[L::oRi + v], lds[L::oLb + v], lds[L::oUb + v]);
-                    yy += rb * (zr - zn);
-                    zz = zn;
-                }
-            }
-            if (tid == 512) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
-                const double xtv = xt[na], rb = misc[L::M_rbT];
-                double xx = misc[L::M_xT], zz = misc[L::M_zbT], yy = misc[L::M_ybT];
-                xx = alpha * xtv + (1.0 - alpha) * xx;
-                const double zr = alpha * xtv + (1.0 - alpha) * zz;
-                const double zn = clip(zr + yy / rb, misc[L::M_lbT], misc[L::M_ubT]);
-                yy += rb * (zr - zn);
-                zz = zn;
-                misc[L::M_xT] = xx; misc[L::M_zbT] = zz; misc[L::M_ybT] = yy;
-                misc[L::M_baseT] = (sigma * xx - 1.0) + (rb * zz - yy);
-            }
-        }
-        __syncthreads();
-        if (check) {
-            // ---- termination test: r_prim = ||[A;I]x - z||inf, r_dual = ||Hx + q + [A;I]^T y||inf (oracle/ocp.c admm) ----
-            double sums[2] = {0.0, 0.0};              // T row: sum coefT_r y_r, sum ha_i x_i of this arm
-            if (wave >= 8) {
-#pragma unroll
-                for (int h = 0; h < NR; h++) {
-                    const int r = si + 512 * h;
-                    if (r < ma) { const double yg = h ? yg1 : yg0; ys[r] = yg; sums[0] += lds[L::oCf + r] * yg; }
-                }
-#pragma unroll
-                for (int h = 0; h < NV; h++) {
-                    const int v = si + 512 * h;
-                    if (v < na) {
-                        const double xx = h ? xv1 : xv0;
-                        double ha, rb, lo, hi;
-                        var_h(v, ha, rb, lo, hi);
-                        xt[v] = xx; sums[1] += ha * xx;
-                    }
-                }
-                if (tid == 512) xt[na] = misc[L::M_xT];
-            }
-            block_reduce16<2, false>(sums, redp, tid);           // (its barriers publish xt / ys)
-            double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
-            if (wave >= 8) {
-                const double xTc = xt[na];
-#pragma unroll
-                for (int h = 0; h < NR; h++) {
-                    const int r = si + 512 * h;
-                    if (r < ma) {
-                        const double zg = h ? zg1 : zg0, ax = row_dot(xt, r);
-                        mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
-                    }
-                }
-#pragma unroll
-                for (int h = 0; h < NV; h++) {
-                    const int v = si + 512 * h;
-                    if (v < na) {
-                        const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
-                        double ha, rb, lo, hi;
-                        var_h(v, ha, rb, lo, hi);
-                        const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, v) + yy;
-                        mx[0] = fmax(mx[0], fabs(xx - zz)); mx[1] = fmax(mx[1], fabs(xx)); mx[2] = fmax(mx[2], fabs(zz));
-                        mx[3] = fmax(mx[3], fabs(hx + aty)); mx[4] = fmax(mx[4], fabs(hx)); mx[5] = fmax(mx[5], fabs(aty));
-                    }
-                }
-            }
-            block_reduce16<6, true>(mx, redp, tid);
-            // combine the arms and add the row / column of T (identical arithmetic in both arm workgroups)
-            double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
-            s1[arm] = sums[0]; s2[arm] = sums[1];
-            if (NARM == 2) {
-                if (tid == 0) {
-                    unsigned long long *po = xown + chk_base + 8 * nchk;
-                    const unsigned long long *pp = xpar + chk_base + 8 * nchk;
-                    xch_post(po + 0, sums[0]); xch_post(po + 1, sums[1]);
-#pragma unroll
-                    for (int q = 0; q < 6; q++) xch_post(po + 2 + q, mx[q]);
-#pragma unroll
-                    for (int q = 0; q < 8; q++) misc[L::M_c0 + q] = xch_poll(pp + q, dead);
-                }
-                __syncthreads();
-                s1[1 - arm] = misc[L::M_c0]; s2[1 - arm] = misc[L::M_c0 + 1];
-#pragma unroll
-                for (int q = 0; q < 6; q++) mx[q] = fmax(mx[q], misc[L::M_c0 + 2 + q]);
-                __syncthreads();
-            }
-            nchk++;
+            for (int j = 0; j < 49; j++) mm[j] = fo[j * 64];
+        };
+        load_row();
+        // Branch-free per lane (selects and dummy slots instead of lane-dependent branches: with a dozen exec-masked blocks in the
+        // hot loop the register allocator gave up on keeping the row in VGPRs).
+        auto solve_g = [&](const bool use_xT, const int it, const LaneC &c) {
+            const int ln = c.lane, wv = wave;
+            if (wv >= NSEG) { __syncthreads(); __syncthreads(); __syncthreads(); return; }      // (N = 19: waves 6, 7 hold no segment)
+            const bool g_row = ln < 49, gu_row = wv == NSEG - 1 && ln >= 49 && ln < 56;
+            const int lr = g_row ? ln : (gu_row ? ln - 49 : 0);                  // row inside its block
+            double *tJ = lds + L::oTJ + wv * 128;                  // wave-private: [0..49] segment operand / result, [64..113] U block, [120] dummy
+            const double *bj = lds + (gu_row ? L::oRhsU : L::oRhsJ + JS * wv);
+            const double *kjc_ = lds + L::oKJC + wv * 196, *kux_ = lds + L::oKUX + wv * 98, *kuX = lds + L::oKuX;
+            const int tslot = g_row ? ln : (gu_row ? 64 + ln - 49 : 120);
+            // ---- P1: t = G b_J, part = K_CJ t ----
             {
-                const double xTc = misc[L::M_xT], zT = misc[L::M_zbT], yT = misc[L::M_ybT];
-                const double hxT = misc[L::M_hdT] * xTc + (s2[0] + s2[1]), atyT = (s1[0] + s1[1]) + yT;
-                mx[0] = fmax(mx[0], fabs(xTc - zT)); mx[1] = fmax(mx[1], fabs(xTc)); mx[2] = fmax(mx[2], fabs(zT));
-                mx[3] = fmax(mx[3], fabs(hxT + atyT + 1.0)); mx[4] = fmax(mx[4], fabs(hxT)); mx[5] = fmax(mx[5], fabs(atyT));
+                tJ[tslot] = g_dot(mm, bj);
+                wave_sync();
+                const int cl = ln < 28 ? ln : 27;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t ref = ((q < 4 ? c.cjl : c.cjh) >> (8 * (q & 3))) & 255u;
+                    double kv = kjc_[(ref >> 2) * 4 + (ref & 3u)];           // (ref = 255: a valid address, value discarded)
+                    kv = ref != 255u ? kv : 0.0;
+                    acc += kv * tJ[(ref >> 2) & 63];
+                    if (q == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const double f14 = ln < 14 ? 1.0 : 0.0;
+                const int c14 = ln < 14 ? ln : 13;
+                double accd = 0.0;
+#pragma unroll
+                for (int r = 0; r < 7; r++) { accd += kux_[r * 14 + c14] * tJ[r]; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
+                acc += f14 * accd;
+                part[ln < 28 ? wv * 28 + cl : NSEG * 28 + 14] = acc;              // (dummy slot behind partU)
+                if (wv == NSEG - 1) {
+                    const int cc = (ln >= 32 && ln < 46) ? ln - 32 : 0;
+                    double au = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 7; r++) { au += kuX[r * 14 + cc] * tJ[64 + r]; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
+                    partU[(ln >= 32 && ln < 46) ? cc : 15] = au;                  // (15: dummy)
+                }
             }
-            const double ep = cfg.eps_abs + cfg.eps_rel * fmax(mx[1], mx[2]);
-            const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);      // ||q||_inf = 1
-            if (mx[0] <= ep && mx[3] <= ed) done = 1;
+            __syncthreads();
+            // ---- P3 (S role) ----
+            __syncthreads();
+            // ---- P4: x_J = G (b_J - K_JC y_I); x~ = y - w x~_T ----
+            {
+                const double xT = use_xT ? border_xT(it, ln) : 0.0;
+                const double *yc = yI + 14 * wv;
+                double cr = bj[lr];
+                const double fs = g_row ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t cc = (c.jcw >> (8 * q)) & 255u;
+                    double kv = kjc_[lr * 4 + q];
+                    kv = cc != 255u ? kv : 0.0;
+                    cr -= fs * kv * yc[cc & 31u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // dense part: rows u_3s x x_3s of the segment, or the U block x x_{N-1}
+                const double fd = (ln < 7 || gu_row) ? 1.0 : 0.0;
+                const double *dp = gu_row ? kuX + lr * 14 : kux_ + (ln < 7 ? ln : 0) * 14, *yb = gu_row ? yI + 14 * NSEG : yc;
+                double cd = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < 14; cc++) { cd += dp[cc] * yb[cc]; if (cc % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
+                cr -= fd * cd;
+                tJ[tslot] = cr;
+                wave_sync();
+                const double xj = g_dot(mm, gu_row ? tJ + 64 : tJ);
+                xt[c.xdst] = xj - wvv[c.xdst] * xT;                            // (inactive lanes: xdst = na + 1, a pad slot)
+            }
+            __syncthreads();
+        };
+        solve_g(false, 0, lane_consts(tid));          // K_0 w = k (the T border)
+        finish_border();
+        // The hot loop is the INNER loop (one termination-test period): it contains nothing but the two matrix-vector phases, so
+        // the register allocator keeps the factor row in VGPRs across it; the test itself sits in the outer loop.
+        int it = 0, done = 0, nchk = 0;
+        while (it < cfg.qp_iters && !done) {
+            const int cnt = cfg.qp_iters - it < cfg.check_every ? cfg.qp_iters - it : cfg.check_every;
+            load_row();
+            for (int k = 0; k < cnt; k++) {
+                int tido = tid;
+                asm volatile("" : "+v"(tido));
+                __syncthreads();                    // A (S role)
+                solve_g(true, it + 1 + k, lane_consts(tido));
+                __syncthreads();                    // E (S role)
+            }
+            it += cnt;
+            if (cnt == cfg.check_every) {
+                double sums[2] = {0.0, 0.0}, mx[6] = {0, 0, 0, 0, 0, 0};
+                block_reduce<16, 2, false>(sums, redp, tid);
+                done = check_tail(sums, mx, nchk++);
+            }
         }
-        if (done) break;
-    }
-    if (it > cfg.qp_iters) it = cfg.qp_iters;
-    // ---------------- results ----------------
-    if (wave >= 8) {
+        it_done = it;
+    } else {
+        // =============================== S role ===============================
+        if (sact && spart == 0) lc0.xdst = ws.ext_of_int[nJ + 7 + srow];
+        init_consts();
+        double sm[CP];                                              // this lane's quarter row of S^-1
+#pragma unroll
+        for (int j = 0; j < CP; j++) sm[j] = fa[L::AUX + 8 * 49 * 64 + j * 512 + si];
+        auto solve_s = [&](const bool use_xT, const int it, const LaneC &c) {
+            const int ln = c.lane, wv = c.wave;
+            // ---- P1 window: this arm's share of the T solve, s_a = (T column of A^T w) - w^T rhs ----
+            if (use_xT && wv == 15 && ln == 63) {
+                double ssum = 0.0, bsum = 0.0;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; w8++) { ssum += redT[w8]; bsum += redB[w8]; }
+                const double sa = ssum - bsum;
+                misc[L::M_s0 + arm] = sa;
+                if (NARM == 2) xch_post(xown + 8 + it, sa);
+            }
+            __syncthreads();
+            // ---- P3: r_I = b_I - part, y_I = S^-1 r_I ----
+            double *rIw = lds + L::oRIw + (wv - 8) * 4 * CP;
+            for (int i = ln; i < 4 * CP; i += 64) {
+                double r = 0.0;
+                if (i < nI) {
+                    const int sN = i / 14, cc = i % 14;
+                    r = rhsI[i];
+                    if (sN > 0) r -= part[(sN - 1) * 28 + 14 + cc];
+                    if (sN < NSEG) r -= part[sN * 28 + cc];
+                    else r -= partU[cc];
+                }
+                rIw[i] = r;
+            }
+            wave_sync();
+            const double *rv = rIw + c.spart * CP;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int j0 = 0; j0 < CP / 2; j0 += 4) {
+                D2 v4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (j0 + q < CP / 2) v4[q] = lds2(rv + 2 * (j0 + q));
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (j0 + q < CP / 2) { a0 += sm[2 * (j0 + q)] * v4[q].x; a1 += sm[2 * (j0 + q) + 1] * v4[q].y; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const double yi = sum4(a0 + a1);
+            const bool s_out = c.srow < nI && c.spart == 0;
+            if (s_out) yI[c.srow] = yi;
+            __syncthreads();
+            // ---- P4: interface part of x~ ----
+            const double xT = use_xT ? border_xT(it, ln) : 0.0;
+            if (s_out) xt[c.xdst] = yi - wvv[c.xdst] * xT;
+            if (wv == 15 && ln == 63) xt[na] = xT;
+            __syncthreads();
+        };
+        // S lane si owns arm variables si, si + 512 and general rows si, si + 512 (ADMM state in registers, constants in LDS)
+        constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
+        static_assert(NV <= 2 && NR <= 2, "two variables and two rows per S lane at most");
+        double xv0 = 0, zb0 = 0, yb0 = 0, xv1 = 0, zb1 = 0, yb1 = 0, zg0 = 0, yg0 = 0, zg1 = 0, yg1 = 0;
+        auto col_gather = [&](const double *w, int v) -> double {      // (A^T w)[v] without the T row
+            double sacc = 0.0;
+            int k, gcol;
+            if (v < 14 * N) {
+                k = v / 14; const int c = v % 14;
+                if (k % 3 != 0) {
+                    const int j = k % 3, rA = 14 * 3 * (k / 3) + c;
+                    sacc += cD[j] * w[rA] + cD[4 + j] * w[rA + 14] + cD[8 + j] * w[rA + 28];
+                } else {
+                    if (k < N - 1) { const int rA = 14 * k + c; sacc += cD[0] * w[rA] + cD[4] * w[rA + 14] + cD[8] * w[rA + 28]; }
+                    if (k > 0) { const int rB = 14 * (k - 3) + c; sacc += cD[3] * w[rB] + cD[7] * w[rB + 14] + cD[11] * w[rB + 28]; }
+                }
+                if (c >= 7 && k <= N - 2) sacc -= tsT * w[14 * k + c - 7];
+                gcol = k * 8 * GS + c;
+            } else {
+                k = (v - 14 * N) / 7; const int c = (v - 14 * N) % 7;
+                if (k <= N - 2) sacc -= tsT * w[14 * k + 7 + c];
+                gcol = k * 8 * GS + 14 + c;
+            }
+            const double *gc = gkl + gcol, *wp = w + meq + 8 * k;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; q++) sacc += gc[q * GS] * wp[q];
+            __builtin_amdgcn_sched_barrier(0);
+            return sacc;
+        };
+        auto row_dot = [&](const double *xe, int r) -> double {         // (A x)[r]; xe: external arm order, T at [na]
+            double sacc;
+            if (r < meq) {
+                const int k = r / 14, rr = r % 14, i = k % 3, ix0 = 14 * 3 * (k / 3) + rr;
+                const int ixf = (rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7;
+                sacc = cD[4 * i] * xe[ix0] + cD[4 * i + 1] * xe[ix0 + 14] + cD[4 * i + 2] * xe[ix0 + 28] + cD[4 * i + 3] * xe[ix0 + 42] -
+                       tsT * xe[ixf] + lds[L::oCf + r] * xe[na];
+            } else {
+                const int k = (r - meq) >> 3;
+                const double *gr = gkl + (r - meq) * GS, *xk = xe + 14 * k, *uk = xe + 14 * N + 7 * k;
+                sacc = gr[21] * xe[na];
+                // (chunks of seven terms: all 42 operand reads in flight at once would cost 84 VGPRs)
+#pragma unroll
+                for (int c = 0; c < 7; c++) sacc += gr[c] * xk[c];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 7; c < 14; c++) sacc += gr[c] * xk[c];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 7; c++) sacc += gr[14 + c] * uk[c];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return sacc;
+        };
+        auto wave_total = [&](double x) -> double {                     // sum over the 64 lanes, valid in every lane
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            return x;
+        };
+        double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests
+        {
+            LaneC lc = lc0;
+            solve_s(false, 0, lc);                    // K_0 w = k (the T border)
+            finish_border();
+        }
+        int it = 0, done = 0, nchk = 0;
+        while (it < cfg.qp_iters && !done) {
+            const int cnt = cfg.qp_iters - it < cfg.check_every ? cfg.qp_iters - it : cfg.check_every;
+            for (int k = 0; k < cnt; k++) {           // the hot loop: one termination-test period
+                LaneC lc = lc0;
+                int sio = si;
+                asm volatile("" : "+v"(lc.lane), "+v"(lc.wave), "+v"(lc.srow), "+v"(lc.spart), "+v"(lc.xdst), "+v"(sio));
+                // ---- A: rhs = sigma x - q + rho_b z_b - y_b + A^T w ----
+                {
+                    double bp = 0.0;
+#pragma unroll
+                    for (int h = 0; h < NV; h++) {
+                        const int v = sio + 512 * h;
+                        if (v < na) {
+                            const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
+                            const double r = (sigma * xx + (lds[L::oRb + v] * zz - yy)) + col_gather(wg, v);
+                            lds[rpos[v]] = r;
+                            bp += wvv[v] * r;
+                        }
+                    }
+                    bp = wave_total(bp);
+                    if (lc.lane == 0) redB[lc.wave - 8] = bp;
+                }
+                __syncthreads();
+                solve_s(true, it + 1 + k, lc);
+                // ---- E: z~ = A x~, relaxation, projection, dual update ----
+                {
+                    double tp = 0.0;
+#pragma unroll
+                    for (int h = 0; h < NR; h++) {
+                        const int r = sio + 512 * h;
+                        if (r < ma) {
+                            double &zg = h ? zg1 : zg0, &yg = h ? yg1 : yg0;
+                            const double rr = lds[L::oRr + r];
+                            const double zt = row_dot(xt, r);
+                            const double zr = alpha * zt + (1.0 - alpha) * zg;
+                            const double zn = clip(zr + yg * lds[L::oRri + r], lds[L::oLg + r], lds[L::oUg + r]);
+                            yg += rr * (zr - zn);
+                            zg = zn;
+                            const double w = rr * zg - yg;
+                            wg[r] = w;
+                            tp += lds[L::oCf + r] * w;
+                        }
+                    }
+                    tp = wave_total(tp);
+                    if (lc.lane == 0) redT[lc.wave - 8] = tp;     // (read by the next iteration's P1 window: two barriers away)
+#pragma unroll
+                    for (int h = 0; h < NV; h++) {
+                        const int v = sio + 512 * h;
+                        if (v < na) {
+                            double &xx = h ? xv1 : xv0, &zz = h ? zb1 : zb0, &yy = h ? yb1 : yb0;
+                            const double xtv = xt[v], rb = lds[L::oRb + v];
+                            xx = alpha * xtv + (1.0 - alpha) * xx;
+                            const double zr = alpha * xtv + (1.0 - alpha) * zz;
+                            const double zn = clip(zr + yy * lds[L::oRi + v], lds[L::oLb + v], lds[L::oUb + v]);
+                            yy += rb * (zr - zn);
+                            zz = zn;
+                        }
+                    }
+                    if (sio == 511) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
+                        const double xtv = xt[na], rb = misc[L::M_rbT];
+                        double xx = misc[L::M_xT], zz = misc[L::M_zbT], yy = misc[L::M_ybT];
+                        xx = alpha * xtv + (1.0 - alpha) * xx;
+                        const double zr = alpha * xtv + (1.0 - alpha) * zz;
+                        const double zn = clip(zr + yy / rb, misc[L::M_lbT], misc[L::M_ubT]);
+                        yy += rb * (zr - zn);
+                        zz = zn;
+                        misc[L::M_xT] = xx; misc[L::M_zbT] = zz; misc[L::M_ybT] = yy;
+                        misc[L::M_baseT] = (sigma * xx - 1.0) + (rb * zz - yy);
+                    }
+                }
+                __syncthreads();
+            }
+            it += cnt;
+            if (cnt == cfg.check_every) {
+                int sio = si;
+                asm volatile("" : "+v"(sio));
+                {
+                    // ---- termination test: r_prim = ||[A;I]x - z||inf, r_dual = ||Hx + q + [A;I]^T y||inf (oracle/ocp.c admm) ----
+                    double sums[2] = {0.0, 0.0};              // T row: sum coefT_r y_r, sum ha_i x_i of this arm
+#pragma unroll
+                    for (int h = 0; h < NR; h++) {
+                        const int r = sio + 512 * h;
+                        if (r < ma) { const double yg = h ? yg1 : yg0; ys[r] = yg; sums[0] += lds[L::oCf + r] * yg; }
+                    }
+#pragma unroll
+                    for (int h = 0; h < NV; h++) {
+                        const int v = sio + 512 * h;
+                        if (v < na) {
+                            const double xx = h ? xv1 : xv0;
+                            double ha, rb, lo, hi;
+                            var_h(v, ha, rb, lo, hi);
+                            xt[v] = xx; sums[1] += ha * xx;
+                        }
+                    }
+                    if (sio == 511) xt[na] = misc[L::M_xT];
+                    block_reduce<16, 2, false>(sums, redp, tid);         // (its barriers publish xt / ys)
+                    double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
+                    const double xTc = xt[na];
+#pragma unroll
+                    for (int h = 0; h < NR; h++) {
+                        const int r = sio + 512 * h;
+                        if (r < ma) {
+                            const double zg = h ? zg1 : zg0, ax = row_dot(xt, r);
+                            mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < NV; h++) {
+                        const int v = sio + 512 * h;
+                        if (v < na) {
+                            const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
+                            double ha, rb, lo, hi;
+                            var_h(v, ha, rb, lo, hi);
+                            const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, v) + yy;
+                            mx[0] = fmax(mx[0], fabs(xx - zz)); mx[1] = fmax(mx[1], fabs(xx)); mx[2] = fmax(mx[2], fabs(zz));
+                            mx[3] = fmax(mx[3], fabs(hx + aty)); mx[4] = fmax(mx[4], fabs(hx)); mx[5] = fmax(mx[5], fabs(aty));
+                        }
+                    }
+                    done = check_tail(sums, mx, nchk++);
+                }
+            }
+        }
+        it_done = it;
+        // ---------------- results ----------------
 #pragma unroll
         for (int h = 0; h < NV; h++) {
             const int v = si + 512 * h;
@@ -806,7 +997,7 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
             const int r = si + 512 * h;
             if (r < ma) ws.y[(size_t)b * mn_tot + arm * ma + r] = h ? yg1 : yg0;
         }
-        if (tid == 512 && arm == 0) {
+        if (si == 511 && arm == 0) {
             ws.p[(size_t)b * n_tot + NARM * na] = misc[L::M_xT];
             ws.y[(size_t)b * mn_tot + mn_tot - 1] = misc[L::M_ybT];
         }
@@ -814,7 +1005,7 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, Qp3Pat pa
     {
         const int any = __syncthreads_or(dead ? 4 : 0);         // bit 2: the partner workgroup never answered
         if (tid == 0) {
-            if (arm == 0) { ws.qpit[b] = it; ws.qp_total[b] += it; }
+            if (arm == 0) { ws.qpit[b] = it_done; ws.qp_total[b] += it_done; }
             if (any) atomicOr(&ws.status[b], any);
         }
     }
