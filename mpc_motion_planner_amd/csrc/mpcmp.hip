@@ -597,7 +597,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
             if (V3C) {
                 double *fh = ctx->d_fac + (size_t)boff[h] * Qp3<V3C ? NSEG : 6>::FAC;
                 hipLaunchKernelGGL((k_qp3f<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);
-                hipLaunchKernelGGL((k_qp3<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
+                hipLaunchKernelGGL((k_qp3<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(512), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
             }
             else if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(Bh[h]), dim3(1024), l_qp2, sh[h], ctx->cfg, wh[h], ctx->streams);
             else hipLaunchKernelGGL((k_qp<V3C ? 1 : NSEG>), dim3(Bh[h]), dim3(Dim<V3C ? 1 : NSEG>::NT), l_qp, sh[h], ctx->cfg, wh[h]);
@@ -661,7 +661,7 @@ static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double 
             const int grid = NARM == 1 ? Bh[h] : ((Bh[h] + 7) / 8) * 16;       // arm workgroups of one OCP are 8 apart (k_qp3)
             double *fh = ctx->d_fac + (size_t)boff[h] * NARM * Qp3<NSEG>::FAC;
             hipLaunchKernelGGL((k_qp3f<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], fh);
-            hipLaunchKernelGGL((k_qp3<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], (const double *)fh);
+            hipLaunchKernelGGL((k_qp3<NSEG, NARM>), dim3(grid), dim3(512), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], (const double *)fh);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;
             hipLaunchKernelGGL((k_step_m<NSEG, NARM>), dim3(Bh[h]), dim3(D::NT), l_m, sh[h], ctx->cfg, ctx->d_model, wh[h], xh[h],

@@ -94,8 +94,8 @@ struct Qp3 {
     static constexpr int oTJ = oRhsI + e2(D::nI);                   // [8][128] wave-private vectors of the G waves ([64..] U block)
     static constexpr int oPart = oTJ + 1024;                        // [NSEG][28] K_CJ t per segment, [14] of the U block
     static constexpr int oRIw = oPart + e2(NSEG * 28 + 16);         // [8][4 CP] wave-private r_I of the S waves; y (duals) at checks
-    static constexpr int oYI = oRIw + cmax(8 * 4 * CP, MAP);        // [nI]
-    static constexpr int oXt = oYI + e2(D::nI);                     // [na + 1] x~ in external arm order, T last
+    static constexpr int oYI = oRIw + cmax(8 * 4 * CP, MAP);        // [nI] + pad slot
+    static constexpr int oXt = oYI + e2(D::nI + 2);                    // [na + 1] x~ in external arm order, T last
     static constexpr int oWg = oXt + NAP;                           // [ma] w = rho z - y
     static constexpr int oRedB = oWg + MAP;                         // [8] per-wave partial sums of w^T rhs
     static constexpr int oRedT = oRedB + 8;                         // [8] per-wave partial sums of the T column of A^T w
@@ -134,10 +134,20 @@ __device__ __forceinline__ double g_dot(const double (&m)[49], const double *op)
     return a0 + a1;
 }
 
-#define QP3_PROLOGUE \
+// diagnostic builds (-DMPCMP_STAMPS, tools/stamps3.py): cycles per phase of the ADMM loop (QS: after a barrier) and the busy part of
+// each phase per wave (QB: in front of the barrier)
+#ifdef MPCMP_STAMPS
+#define QS(k) do { const unsigned long long n_ = clock64(); st_acc[k] += n_ - st_t; st_t = n_; } while (0)
+#define QB(k) do { st_busy[k] += clock64() - st_t; } while (0)
+#else
+#define QS(k) do { } while (0)
+#define QB(k) do { } while (0)
+#endif
+
+#define QP3_PROLOGUE(NT_) \
     using D = Dim3<NSEG>; \
     using L = Qp3<NSEG>; \
-    constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = L::NT, GS = L::GS, JS = L::JS, CP = L::CP; \
+    constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = NT_, GS = L::GS, JS = L::JS, CP = L::CP; \
     constexpr int n_tot = NARM * na + 1, mn_tot = NARM * (ma + na) + 1; \
     extern __shared__ __attribute__((aligned(16))) double lds[]; \
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = tid & 63; \
@@ -242,7 +252,7 @@ __device__ __forceinline__ double g_dot(const double (&m)[49], const double *op)
 // reloads per matrix-vector product).
 template <int NSEG, int NARM>
 __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, double *__restrict__ fac) {
-    QP3_PROLOGUE
+    QP3_PROLOGUE(1024)
     assemble(0, D::EA);
     {   // sum |ha| of this arm (Gershgorin row of T, polympc_redef.hpp:57-70)
         double s = 0.0;
@@ -490,34 +500,35 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     }
 }
 
-// ADMM half of the QP (see the header comment).
+// ADMM half of the QP (see the header comment): 512 threads = 8 waves, two per SIMD, so every lane may hold 256 registers — its row
+// of G_s (98), its quarter row of S^-1 (2 CP) and its ADMM state stay in VGPRs for the whole loop.  (With 1024 threads and 128
+// registers the compiler kept part of the rows in scratch; one scratch reload costs ~500 cycles and they are serialised, so the
+// seven reloads of a 26-term dot product made it take 3,500 cycles.)  Every wave takes part in every phase:
+//     A   rhs = sigma x - q + rho_b z_b - y_b + A^T w                      (lane = variable)
+//     P1  t = G b_J, part = K_CJ t                                         (wave = segment, lane = row of G_s)
+//     P3  r_I = b_I - part, y_I = S^-1 r_I                                 (four lanes per row of S^-1)
+//     P4  x_J = G (b_J - K_JC y_I), x~ = y - w x~_T                        (wave = segment; interface rows by the S lanes)
+//     E   z~ = A x~, relaxation, projection, dual update                   (lane = row / variable)
 template <int NSEG, int NARM>
-__global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, const double *__restrict__ fac) {
-    QP3_PROLOGUE
+__global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, const double *__restrict__ fac) {
+    QP3_PROLOGUE(512)
+#ifdef MPCMP_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_busy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#endif
     // ---------------- the factor, as the factorisation kernel left it ----------------
     const double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
     for (int i = tid; i < L::AUX - 8; i += NT) lds[L::oKJC + i] = fa[i];
     if (tid == 0) misc[L::M_sumha] = fa[L::AUX - 8];
-    const bool isG = wave < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 49 && lane < 56;
-    const uint32_t jcw = lane < 49 ? pat->jc[lane] : 0xFFFFFFFFu;
-    const uint32_t cjl = lane < 28 ? pat->cjl[lane] : 0xFFFFFFFFu, cjh = lane < 28 ? pat->cjh[lane] : 0xFFFFFFFFu;
-    (void)isG; (void)isGu;
     __syncthreads();
-    // ---------------- role-independent pieces of the loop set-up ----------------
-    const int si = tid - 512, srow = si >> 2, spart = si & 3;      // S role: four lanes per row of S^-1, CP columns each
-    const bool sact = si >= 0 && srow < nI;
+    // ---------------- loop set-up ----------------
     int *rpos = reinterpret_cast<int *>(lds + L::oRpos);
     auto rhs_slot = [&](int ip) -> int {
         return ip < nJ ? L::oRhsJ + JS * (ip / 49) + ip % 49 : (ip < nJ + 7 ? L::oRhsU + (ip - nJ) : L::oRhsI + (ip - nJ - 7));
     };
     double *rhsI = lds + L::oRhsI, *part = lds + L::oPart, *partU = lds + L::oPart + NSEG * 28, *yI = lds + L::oYI, *xt = lds + L::oXt,
            *wg = lds + L::oWg, *wvv = lds + L::oWv, *redB = lds + L::oRedB, *redT = lds + L::oRedT;
-    // loop-resident constants (written by every thread once the factor area has been consumed) and the rhs of K_0 w = k
-    auto init_consts = [&]() {
-        {
-            const int any = __syncthreads_or(status);       // (also: S consumed, the loop view may now be written)
-            if (tid == 0 && any) atomicOr(&ws.status[b], any);
-        }
+    {
+        // loop-resident constants and the rhs of K_0 w = k
         for (int i = tid; i < L::oRedT + 8 - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;        // vectors, pads, partial sums
         __syncthreads();
         for (int v = tid; v < na; v += NT) {
@@ -546,13 +557,13 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, const Qp3
         __syncthreads();
         for (int ip = tid; ip < na; ip += NT) lds[rhs_slot(ip)] = lds[L::oKT + ip];
         __syncthreads();
-    };
-    // after the solve of K_0 w = k: w and delta of the T border (all threads; one exchange between the arm workgroups)
+    }
+    // after the solve of K_0 w = k: w and delta of the T border (one exchange between the arm workgroups)
     auto finish_border = [&]() {
         double sacc = 0.0;
         for (int v = tid; v < na; v += NT) sacc += lds[L::oKT + int3_of_ext(NSEG, v)] * xt[v];
         double sv[1] = {sacc};
-        block_reduce<16, 1, false>(sv, redp, tid);
+        block_reduce<8, 1, false>(sv, redp, tid);
         for (int v = tid; v < na; v += NT) wvv[v] = xt[v];
         if (tid == 0) {
             double kap[2] = {0.0, 0.0}, sh[2] = {0.0, 0.0}, dl[2] = {0.0, 0.0};
@@ -581,10 +592,10 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, const Qp3
         }
         return (misc[L::M_baseT] + (s0 + s1)) / misc[L::M_delta];
     };
-    // termination test, common tail (all threads): combine the arms, add the row / column of T, decide
+    // termination test, common tail: combine the arms, add the row / column of T, decide
     const unsigned chk_base = 8 + cfg.qp_iters + 1;
     auto check_tail = [&](double (&sums)[2], double (&mx)[6], int nchk) -> int {
-        block_reduce<16, 6, true>(mx, redp, tid);
+        block_reduce<8, 6, true>(mx, redp, tid);
         double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
         s1[arm] = sums[0]; s2[arm] = sums[1];
         if (NARM == 2) {
@@ -611,156 +622,85 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, const Qp3
         const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);      // ||q||_inf = 1
         return (mx[0] <= ep && mx[3] <= ed) ? 1 : 0;
     };
-    // per-lane constants of the solve; the ADMM loop works on an opaque copy re-made every iteration: everything derived from
-    // them (LDS addresses of the sparse K_JC entries, of the operands, ...) is loop invariant, and hoisted out of the loop it would
-    // occupy > 100 VGPRs and evict the factor rows to scratch
-    struct LaneC { int lane, wave, srow, spart, xdst; uint32_t jcw, cjl, cjh; };
-    LaneC lc0;
-    lc0.lane = lane; lc0.wave = wave; lc0.srow = srow; lc0.spart = spart; lc0.xdst = 0; lc0.jcw = jcw; lc0.cjl = cjl; lc0.cjh = cjh;
-
-    int it_done = 0;
-    if (wave < 8) {
-        // =============================== G role ===============================
-        init_consts();
-        // lane constants of the G role, rebuilt from LDS tables on demand (nothing but the row itself stays in VGPRs across the loop)
-        const int *patw = reinterpret_cast<const int *>(lds + L::oPat), *xdg = reinterpret_cast<const int *>(lds + L::oXdG);
-        auto lane_consts = [&](int t) -> LaneC {
-            LaneC c;
-            c.lane = t & 63; c.wave = wave; c.srow = 0; c.spart = 0; c.xdst = xdg[t];
-            c.jcw = c.lane < 49 ? (uint32_t)patw[c.lane] : 0xFFFFFFFFu;
-            c.cjl = c.lane < 28 ? (uint32_t)patw[49 + c.lane] : 0xFFFFFFFFu;
-            c.cjh = c.lane < 28 ? (uint32_t)patw[77 + c.lane] : 0xFFFFFFFFu;
-            return c;
-        };
-        // this lane's row of G_s (k_qp3f left it in the factor workspace)
-        double mm[49];
-        // (Re-)load the row from the factor workspace (L2 resident) through an opaque pointer.  It is loaded again at the top of every
-        // termination-test period: a value defined right in front of the hot loop and dead after it is kept in VGPRs by the register
-        // allocator, whereas one that is live across the whole kernel was assigned a stack slot with a scratch reload folded into
-        // every use (49 serialised scratch loads per matrix-vector product), although the loop leaves 100 VGPRs free.
-        auto load_row = [&]() {
-            const double *fo = fa + L::AUX + (size_t)(wave * 49) * 64 + lane;
-            asm volatile("" : "+v"(fo));
+    // Per-lane constants of the solve, rebuilt from LDS tables / arithmetic on an OPAQUE copy of the thread index in every
+    // iteration: everything derived from them (LDS addresses of the sparse K_JC entries, of the operands, ...) is loop invariant,
+    // and hoisted out of the loop it would occupy > 100 VGPRs and evict the factor rows to scratch.
+    struct LaneC { int lane, srow, spart, xdg, xds; uint32_t jcw, cjl, cjh; };
+    const int *patw = reinterpret_cast<const int *>(lds + L::oPat), *xdgt = reinterpret_cast<const int *>(lds + L::oXdG);
+    auto lane_consts = [&](int t) -> LaneC {
+        LaneC c;
+        c.lane = t & 63; c.srow = t >> 2; c.spart = t & 3; c.xdg = xdgt[t];
+        c.xds = (c.srow < nI && c.spart == 0) ? 42 * (c.srow / 14) + c.srow % 14 : na + 1;      // interface rows x_0, x_3, ... (pad slot otherwise)
+        c.jcw = c.lane < 49 ? (uint32_t)patw[c.lane] : 0xFFFFFFFFu;
+        c.cjl = c.lane < 28 ? (uint32_t)patw[49 + c.lane] : 0xFFFFFFFFu;
+        c.cjh = c.lane < 28 ? (uint32_t)patw[77 + c.lane] : 0xFFFFFFFFu;
+        return c;
+    };
+    // this lane's row of G_s and quarter row of S^-1 (k_qp3f left them in the factor workspace).  They are loaded again at the top
+    // of every termination-test period, through an opaque pointer: a value defined right in front of the hot loop and dead
+    // after it is kept in VGPRs by the register allocator.
+    double mm[49], sm[CP];
+    auto load_rows = [&]() {
+        const double *fo = fa + L::AUX + (size_t)(wave * 49) * 64 + lane, *so = fa + L::AUX + 8 * 49 * 64 + tid;
+        asm volatile("" : "+v"(fo), "+v"(so));
 #pragma unroll
-            for (int j = 0; j < 49; j++) mm[j] = fo[j * 64];
-        };
-        load_row();
-        // Branch-free per lane (selects and dummy slots instead of lane-dependent branches: with a dozen exec-masked blocks in the
-        // hot loop the register allocator gave up on keeping the row in VGPRs).
-        auto solve_g = [&](const bool use_xT, const int it, const LaneC &c) {
-            const int ln = c.lane, wv = wave;
-            if (wv >= NSEG) { __syncthreads(); __syncthreads(); __syncthreads(); return; }      // (N = 19: waves 6, 7 hold no segment)
-            const bool g_row = ln < 49, gu_row = wv == NSEG - 1 && ln >= 49 && ln < 56;
-            const int lr = g_row ? ln : (gu_row ? ln - 49 : 0);                  // row inside its block
-            double *tJ = lds + L::oTJ + wv * 128;                  // wave-private: [0..49] segment operand / result, [64..113] U block, [120] dummy
-            const double *bj = lds + (gu_row ? L::oRhsU : L::oRhsJ + JS * wv);
-            const double *kjc_ = lds + L::oKJC + wv * 196, *kux_ = lds + L::oKUX + wv * 98, *kuX = lds + L::oKuX;
-            const int tslot = g_row ? ln : (gu_row ? 64 + ln - 49 : 120);
-            // ---- P1: t = G b_J, part = K_CJ t ----
-            {
-                tJ[tslot] = g_dot(mm, bj);
-                wave_sync();
-                const int cl = ln < 28 ? ln : 27;
-                double acc = 0.0;
+        for (int j = 0; j < 49; j++) mm[j] = fo[j * 64];
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint32_t ref = ((q < 4 ? c.cjl : c.cjh) >> (8 * (q & 3))) & 255u;
-                    double kv = kjc_[(ref >> 2) * 4 + (ref & 3u)];           // (ref = 255: a valid address, value discarded)
-                    kv = ref != 255u ? kv : 0.0;
-                    acc += kv * tJ[(ref >> 2) & 63];
-                    if (q == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const double f14 = ln < 14 ? 1.0 : 0.0;
-                const int c14 = ln < 14 ? ln : 13;
-                double accd = 0.0;
+        for (int j = 0; j < CP; j++) sm[j] = so[j * 512];
+    };
+    // One solve with K_0 (three barriers).  Branch-free per lane (selects and dummy slots instead of lane-dependent branches:
+    // with a dozen exec-masked blocks in the hot loop the register allocator gave up on keeping the rows in VGPRs).
+    auto solve = [&](const bool use_xT, const int it, const LaneC &c) {
+        const int ln = c.lane, wv = wave;
+        const bool g_row = ln < 49, gu_row = wv == NSEG - 1 && ln >= 49 && ln < 56;
+        const int lr = g_row ? ln : (gu_row ? ln - 49 : 0);                  // row inside its block
+        double *tJ = lds + L::oTJ + wv * 128;                  // wave-private: [0..49] segment operand / result, [64..113] U block, [120] dummy
+        const double *bj = lds + (gu_row ? L::oRhsU : L::oRhsJ + JS * wv);
+        const double *kjc_ = lds + L::oKJC + wv * 196, *kux_ = lds + L::oKUX + wv * 98, *kuX = lds + L::oKuX;
+        const int tslot = g_row ? ln : (gu_row ? 64 + ln - 49 : 120);
+        // ---- P1: t = G b_J, part = K_CJ t; this arm's share of the T solve, s_a = (T column of A^T w) - w^T rhs ----
+        if (wv < NSEG) {
+            tJ[tslot] = g_dot(mm, bj);
+            wave_sync();
+            const int cl = ln < 28 ? ln : 27;
+            double acc = 0.0;
 #pragma unroll
-                for (int r = 0; r < 7; r++) { accd += kux_[r * 14 + c14] * tJ[r]; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
-                acc += f14 * accd;
-                part[ln < 28 ? wv * 28 + cl : NSEG * 28 + 14] = acc;              // (dummy slot behind partU)
-                if (wv == NSEG - 1) {
-                    const int cc = (ln >= 32 && ln < 46) ? ln - 32 : 0;
-                    double au = 0.0;
-#pragma unroll
-                    for (int r = 0; r < 7; r++) { au += kuX[r * 14 + cc] * tJ[64 + r]; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
-                    partU[(ln >= 32 && ln < 46) ? cc : 15] = au;                  // (15: dummy)
-                }
+            for (int q = 0; q < 8; q++) {
+                const uint32_t ref = ((q < 4 ? c.cjl : c.cjh) >> (8 * (q & 3))) & 255u;
+                double kv = kjc_[(ref >> 2) * 4 + (ref & 3u)];           // (ref = 255: a valid address, value discarded)
+                kv = ref != 255u ? kv : 0.0;
+                acc += kv * tJ[(ref >> 2) & 63];
+                if (q == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
-            // ---- P3 (S role) ----
-            __syncthreads();
-            // ---- P4: x_J = G (b_J - K_JC y_I); x~ = y - w x~_T ----
-            {
-                const double xT = use_xT ? border_xT(it, ln) : 0.0;
-                const double *yc = yI + 14 * wv;
-                double cr = bj[lr];
-                const double fs = g_row ? 1.0 : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+            const double f14 = ln < 14 ? 1.0 : 0.0;
+            const int c14 = ln < 14 ? ln : 13;
+            double accd = 0.0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t cc = (c.jcw >> (8 * q)) & 255u;
-                    double kv = kjc_[lr * 4 + q];
-                    kv = cc != 255u ? kv : 0.0;
-                    cr -= fs * kv * yc[cc & 31u];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // dense part: rows u_3s x x_3s of the segment, or the U block x x_{N-1}
-                const double fd = (ln < 7 || gu_row) ? 1.0 : 0.0;
-                const double *dp = gu_row ? kuX + lr * 14 : kux_ + (ln < 7 ? ln : 0) * 14, *yb = gu_row ? yI + 14 * NSEG : yc;
-                double cd = 0.0;
+            for (int r = 0; r < 7; r++) { accd += kux_[r * 14 + c14] * tJ[r]; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
+            acc += f14 * accd;
+            part[ln < 28 ? wv * 28 + cl : NSEG * 28 + 14] = acc;              // (dummy slot behind partU)
+            if (wv == NSEG - 1) {
+                const int cc = (ln >= 32 && ln < 46) ? ln - 32 : 0;
+                double au = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < 14; cc++) { cd += dp[cc] * yb[cc]; if (cc % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
-                cr -= fd * cd;
-                tJ[tslot] = cr;
-                wave_sync();
-                const double xj = g_dot(mm, gu_row ? tJ + 64 : tJ);
-                xt[c.xdst] = xj - wvv[c.xdst] * xT;                            // (inactive lanes: xdst = na + 1, a pad slot)
-            }
-            __syncthreads();
-        };
-        solve_g(false, 0, lane_consts(tid));          // K_0 w = k (the T border)
-        finish_border();
-        // The hot loop is the INNER loop (one termination-test period): it contains nothing but the two matrix-vector phases, so
-        // the register allocator keeps the factor row in VGPRs across it; the test itself sits in the outer loop.
-        int it = 0, done = 0, nchk = 0;
-        while (it < cfg.qp_iters && !done) {
-            const int cnt = cfg.qp_iters - it < cfg.check_every ? cfg.qp_iters - it : cfg.check_every;
-            load_row();
-            for (int k = 0; k < cnt; k++) {
-                int tido = tid;
-                asm volatile("" : "+v"(tido));
-                __syncthreads();                    // A (S role)
-                solve_g(true, it + 1 + k, lane_consts(tido));
-                __syncthreads();                    // E (S role)
-            }
-            it += cnt;
-            if (cnt == cfg.check_every) {
-                double sums[2] = {0.0, 0.0}, mx[6] = {0, 0, 0, 0, 0, 0};
-                block_reduce<16, 2, false>(sums, redp, tid);
-                done = check_tail(sums, mx, nchk++);
+                for (int r = 0; r < 7; r++) { au += kuX[r * 14 + cc] * tJ[64 + r]; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
+                partU[(ln >= 32 && ln < 46) ? cc : 15] = au;                  // (15: dummy)
             }
         }
-        it_done = it;
-    } else {
-        // =============================== S role ===============================
-        if (sact && spart == 0) lc0.xdst = ws.ext_of_int[nJ + 7 + srow];
-        init_consts();
-        double sm[CP];                                              // this lane's quarter row of S^-1
+        if (use_xT && wv == 7 && ln == 63) {
+            double ssum = 0.0, bsum = 0.0;
 #pragma unroll
-        for (int j = 0; j < CP; j++) sm[j] = fa[L::AUX + 8 * 49 * 64 + j * 512 + si];
-        auto solve_s = [&](const bool use_xT, const int it, const LaneC &c) {
-            const int ln = c.lane, wv = c.wave;
-            // ---- P1 window: this arm's share of the T solve, s_a = (T column of A^T w) - w^T rhs ----
-            if (use_xT && wv == 15 && ln == 63) {
-                double ssum = 0.0, bsum = 0.0;
-#pragma unroll
-                for (int w8 = 0; w8 < 8; w8++) { ssum += redT[w8]; bsum += redB[w8]; }
-                const double sa = ssum - bsum;
-                misc[L::M_s0 + arm] = sa;
-                if (NARM == 2) xch_post(xown + 8 + it, sa);
-            }
-            __syncthreads();
-            // ---- P3: r_I = b_I - part, y_I = S^-1 r_I ----
-            double *rIw = lds + L::oRIw + (wv - 8) * 4 * CP;
+            for (int w8 = 0; w8 < 8; w8++) { ssum += redT[w8]; bsum += redB[w8]; }
+            const double sa = ssum - bsum;
+            misc[L::M_s0 + arm] = sa;
+            if (NARM == 2) xch_post(xown + 8 + it, sa);
+        }
+        QB(1); __syncthreads(); QS(1);
+        // ---- P3: r_I = b_I - part (every wave its own copy), y_I = S^-1 r_I ----
+        double yi;
+        {
+            double *rIw = lds + L::oRIw + wv * 4 * CP;
             for (int i = ln; i < 4 * CP; i += 64) {
                 double r = 0.0;
                 if (i < nI) {
@@ -784,228 +724,263 @@ __global__ __launch_bounds__(1024) void k_qp3(mpcmp_config cfg, WS ws, const Qp3
                 for (int q = 0; q < 4; q++) if (j0 + q < CP / 2) { a0 += sm[2 * (j0 + q)] * v4[q].x; a1 += sm[2 * (j0 + q) + 1] * v4[q].y; }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const double yi = sum4(a0 + a1);
-            const bool s_out = c.srow < nI && c.spart == 0;
-            if (s_out) yI[c.srow] = yi;
-            __syncthreads();
-            // ---- P4: interface part of x~ ----
-            const double xT = use_xT ? border_xT(it, ln) : 0.0;
-            if (s_out) xt[c.xdst] = yi - wvv[c.xdst] * xT;
-            if (wv == 15 && ln == 63) xt[na] = xT;
-            __syncthreads();
-        };
-        // S lane si owns arm variables si, si + 512 and general rows si, si + 512 (ADMM state in registers, constants in LDS)
-        constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
-        static_assert(NV <= 2 && NR <= 2, "two variables and two rows per S lane at most");
-        double xv0 = 0, zb0 = 0, yb0 = 0, xv1 = 0, zb1 = 0, yb1 = 0, zg0 = 0, yg0 = 0, zg1 = 0, yg1 = 0;
-        auto col_gather = [&](const double *w, int v) -> double {      // (A^T w)[v] without the T row
-            double sacc = 0.0;
-            int k, gcol;
-            if (v < 14 * N) {
-                k = v / 14; const int c = v % 14;
-                if (k % 3 != 0) {
-                    const int j = k % 3, rA = 14 * 3 * (k / 3) + c;
-                    sacc += cD[j] * w[rA] + cD[4 + j] * w[rA + 14] + cD[8 + j] * w[rA + 28];
-                } else {
-                    if (k < N - 1) { const int rA = 14 * k + c; sacc += cD[0] * w[rA] + cD[4] * w[rA + 14] + cD[8] * w[rA + 28]; }
-                    if (k > 0) { const int rB = 14 * (k - 3) + c; sacc += cD[3] * w[rB] + cD[7] * w[rB + 14] + cD[11] * w[rB + 28]; }
-                }
-                if (c >= 7 && k <= N - 2) sacc -= tsT * w[14 * k + c - 7];
-                gcol = k * 8 * GS + c;
-            } else {
-                k = (v - 14 * N) / 7; const int c = (v - 14 * N) % 7;
-                if (k <= N - 2) sacc -= tsT * w[14 * k + 7 + c];
-                gcol = k * 8 * GS + 14 + c;
-            }
-            const double *gc = gkl + gcol, *wp = w + meq + 8 * k;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 8; q++) sacc += gc[q * GS] * wp[q];
-            __builtin_amdgcn_sched_barrier(0);
-            return sacc;
-        };
-        auto row_dot = [&](const double *xe, int r) -> double {         // (A x)[r]; xe: external arm order, T at [na]
-            double sacc;
-            if (r < meq) {
-                const int k = r / 14, rr = r % 14, i = k % 3, ix0 = 14 * 3 * (k / 3) + rr;
-                const int ixf = (rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7;
-                sacc = cD[4 * i] * xe[ix0] + cD[4 * i + 1] * xe[ix0 + 14] + cD[4 * i + 2] * xe[ix0 + 28] + cD[4 * i + 3] * xe[ix0 + 42] -
-                       tsT * xe[ixf] + lds[L::oCf + r] * xe[na];
-            } else {
-                const int k = (r - meq) >> 3;
-                const double *gr = gkl + (r - meq) * GS, *xk = xe + 14 * k, *uk = xe + 14 * N + 7 * k;
-                sacc = gr[21] * xe[na];
-                // (chunks of seven terms: all 42 operand reads in flight at once would cost 84 VGPRs)
-#pragma unroll
-                for (int c = 0; c < 7; c++) sacc += gr[c] * xk[c];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 7; c < 14; c++) sacc += gr[c] * xk[c];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 7; c++) sacc += gr[14 + c] * uk[c];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            return sacc;
-        };
-        auto wave_total = [&](double x) -> double {                     // sum over the 64 lanes, valid in every lane
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            return x;
-        };
-        double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests
-        {
-            LaneC lc = lc0;
-            solve_s(false, 0, lc);                    // K_0 w = k (the T border)
-            finish_border();
+            yi = sum4(a0 + a1);
+            yI[(c.srow < nI && c.spart == 0) ? c.srow : nI + 1] = yi;          // (pad slot behind y_I)
         }
-        int it = 0, done = 0, nchk = 0;
-        while (it < cfg.qp_iters && !done) {
-            const int cnt = cfg.qp_iters - it < cfg.check_every ? cfg.qp_iters - it : cfg.check_every;
-            for (int k = 0; k < cnt; k++) {           // the hot loop: one termination-test period
-                LaneC lc = lc0;
-                int sio = si;
-                asm volatile("" : "+v"(lc.lane), "+v"(lc.wave), "+v"(lc.srow), "+v"(lc.spart), "+v"(lc.xdst), "+v"(sio));
-                // ---- A: rhs = sigma x - q + rho_b z_b - y_b + A^T w ----
-                {
-                    double bp = 0.0;
+        QB(2); __syncthreads(); QS(2);
+        // ---- P4: x_J = G (b_J - K_JC y_I); x~ = y - w x~_T ----
+        {
+            const double xT = use_xT ? border_xT(it, ln) : 0.0;
+            xt[c.xds] = yi - wvv[c.xds] * xT;                                  // interface rows (others: pad slot na + 1)
+            if (wv == 7 && ln == 63) xt[na] = xT;
+            if (wv < NSEG) {
+                const double *yc = yI + 14 * wv;
+                double cr = bj[lr];
+                const double fs = g_row ? 1.0 : 0.0;
 #pragma unroll
-                    for (int h = 0; h < NV; h++) {
-                        const int v = sio + 512 * h;
-                        if (v < na) {
-                            const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
-                            const double r = (sigma * xx + (lds[L::oRb + v] * zz - yy)) + col_gather(wg, v);
-                            lds[rpos[v]] = r;
-                            bp += wvv[v] * r;
-                        }
-                    }
-                    bp = wave_total(bp);
-                    if (lc.lane == 0) redB[lc.wave - 8] = bp;
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t cc = (c.jcw >> (8 * q)) & 255u;
+                    double kv = kjc_[lr * 4 + q];
+                    kv = cc != 255u ? kv : 0.0;
+                    cr -= fs * kv * yc[cc & 31u];
                 }
-                __syncthreads();
-                solve_s(true, it + 1 + k, lc);
-                // ---- E: z~ = A x~, relaxation, projection, dual update ----
-                {
-                    double tp = 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+                // dense part: rows u_3s x x_3s of the segment, or the U block x x_{N-1}
+                const double fd = (ln < 7 || gu_row) ? 1.0 : 0.0;
+                const double *dp = gu_row ? kuX + lr * 14 : kux_ + (ln < 7 ? ln : 0) * 14, *yb = gu_row ? yI + 14 * NSEG : yc;
+                double cd = 0.0;
 #pragma unroll
-                    for (int h = 0; h < NR; h++) {
-                        const int r = sio + 512 * h;
-                        if (r < ma) {
-                            double &zg = h ? zg1 : zg0, &yg = h ? yg1 : yg0;
-                            const double rr = lds[L::oRr + r];
-                            const double zt = row_dot(xt, r);
-                            const double zr = alpha * zt + (1.0 - alpha) * zg;
-                            const double zn = clip(zr + yg * lds[L::oRri + r], lds[L::oLg + r], lds[L::oUg + r]);
-                            yg += rr * (zr - zn);
-                            zg = zn;
-                            const double w = rr * zg - yg;
-                            wg[r] = w;
-                            tp += lds[L::oCf + r] * w;
-                        }
-                    }
-                    tp = wave_total(tp);
-                    if (lc.lane == 0) redT[lc.wave - 8] = tp;     // (read by the next iteration's P1 window: two barriers away)
+                for (int cc = 0; cc < 14; cc++) { cd += dp[cc] * yb[cc]; if (cc % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
+                cr -= fd * cd;
+                tJ[tslot] = cr;
+                wave_sync();
+                const double xj = g_dot(mm, gu_row ? tJ + 64 : tJ);
+                xt[c.xdg] = xj - wvv[c.xdg] * xT;                              // (inactive lanes: xdg = na + 1, the pad slot)
+            }
+        }
+        QB(3); __syncthreads(); QS(3);
+    };
+    // lane si owns arm variables si, si + 512 and general rows si, si + 512 (ADMM state in registers, constants in LDS)
+    constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
+    static_assert(NV <= 2 && NR <= 2, "two variables and two rows per lane at most");
+    double xv0 = 0, zb0 = 0, yb0 = 0, xv1 = 0, zb1 = 0, yb1 = 0, zg0 = 0, yg0 = 0, zg1 = 0, yg1 = 0;
+    auto col_gather = [&](const double *w, int v) -> double {      // (A^T w)[v] without the T row
+        double sacc = 0.0;
+        int k, gcol;
+        if (v < 14 * N) {
+            k = v / 14; const int c = v % 14;
+            if (k % 3 != 0) {
+                const int j = k % 3, rA = 14 * 3 * (k / 3) + c;
+                sacc += cD[j] * w[rA] + cD[4 + j] * w[rA + 14] + cD[8 + j] * w[rA + 28];
+            } else {
+                if (k < N - 1) { const int rA = 14 * k + c; sacc += cD[0] * w[rA] + cD[4] * w[rA + 14] + cD[8] * w[rA + 28]; }
+                if (k > 0) { const int rB = 14 * (k - 3) + c; sacc += cD[3] * w[rB] + cD[7] * w[rB + 14] + cD[11] * w[rB + 28]; }
+            }
+            if (c >= 7 && k <= N - 2) sacc -= tsT * w[14 * k + c - 7];
+            gcol = k * 8 * GS + c;
+        } else {
+            k = (v - 14 * N) / 7; const int c = (v - 14 * N) % 7;
+            if (k <= N - 2) sacc -= tsT * w[14 * k + 7 + c];
+            gcol = k * 8 * GS + 14 + c;
+        }
+        const double *gc = gkl + gcol, *wp = w + meq + 8 * k;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int h = 0; h < NV; h++) {
-                        const int v = sio + 512 * h;
-                        if (v < na) {
-                            double &xx = h ? xv1 : xv0, &zz = h ? zb1 : zb0, &yy = h ? yb1 : yb0;
-                            const double xtv = xt[v], rb = lds[L::oRb + v];
-                            xx = alpha * xtv + (1.0 - alpha) * xx;
-                            const double zr = alpha * xtv + (1.0 - alpha) * zz;
-                            const double zn = clip(zr + yy * lds[L::oRi + v], lds[L::oLb + v], lds[L::oUb + v]);
-                            yy += rb * (zr - zn);
-                            zz = zn;
-                        }
+        for (int q = 0; q < 8; q++) sacc += gc[q * GS] * wp[q];
+        __builtin_amdgcn_sched_barrier(0);
+        return sacc;
+    };
+    auto row_dot = [&](const double *xe, int r) -> double {         // (A x)[r]; xe: external arm order, T at [na]
+        double sacc;
+        if (r < meq) {
+            const int k = r / 14, rr = r % 14, i = k % 3, ix0 = 14 * 3 * (k / 3) + rr;
+            const int ixf = (rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7;
+            sacc = cD[4 * i] * xe[ix0] + cD[4 * i + 1] * xe[ix0 + 14] + cD[4 * i + 2] * xe[ix0 + 28] + cD[4 * i + 3] * xe[ix0 + 42] -
+                   tsT * xe[ixf] + lds[L::oCf + r] * xe[na];
+        } else {
+            const int k = (r - meq) >> 3;
+            const double *gr = gkl + (r - meq) * GS, *xk = xe + 14 * k, *uk = xe + 14 * N + 7 * k;
+            sacc = gr[21] * xe[na];
+            // (chunks of seven terms: all 42 operand reads in flight at once would cost 84 VGPRs)
+#pragma unroll
+            for (int c = 0; c < 7; c++) sacc += gr[c] * xk[c];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 7; c < 14; c++) sacc += gr[c] * xk[c];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 7; c++) sacc += gr[14 + c] * uk[c];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return sacc;
+    };
+    auto wave_total = [&](double x) -> double {                     // sum over the 64 lanes, valid in every lane
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        return x;
+    };
+    double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests
+    load_rows();
+    solve(false, 0, lane_consts(tid));                // K_0 w = k (the T border)
+    finish_border();
+#ifdef MPCMP_STAMPS
+    for (int k = 0; k < 8; k++) st_acc[k] = st_busy[k] = 0;
+    QS(6);
+#endif
+    // The hot loop is the INNER loop (one termination-test period): it contains nothing but the five phases; the test itself
+    // sits in the outer loop.
+    int it = 0, done = 0, nchk = 0;
+    while (it < cfg.qp_iters && !done) {
+        const int cnt = cfg.qp_iters - it < cfg.check_every ? cfg.qp_iters - it : cfg.check_every;
+        load_rows();
+        for (int k = 0; k < cnt; k++) {
+            int sio = tid;
+            asm volatile("" : "+v"(sio));
+            const LaneC lc = lane_consts(sio);
+            // ---- A: rhs = sigma x - q + rho_b z_b - y_b + A^T w ----
+            {
+                double bp = 0.0;
+#pragma unroll
+                for (int h = 0; h < NV; h++) {
+                    const int v = sio + 512 * h;
+                    if (v < na) {
+                        const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
+                        const double r = (sigma * xx + (lds[L::oRb + v] * zz - yy)) + col_gather(wg, v);
+                        lds[rpos[v]] = r;
+                        bp += wvv[v] * r;
                     }
-                    if (sio == 511) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
-                        const double xtv = xt[na], rb = misc[L::M_rbT];
-                        double xx = misc[L::M_xT], zz = misc[L::M_zbT], yy = misc[L::M_ybT];
+                }
+                bp = wave_total(bp);
+                if (lc.lane == 0) redB[wave] = bp;
+            }
+            QB(0); __syncthreads(); QS(0);
+            solve(true, it + 1 + k, lc);
+            // ---- E: z~ = A x~, relaxation, projection, dual update ----
+            {
+                double tp = 0.0;
+#pragma unroll
+                for (int h = 0; h < NR; h++) {
+                    const int r = sio + 512 * h;
+                    if (r < ma) {
+                        double &zg = h ? zg1 : zg0, &yg = h ? yg1 : yg0;
+                        const double rr = lds[L::oRr + r];
+                        const double zt = row_dot(xt, r);
+                        const double zr = alpha * zt + (1.0 - alpha) * zg;
+                        const double zn = clip(zr + yg * lds[L::oRri + r], lds[L::oLg + r], lds[L::oUg + r]);
+                        yg += rr * (zr - zn);
+                        zg = zn;
+                        const double w = rr * zg - yg;
+                        wg[r] = w;
+                        tp += lds[L::oCf + r] * w;
+                    }
+                }
+                tp = wave_total(tp);
+                if (lc.lane == 0) redT[wave] = tp;            // (read by the next iteration's P1: two barriers away)
+#pragma unroll
+                for (int h = 0; h < NV; h++) {
+                    const int v = sio + 512 * h;
+                    if (v < na) {
+                        double &xx = h ? xv1 : xv0, &zz = h ? zb1 : zb0, &yy = h ? yb1 : yb0;
+                        const double xtv = xt[v], rb = lds[L::oRb + v];
                         xx = alpha * xtv + (1.0 - alpha) * xx;
                         const double zr = alpha * xtv + (1.0 - alpha) * zz;
-                        const double zn = clip(zr + yy / rb, misc[L::M_lbT], misc[L::M_ubT]);
+                        const double zn = clip(zr + yy * lds[L::oRi + v], lds[L::oLb + v], lds[L::oUb + v]);
                         yy += rb * (zr - zn);
                         zz = zn;
-                        misc[L::M_xT] = xx; misc[L::M_zbT] = zz; misc[L::M_ybT] = yy;
-                        misc[L::M_baseT] = (sigma * xx - 1.0) + (rb * zz - yy);
                     }
                 }
-                __syncthreads();
-            }
-            it += cnt;
-            if (cnt == cfg.check_every) {
-                int sio = si;
-                asm volatile("" : "+v"(sio));
-                {
-                    // ---- termination test: r_prim = ||[A;I]x - z||inf, r_dual = ||Hx + q + [A;I]^T y||inf (oracle/ocp.c admm) ----
-                    double sums[2] = {0.0, 0.0};              // T row: sum coefT_r y_r, sum ha_i x_i of this arm
-#pragma unroll
-                    for (int h = 0; h < NR; h++) {
-                        const int r = sio + 512 * h;
-                        if (r < ma) { const double yg = h ? yg1 : yg0; ys[r] = yg; sums[0] += lds[L::oCf + r] * yg; }
-                    }
-#pragma unroll
-                    for (int h = 0; h < NV; h++) {
-                        const int v = sio + 512 * h;
-                        if (v < na) {
-                            const double xx = h ? xv1 : xv0;
-                            double ha, rb, lo, hi;
-                            var_h(v, ha, rb, lo, hi);
-                            xt[v] = xx; sums[1] += ha * xx;
-                        }
-                    }
-                    if (sio == 511) xt[na] = misc[L::M_xT];
-                    block_reduce<16, 2, false>(sums, redp, tid);         // (its barriers publish xt / ys)
-                    double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
-                    const double xTc = xt[na];
-#pragma unroll
-                    for (int h = 0; h < NR; h++) {
-                        const int r = sio + 512 * h;
-                        if (r < ma) {
-                            const double zg = h ? zg1 : zg0, ax = row_dot(xt, r);
-                            mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
-                        }
-                    }
-#pragma unroll
-                    for (int h = 0; h < NV; h++) {
-                        const int v = sio + 512 * h;
-                        if (v < na) {
-                            const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
-                            double ha, rb, lo, hi;
-                            var_h(v, ha, rb, lo, hi);
-                            const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, v) + yy;
-                            mx[0] = fmax(mx[0], fabs(xx - zz)); mx[1] = fmax(mx[1], fabs(xx)); mx[2] = fmax(mx[2], fabs(zz));
-                            mx[3] = fmax(mx[3], fabs(hx + aty)); mx[4] = fmax(mx[4], fabs(hx)); mx[5] = fmax(mx[5], fabs(aty));
-                        }
-                    }
-                    done = check_tail(sums, mx, nchk++);
+                if (sio == 511) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
+                    const double xtv = xt[na], rb = misc[L::M_rbT];
+                    double xx = misc[L::M_xT], zz = misc[L::M_zbT], yy = misc[L::M_ybT];
+                    xx = alpha * xtv + (1.0 - alpha) * xx;
+                    const double zr = alpha * xtv + (1.0 - alpha) * zz;
+                    const double zn = clip(zr + yy / rb, misc[L::M_lbT], misc[L::M_ubT]);
+                    yy += rb * (zr - zn);
+                    zz = zn;
+                    misc[L::M_xT] = xx; misc[L::M_zbT] = zz; misc[L::M_ybT] = yy;
+                    misc[L::M_baseT] = (sigma * xx - 1.0) + (rb * zz - yy);
                 }
             }
+            QB(4); __syncthreads(); QS(4);
         }
-        it_done = it;
-        // ---------------- results ----------------
+        it += cnt;
+        if (cnt == cfg.check_every) {
+            int sio = tid;
+            asm volatile("" : "+v"(sio));
+            // ---- termination test: r_prim = ||[A;I]x - z||inf, r_dual = ||Hx + q + [A;I]^T y||inf (oracle/ocp.c admm) ----
+            double sums[2] = {0.0, 0.0};              // T row: sum coefT_r y_r, sum ha_i x_i of this arm
 #pragma unroll
-        for (int h = 0; h < NV; h++) {
-            const int v = si + 512 * h;
-            if (v < na) {
-                ws.p[(size_t)b * n_tot + arm * na + v] = h ? xv1 : xv0;
-                ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? yb1 : yb0;
+            for (int h = 0; h < NR; h++) {
+                const int r = sio + 512 * h;
+                if (r < ma) { const double yg = h ? yg1 : yg0; ys[r] = yg; sums[0] += lds[L::oCf + r] * yg; }
             }
-        }
 #pragma unroll
-        for (int h = 0; h < NR; h++) {
-            const int r = si + 512 * h;
-            if (r < ma) ws.y[(size_t)b * mn_tot + arm * ma + r] = h ? yg1 : yg0;
-        }
-        if (si == 511 && arm == 0) {
-            ws.p[(size_t)b * n_tot + NARM * na] = misc[L::M_xT];
-            ws.y[(size_t)b * mn_tot + mn_tot - 1] = misc[L::M_ybT];
+            for (int h = 0; h < NV; h++) {
+                const int v = sio + 512 * h;
+                if (v < na) {
+                    const double xx = h ? xv1 : xv0;
+                    double ha, rb, lo, hi;
+                    var_h(v, ha, rb, lo, hi);
+                    xt[v] = xx; sums[1] += ha * xx;
+                }
+            }
+            if (sio == 511) xt[na] = misc[L::M_xT];
+            block_reduce<8, 2, false>(sums, redp, tid);          // (its barriers publish xt / ys)
+            double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
+            const double xTc = xt[na];
+#pragma unroll
+            for (int h = 0; h < NR; h++) {
+                const int r = sio + 512 * h;
+                if (r < ma) {
+                    const double zg = h ? zg1 : zg0, ax = row_dot(xt, r);
+                    mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < NV; h++) {
+                const int v = sio + 512 * h;
+                if (v < na) {
+                    const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
+                    double ha, rb, lo, hi;
+                    var_h(v, ha, rb, lo, hi);
+                    const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, v) + yy;
+                    mx[0] = fmax(mx[0], fabs(xx - zz)); mx[1] = fmax(mx[1], fabs(xx)); mx[2] = fmax(mx[2], fabs(zz));
+                    mx[3] = fmax(mx[3], fabs(hx + aty)); mx[4] = fmax(mx[4], fabs(hx)); mx[5] = fmax(mx[5], fabs(aty));
+                }
+            }
+            done = check_tail(sums, mx, nchk++);
+            QS(5);
         }
     }
+    // ---------------- results ----------------
+#pragma unroll
+    for (int h = 0; h < NV; h++) {
+        const int v = tid + 512 * h;
+        if (v < na) {
+            ws.p[(size_t)b * n_tot + arm * na + v] = h ? xv1 : xv0;
+            ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? yb1 : yb0;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NR; h++) {
+        const int r = tid + 512 * h;
+        if (r < ma) ws.y[(size_t)b * mn_tot + arm * ma + r] = h ? yg1 : yg0;
+    }
+    if (tid == 511 && arm == 0) {
+        ws.p[(size_t)b * n_tot + NARM * na] = misc[L::M_xT];
+        ws.y[(size_t)b * mn_tot + mn_tot - 1] = misc[L::M_ybT];
+    }
+#ifdef MPCMP_STAMPS
+    if (lane == 0 && arm == 0) {
+        unsigned long long *o = ws.dbg + (size_t)b * MPCMP_DBG_WORDS;
+        for (int k = 0; k < 8; k++) o[16 + wave * 8 + k] = st_busy[k];
+        if (wave == 0) { for (int k = 0; k < 7; k++) o[k] = st_acc[k]; o[15] = it; }
+    }
+#endif
     {
         const int any = __syncthreads_or(dead ? 4 : 0);         // bit 2: the partner workgroup never answered
         if (tid == 0) {
-            if (arm == 0) { ws.qpit[b] = it_done; ws.qp_total[b] += it_done; }
+            if (arm == 0) { ws.qpit[b] = it; ws.qp_total[b] += it; }
             if (any) atomicOr(&ws.status[b], any);
         }
     }
