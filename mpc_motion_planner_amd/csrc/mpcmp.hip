@@ -553,8 +553,8 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     constexpr bool V2C = (NSEG == 2 || NSEG == 4);      // role-specialised 1024-thread QP kernel
     constexpr bool V3C = (NSEG >= 6);                   // k_qp3: T bordered out, E-free interior solve (N = 19, 25)
     const bool V2 = V2C && !force_v1;
-    const size_t l_qp3 = Qp3<V3C ? NSEG : 6>::size * sizeof(double);
-    if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3C ? NSEG : 6, 1>, l_qp3)) return rc; if (int rc = set_lds(ctx, k_qp3f<V3C ? NSEG : 6, 1>, l_qp3)) return rc; }
+    const size_t l_qp3 = Qp3<V3C ? NSEG : 6>::sizeL * sizeof(double), l_qp3f = Qp3<V3C ? NSEG : 6>::sizeF * sizeof(double);
+    if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3C ? NSEG : 6, 1>, l_qp3)) return rc; if (int rc = set_lds(ctx, k_qp3f<V3C ? NSEG : 6, 1>, l_qp3f)) return rc; }
     const size_t l_qp2 = Qp2<V2C ? NSEG : 4>::size * sizeof(double);
     if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
     else if (!V3C) { if (int rc = set_lds(ctx, k_qp<V3C ? 1 : NSEG>, l_qp)) return rc; }
@@ -596,7 +596,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
             if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
             if (V3C) {
                 double *fh = ctx->d_fac + (size_t)boff[h] * Qp3<V3C ? NSEG : 6>::FAC;
-                hipLaunchKernelGGL((k_qp3f<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);
+                hipLaunchKernelGGL((k_qp3f<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3f, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);
                 hipLaunchKernelGGL((k_qp3<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(512), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
             }
             else if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(Bh[h]), dim3(1024), l_qp2, sh[h], ctx->cfg, wh[h], ctx->streams);
@@ -621,11 +621,11 @@ static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double 
     constexpr int N = D::N;
     WS w = ctx->ws;
     w.x0 = d_x0; w.xf = d_xf;
-    const size_t l_m = D::size * sizeof(double), l_qp3 = Qp3<NSEG>::size * sizeof(double);
+    const size_t l_m = D::size * sizeof(double), l_qp3 = Qp3<NSEG>::sizeL * sizeof(double), l_qp3f = Qp3<NSEG>::sizeF * sizeof(double);
     if (int rc = set_lds(ctx, k_init_m<NSEG, NARM>, l_m)) return rc;
     if (int rc = set_lds(ctx, k_step_m<NSEG, NARM>, l_m)) return rc;
     if (int rc = set_lds(ctx, k_qp3<NSEG, NARM>, l_qp3)) return rc;
-    if (int rc = set_lds(ctx, k_qp3f<NSEG, NARM>, l_qp3)) return rc;
+    if (int rc = set_lds(ctx, k_qp3f<NSEG, NARM>, l_qp3f)) return rc;
     // two parts on two streams once one part alone fills the chip (one CU per arm): see solve_impl
     static const bool single_stream = std::getenv("MPCMP_SINGLE_STREAM") != nullptr;
     const bool dual = !single_stream && !only_qp && B * NARM >= 512;
@@ -660,7 +660,7 @@ static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double 
             if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
             const int grid = NARM == 1 ? Bh[h] : ((Bh[h] + 7) / 8) * 16;       // arm workgroups of one OCP are 8 apart (k_qp3)
             double *fh = ctx->d_fac + (size_t)boff[h] * NARM * Qp3<NSEG>::FAC;
-            hipLaunchKernelGGL((k_qp3f<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], fh);
+            hipLaunchKernelGGL((k_qp3f<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3f, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], fh);
             hipLaunchKernelGGL((k_qp3<NSEG, NARM>), dim3(grid), dim3(512), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], (const double *)fh);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;

@@ -51,32 +51,36 @@ template <int NSEG>
 struct Qp3 {
     using D = Dim3<NSEG>;
     static constexpr int NT = 1024;
-    static constexpr int GS = 24;                                   // row stride of the path Jacobians in LDS
-    static constexpr int JS = 50;                                   // stride of one segment's part of rhs (49 + a zero pad)
-    static constexpr int CP = ((D::nI + 3) / 4 + 1) / 2 * 2;        // columns of S^-1 per lane (four lanes per row), even
+    static constexpr int GS = 22;                                   // row stride of the path Jacobians in LDS (2 x odd: lane = row reads of 8 or 16 bytes are conflict free)
+    static constexpr int NS = 22;                                   // node stride of x~, w (border), w = rho z - y in the loop kernel: [x_k (14) | u_k (7) | x~_T] resp. [dynamics rows (14) | path rows (8)]
+    static constexpr int NX = NS * D::N, NXP = (NX + 2 + 1) / 2 * 2; // (slot NX: pad for lanes without a job)
+    static constexpr int JS = 52;                                   // stride of one segment's part of rhs (49 + zero pad: 4 x 13 column groups)
+    static constexpr int SC = (D::nI + 15) / 16;                    // columns of S^-1 per lane (16 lanes per group of four rows)
+    static constexpr int RIW = 16 * SC;                             // padded length of r_I
     static constexpr int NAP = (D::na + 2 + 1) / 2 * 2;             // na + T slot, even
     static constexpr int MAP = (D::ma + 1) / 2 * 2;
     static constexpr int NB = NSEG + 1;                             // blocks of the interior sweep (segments + padded K_UU)
     static constexpr int CB = NB * 52 > 128 ? NB * 52 : 128;        // pivot-column buffer of the sweeps
     static constexpr int e2(int x) { return (x + 1) / 2 * 2; }
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-    // ---- persistent (doubles) ----
+    // ---- common part, both kernels (doubles) ----
     static constexpr int oGk = 0;                                   // [N][8][GS]    path Jacobians
-    static constexpr int oCT = oGk + D::N * 8 * GS;                 // [meq]         T coefficient -ts*f of the dynamics rows
-    static constexpr int oKJC = oCT + e2(D::meq);                   // [NSEG][49][4] sparse K_JC
-    static constexpr int oKUX = oKJC + NSEG * 196;                  // [NSEG][7][14] dense block u_3s x x_3s
+    static constexpr int oMisc = oGk + D::N * 8 * GS;               // [32]  see M_* below
+    static constexpr int oCD = oMisc + 32;                          // [16]  differentiation matrix, [16] zeros
+    static constexpr int oRedP = oCD + 32;                          // [160] workgroup reductions
+    static constexpr int oCfg = oRedP + 160;                        // [64] bound tables of the configuration: lbx 0, ubx 14, lbu 28, ubu 35, lbg 42, ubg 50
+    static constexpr int oPat = oCfg + 64;                          // [49 + 28 + 28] ints: sparse K_JC pattern words (jc | cjl | cjh)
+    static constexpr int oXdG = oPat + 54;                          // [8][64] ints: where the G lanes' x~ entries go (loop kernel)
+    static constexpr int oPE = oXdG + 256;                          // end of the common part
+    static constexpr int KJN = NSEG * 196 + 4;                      // sparse K_JC [NSEG][49][4] (canonical slots, structure3.hpp) + a zero row
+    // ---- factorisation kernel ----
+    static constexpr int oKJC = oPE;                                // [KJN]
+    static constexpr int oKUX = oKJC + KJN;                         // [NSEG][7][14] dense block u_3s x x_3s
     static constexpr int oKuX = oKUX + NSEG * 98;                   // [7][14]       u_{N-1} x x_{N-1}
     static constexpr int oGu = oKuX + 98;                           // [28]          -(K_UU^-1) packed
     static constexpr int oKT = oGu + 32;                            // [na] T column k (internal order), [na] kappa_a
-    static constexpr int oMisc = oKT + NAP;                         // [32]  see M_* below
-    static constexpr int oCD = oMisc + 32;                          // [16]  differentiation matrix
-    static constexpr int oRedP = oCD + 16;                          // [160] workgroup reductions
-    static constexpr int oCfg = oRedP + 160;                        // [64] bound tables of the configuration: lbx 0, ubx 14, lbu 28, ubu 35, lbg 42, ubg 50
-    static constexpr int oPat = oCfg + 64;                          // [49 + 28 + 28] ints: sparse K_JC pattern words (jc | cjl | cjh)
-    static constexpr int oXdG = oPat + 54;                          // [8][64] ints: where the G lanes' x~ entries go (external arm order)
-    static constexpr int oU = oXdG + 256;                           // union region
-    // ---- factor view of the union ----
-    static constexpr int fKJJ = oU;                                 // [NSEG][1225], later S packed [SP]
+    static constexpr int oCT = oKT + NAP;                           // [meq]         T coefficient -ts*f of the dynamics rows
+    static constexpr int fKJJ = oCT + e2(D::meq);                   // [NSEG][1225], later S packed [SP]
     static constexpr int fKUU = fKJJ + NSEG * D::JP;                // [28]
     static constexpr int fZ = fKUU + 32;                            // [na] iterate of this arm (assembly operands)
     static constexpr int fCol = fZ + NAP;                           // [2][CB]
@@ -84,27 +88,41 @@ struct Qp3 {
     static constexpr int fEnd = fRdv + 32;
     static constexpr int fSW = fKJJ + e2(D::SP);                    // Schur phase scratch behind S: [8][64] column, [8][64] product
     static_assert(fSW + 1024 <= fKUU, "Schur scratch must fit between S and the K_UU block");
-    // ---- loop view of the union ----
-    static constexpr int oLb = oU, oUb = oLb + NAP, oRb = oUb + NAP, oRi = oRb + NAP, oWv = oRi + NAP;     // variable constants
-    static constexpr int oLg = oWv + NAP, oUg = oLg + MAP, oRr = oUg + MAP, oRri = oRr + MAP, oCf = oRri + MAP;   // row constants
+    // ---- loop kernel ----
+    static constexpr int lKJC = oPE;                                // [KJN] sparse K_JC, row form
+    static constexpr int lKT = lKJC + KJN;                          // [na] T column k (internal order), [na] kappa_a
+    static constexpr int oKCJ = lKT + NAP;                          // [NSEG][28][8] column form of the sparse K_JC: C-column c, rows c % 14 + 7 d, d = -1..5
+    static constexpr int oKUXT = oKCJ + NSEG * 224;                 // [NSEG + 1][14][8] dense blocks transposed (column c: 7 entries + pad), last: u_{N-1} x x_{N-1}
+    static constexpr int oKUXP = oKUXT + (NSEG + 1) * 112;          // [NSEG + 1][7][16] dense blocks, rows padded to 16
+    static constexpr int oZR = oKUXP + (NSEG + 1) * 112;            // [16] zeros
+    static constexpr int DER = NSEG * 224 + 2 * (NSEG + 1) * 112 + 16;   // (doubles of the derived copies)
+    static constexpr int oLb = oKCJ + DER, oUb = oLb + NAP, oRb = oUb + NAP, oWv = oRb + NAP;     // variable constants; w of the T border (node order)
+    static constexpr int oLg = oWv + NXP, oUg = oLg + MAP, oRr = oUg + MAP, oCf = oRr + MAP;   // row constants
     static constexpr int oRpos = oCf + MAP;                         // [na] ints: LDS slot of the variable's rhs entry
     static constexpr int oRhsJ = oRpos + e2((D::na + 1) / 2);       // [NSEG][JS]
     static constexpr int oRhsU = oRhsJ + NSEG * JS;                 // [JS] (7 used, rest zero)
     static constexpr int oRhsI = oRhsU + JS;                        // [nI]
-    static constexpr int oTJ = oRhsI + e2(D::nI);                   // [8][128] wave-private vectors of the G waves ([64..] U block)
-    static constexpr int oPart = oTJ + 1024;                        // [NSEG][28] K_CJ t per segment, [14] of the U block
-    static constexpr int oRIw = oPart + e2(NSEG * 28 + 16);         // [8][4 CP] wave-private r_I of the S waves; y (duals) at checks
-    static constexpr int oYI = oRIw + cmax(8 * 4 * CP, MAP);        // [nI] + pad slot
-    static constexpr int oXt = oYI + e2(D::nI + 2);                    // [na + 1] x~ in external arm order, T last
-    static constexpr int oWg = oXt + NAP;                           // [ma] w = rho z - y
-    static constexpr int oRedB = oWg + MAP;                         // [8] per-wave partial sums of w^T rhs
+    static constexpr int TS = 64;                                   // wave-private vector of a G wave: [0..51] operand / result, [56] dummy
+    static constexpr int oTJ = oRhsI + e2(D::nI);                   // [8][TS], then the U block of the last segment's wave [TS]
+    static constexpr int oTU = oTJ + 8 * TS;
+    static constexpr int oDW = oTU + TS;                            // [8][16] wave-private: dense parts of the rows u_3s ([0..6]) and of the U block ([7..13])
+    static constexpr int oDP = oDW + 128;                           // [NSEG][14] dense part of K_CJ t (columns x_3s), + pad slot
+    static constexpr int oPart = oDP + e2(NSEG * 14 + 2);           // [NSEG][28] sparse part of K_CJ t per segment, [14] of the U block
+    static constexpr int oRIw = oPart + e2(NSEG * 28 + 16);         // [8][RIW] wave-private r_I; y (duals) at checks
+    static constexpr int oYI = oRIw + cmax(8 * RIW, NXP);           // [nI] + pad slot
+    static constexpr int oXt = oYI + e2(D::nI + 2);                 // [NXP] x~ in node order
+    static constexpr int oWg = oXt + NXP;                           // [NXP] w = rho z - y in node order
+    static constexpr int oRedB = oWg + NXP;                         // [8] per-wave partial sums of w^T rhs
     static constexpr int oRedT = oRedB + 8;                         // [8] per-wave partial sums of the T column of A^T w
     static constexpr int lEnd = oRedT + 8;
-    static constexpr int size = cmax(fEnd, lEnd);
-    static_assert(size * 8 <= 160 * 1024 - 512, "LDS budget");
-    // factor workspace (doubles per arm): aux = LDS [oKJC, oMisc) + sum|ha|, then G rows [8][49][64], then S^-1 [CP][512]
-    static constexpr int AUX = oMisc - oKJC + 8;
-    static constexpr int FAC = AUX + 8 * 49 * 64 + CP * 512;
+    static constexpr int sizeF = fEnd, sizeL = lEnd;
+    static_assert(sizeF * 8 <= 160 * 1024 - 512 && sizeL * 8 <= 160 * 1024 - 512, "LDS budget");
+    // factor workspace (doubles per arm): the sparse K_JC [KJN], the T column [NAP], sum|ha| [8], the derived copies [DER], then
+    // the 4 x 13 blocks of G [8][52][64], then the 4 x SC blocks of S^-1 [4 SC][512] (both in the loop kernel's lane layout,
+    // see g_blk / s_blk)
+    static constexpr int oFT = KJN, oFH = oFT + NAP, AUX = oFH + 8;
+    static constexpr int oFD = AUX, oFG = oFD + DER, oFS = oFG + 8 * 52 * 64;
+    static constexpr int FAC = oFS + 4 * SC * 512;
     // misc slots
     static constexpr int M_xT = 0, M_zbT = 1, M_ybT = 2, M_baseT = 3, M_delta = 4, M_hdT = 5, M_rbT = 6, M_lbT = 7, M_ubT = 8,
                          M_xtT = 9, M_sumha = 10, M_dl = 12, M_done = 13, M_s0 = 14, M_s1 = 15, M_c0 = 16 /* 16..31: check exchange */;
@@ -144,10 +162,51 @@ __device__ __forceinline__ double g_dot(const double (&m)[49], const double *op)
 #define QB(k) do { } while (0)
 #endif
 
-#define QP3_PROLOGUE(NT_) \
+// LDS reads of the hot loop.  On gfx950 a ds_read_b64 occupies the LDS array for 2 cycles and a ds_read_b128 for 4, but a
+// ds_read2_b64 for 8 (MI355X_MICROARCH.md, LDS): the pairs the compiler forms out of neighbouring 8-byte reads cost twice what the
+// two single reads do.  Volatile reads in the LDS address space are neither paired nor re-ordered among themselves: they are issued
+// in program order, all in flight, and the compiler waits for each with a counted lgkmcnt just before its first use.
+typedef const volatile __attribute__((address_space(3))) double *vlds_t;
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) v2d *vlds2_t;
+__device__ __forceinline__ double ldv(const double *p) { return *(vlds_t)p; }
+__device__ __forceinline__ v2d ldv2(const double *p) { return *(vlds2_t)p; }       // p: 16-byte aligned
+
+// Block form of the same product for the loop kernel: the four lanes of a quad share four rows of G_s; lane (quad g, m) holds the
+// 4 x 13 block of rows 4g + (m ^ pos), pos = 0..3, and columns 13m .. 13m + 12, reads only ITS 13 operand entries (a row per
+// lane needs all 49 through LDS broadcasts), and a reduce-scatter over the quad (three DPP exchanges; the row order m ^ pos makes
+// them select-free) leaves row 4g + m in lane 4g + m.
+__device__ __forceinline__ double g_blk(const double (&m)[52], const double *op) {
+    double o[13];
+#pragma unroll
+    for (int j = 0; j < 13; j++) o[j] = ldv(op + j);
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 13; j++) { p0 += m[j] * o[j]; p1 += m[13 + j] * o[j]; p2 += m[26 + j] * o[j]; p3 += m[39 + j] * o[j]; }
+    const double q0 = p0 + dpp_mov<0x4E>(p2), q1 = p1 + dpp_mov<0x4E>(p3);          // lanes m, m ^ 2
+    return q0 + dpp_mov<0xB1>(q1);                                                  // lanes m, m ^ 1
+}
+// S^-1: sixteen lanes share four rows; lane (group g, c = 4a + m) holds rows 4g + (m ^ pos) x columns SC c .. SC c + SC - 1.
+// Quad reduce-scatter as above, then the four quads of the 16-lane DPP row are summed (row_ror 4, 8): every lane of the group
+// ends with the total of row 4g + m.
+template <int SC>
+__device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double *op) {
+    double o[SC];
+#pragma unroll
+    for (int j = 0; j < SC; j++) o[j] = ldv(op + j);
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SC; j++) { p0 += m[j] * o[j]; p1 += m[SC + j] * o[j]; p2 += m[2 * SC + j] * o[j]; p3 += m[3 * SC + j] * o[j]; }
+    const double q0 = p0 + dpp_mov<0x4E>(p2), q1 = p1 + dpp_mov<0x4E>(p3);
+    double x = q0 + dpp_mov<0xB1>(q1);
+    x += dpp_mov<0x124>(x);                                                         // row_ror:4
+    return x + dpp_mov<0x128>(x);                                                   // row_ror:8
+}
+
+#define QP3_PROLOGUE(NT_, FILL_CT_) \
     using D = Dim3<NSEG>; \
     using L = Qp3<NSEG>; \
-    constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = NT_, GS = L::GS, JS = L::JS, CP = L::CP; \
+    constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = NT_, GS = L::GS, JS = L::JS, SC = L::SC; \
     constexpr int n_tot = NARM * na + 1, mn_tot = NARM * (ma + na) + 1; \
     extern __shared__ __attribute__((aligned(16))) double lds[]; \
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = tid & 63; \
@@ -170,28 +229,19 @@ __device__ __forceinline__ double g_dot(const double (&m)[49], const double *op)
     const unsigned long long *xpar = NARM == 2 ? xch.buf + ((size_t)b * 2 + (1 - arm)) * MPCMP_XCH_STRIDE : nullptr; \
     int dead = 0, status = 0; \
     for (int i = tid; i < N * 8 * GS; i += NT) gkl[i] = (i % GS < 22) ? Gkg[(i / GS) * 22 + i % GS] : 0.0; \
-    for (int r = tid; r < meq; r += NT) { \
-        const int k = r / 14, rr = r % 14; \
-        lds[L::oCT + r] = -ts * zg_[(rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7]; \
-    } \
-    if (tid < 16) cD[tid] = c_D[tid]; \
+    auto coef_T = [&](int r) -> double { const int k = r / 14, rr = r % 14; return -ts * zg_[(rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7]; }; \
+    if (FILL_CT_) for (int r = tid; r < meq; r += NT) lds[L::oCT + r] = coef_T(r); \
+    if (tid < 32) cD[tid] = tid < 16 ? c_D[tid] : 0.0; \
     if (tid < 32) misc[tid] = 0.0; \
     double *cfl = lds + L::oCfg; \
     if (tid < 14) { cfl[tid] = cfg.lbx[tid]; cfl[14 + tid] = cfg.ubx[tid]; } \
     else if (tid < 21) { cfl[28 + tid - 14] = cfg.lbu[tid - 14]; cfl[35 + tid - 14] = cfg.ubu[tid - 14]; } \
     else if (tid < 29) { cfl[42 + tid - 21] = cfg.lbg[tid - 21]; cfl[50 + tid - 21] = cfg.ubg[tid - 21]; } \
     { \
-        int *pt = reinterpret_cast<int *>(lds + L::oPat), *xg = reinterpret_cast<int *>(lds + L::oXdG); \
+        int *pt = reinterpret_cast<int *>(lds + L::oPat); \
         if (tid < 49) pt[tid] = (int)pat->jc[tid]; \
         else if (tid < 77) pt[tid] = (int)pat->cjl[tid - 49]; \
         else if (tid < 105) pt[tid] = (int)pat->cjh[tid - 77]; \
-        if (tid < 512) { \
-            const int wv = tid >> 6, ln = tid & 63; \
-            int xd = na + 1; \
-            if (wv < NSEG && ln < 49) xd = ws.ext_of_int[49 * wv + ln]; \
-            if (wv == NSEG - 1 && ln >= 49 && ln < 56) xd = ws.ext_of_int[nJ + (ln - 49)]; \
-            xg[tid] = xd; \
-        } \
     } \
     __syncthreads(); \
     const double *c_lbx = cfl, *c_ubx = cfl + 14, *c_lbu = cfl + 28, *c_ubu = cfl + 35, *c_lbg = cfl + 42, *c_ubg = cfl + 50; \
@@ -252,7 +302,7 @@ __device__ __forceinline__ double g_dot(const double (&m)[49], const double *op)
 // reloads per matrix-vector product).
 template <int NSEG, int NARM>
 __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, double *__restrict__ fac) {
-    QP3_PROLOGUE(1024)
+    QP3_PROLOGUE(1024, true)
     assemble(0, D::EA);
     {   // sum |ha| of this arm (Gershgorin row of T, polympc_redef.hpp:57-70)
         double s = 0.0;
@@ -396,13 +446,13 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
               else if (i < 7) lds[L::fKUU + packed(i, j)] = val;
           });
     // factor registers: a G lane keeps its whole row of G_s, an S lane (later) its quarter row of S^-1
-    const bool isG = wave < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 49 && lane < 56;
+    const bool isG = wave < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 56 && lane < 63;
     double m[49];
 #pragma unroll
     for (int j = 0; j < 49; j++) {
         double val = 0.0;
         if (isG) val = -lds[L::fKJJ + wave * D::JP + packed(lane, j)];
-        if (isGu && j < 7) val = -lds[L::fKUU + packed(lane - 49, j)];
+        if (isGu && j < 7) val = -lds[L::fKUU + packed(lane - 56, j)];
         m[j] = val;
         if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);          // one-time loads: keep the address temporaries few
     }
@@ -479,68 +529,109 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     sweep(nI, 1, L::CB,
           [&](int, int i, int j) -> double { return S[packed(i, j)]; },
           [&](int, int i, int j, double val) { S[packed(i, j)] = val; });        // S <- -(S^-1)
+    // ---------------- derived copies of the coupling blocks in the access order of the loop kernel ----------------
+    double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
+    for (int i = tid; i < NSEG * 224; i += NT) {
+        const int sg = i / 224, c = (i % 224) >> 3, d = i & 7, r = c % 14 + 7 * (d - 1);
+        double val = 0.0;
+        if (d < 7 && r >= 0 && r < 49) {
+            const uint32_t w = pat->jc[r];
+#pragma unroll
+            for (int q = 0; q < 4; q++) if ((int)((w >> (8 * q)) & 255u) == c) val = lds[L::oKJC + sg * 196 + r * 4 + q];
+        }
+        fa[L::oFD + i] = val;
+    }
+    for (int i = tid; i < (NSEG + 1) * 112; i += NT) {
+        const int sg = i / 112;
+        const double *src = sg < NSEG ? lds + L::oKUX + sg * 98 : lds + L::oKuX;
+        { const int c = (i % 112) >> 3, r = i & 7; fa[L::oFD + (L::oKUXT - L::oKCJ) + i] = r < 7 ? src[r * 14 + c] : 0.0; }
+        { const int r = (i % 112) >> 4, c = i & 15; fa[L::oFD + (L::oKUXP - L::oKCJ) + i] = c < 14 ? src[r * 14 + c] : 0.0; }
+    }
+    if (tid < 16) fa[L::oFD + (L::oZR - L::oKCJ) + tid] = 0.0;
+    if (tid < 4) lds[L::oKJC + NSEG * 196 + tid] = 0.0;
+    __syncthreads();
     // ---------------- hand the factor to the loop kernel (once per QP: ~45k doubles per arm) ----------------
     {
         const int any = __syncthreads_or(status);
         if (tid == 0 && any) atomicOr(&ws.status[b], any);
     }
-    double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
-    for (int i = tid; i < L::AUX - 8; i += NT) fa[i] = lds[L::oKJC + i];            // sparse K_JC, dense blocks, -(K_UU^-1), T column, kappa
-    if (tid == 0) fa[L::AUX - 8] = misc[L::M_sumha];
+    for (int i = tid; i < L::KJN; i += NT) fa[i] = lds[L::oKJC + i];                // sparse K_JC + zero row
+    for (int i = tid; i < L::NAP; i += NT) fa[L::oFT + i] = lds[L::oKT + i];        // T column, kappa
+    if (tid == 0) fa[L::oFH] = misc[L::M_sumha];
     if (wave < 8) {
+        // row `lane` of G_s (or of G_u: lanes 56..62 of the last segment's wave), scattered into the block layout of g_blk
+        double *fg = fa + L::oFG + (size_t)(wave * 52) * 64 + (lane & ~3);
+        const int rpos = lane & 3;
 #pragma unroll
-        for (int j = 0; j < 49; j++) fa[L::AUX + (wave * 49 + j) * 64 + lane] = m[j];
+        for (int c = 0; c < 52; c++) {
+            const int mcol = c / 13, e = ((rpos ^ mcol) * 13 + c % 13);
+            fg[e * 64 + mcol] = c < 49 ? m[c] : 0.0;
+        }
     } else {
-        const int si = tid - 512, srow = si >> 2, spart = si & 3;
-#pragma unroll 4
-        for (int j = 0; j < CP; j++) {
-            const int col = spart * CP + j;
-            fa[L::AUX + 8 * 49 * 64 + j * 512 + si] = (srow < nI && col < nI) ? -S[packed(srow, col)] : 0.0;
+        const int si = tid - 512, row0 = 4 * (si >> 4), mpos = si & 3, col0 = SC * (si & 15);
+        for (int e = 0; e < 4 * SC; e++) {
+            const int row = row0 + (mpos ^ (e / SC)), col = col0 + e % SC;
+            fa[L::oFS + e * 512 + si] = (row < nI && col < nI) ? -S[packed(row, col)] : 0.0;
         }
     }
 }
 
-// ADMM half of the QP (see the header comment): 512 threads = 8 waves, two per SIMD, so every lane may hold 256 registers — its row
-// of G_s (98), its quarter row of S^-1 (2 CP) and its ADMM state stay in VGPRs for the whole loop.  (With 1024 threads and 128
-// registers the compiler kept part of the rows in scratch; one scratch reload costs ~500 cycles and they are serialised, so the
-// seven reloads of a 26-term dot product made it take 3,500 cycles.)  Every wave takes part in every phase:
+// ADMM half of the QP (see the header comment): 512 threads = 8 waves, two per SIMD, so every lane may hold 256 registers — its
+// 4 x 13 block of G_s (104), its 4 x SC block of S^-1 (56..64) and its ADMM state stay in VGPRs for the whole loop.  (With 1024
+// threads and 128 registers the compiler kept part of the factor in scratch; one scratch reload costs ~500 cycles and they are
+// serialised, so the seven reloads of a 26-term dot product made it take 3,500 cycles.)  Every wave takes part in every phase:
 //     A   rhs = sigma x - q + rho_b z_b - y_b + A^T w                      (lane = variable)
-//     P1  t = G b_J, part = K_CJ t                                         (wave = segment, lane = row of G_s)
-//     P3  r_I = b_I - part, y_I = S^-1 r_I                                 (four lanes per row of S^-1)
+//     P1  t = G b_J, part = K_CJ t                                         (wave = segment, quad = four rows of G_s)
+//     P3  r_I = b_I - part, y_I = S^-1 r_I                                 (sixteen lanes per four rows of S^-1)
 //     P4  x_J = G (b_J - K_JC y_I), x~ = y - w x~_T                        (wave = segment; interface rows by the S lanes)
 //     E   z~ = A x~, relaxation, projection, dual update                   (lane = row / variable)
+// The loop is bound by instruction issue (a wave64 VALU or LDS instruction occupies its unit for >= 4 clocks, and there are only
+// two waves per SIMD to overlap anything), so the data layout is chosen to make every hot-loop access "lane base + immediate":
+// x~, the border vector w and w = rho z - y are kept in NODE order ([x_k | u_k | x~_T], [dynamics rows | path rows], stride 22 =
+// the row stride of the path Jacobians), and what a lane needs to know about its variable / row is packed in one register.
 template <int NSEG, int NARM>
 __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, const double *__restrict__ fac) {
-    QP3_PROLOGUE(512)
+    QP3_PROLOGUE(512, false)
+    constexpr int NS = L::NS, NX = L::NX;
 #ifdef MPCMP_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_busy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
 #endif
     // ---------------- the factor, as the factorisation kernel left it ----------------
     const double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
-    for (int i = tid; i < L::AUX - 8; i += NT) lds[L::oKJC + i] = fa[i];
-    if (tid == 0) misc[L::M_sumha] = fa[L::AUX - 8];
-    __syncthreads();
+    for (int i = tid; i < L::KJN + L::NAP; i += NT) lds[L::lKJC + i] = fa[i];
+    for (int i = tid; i < L::DER; i += NT) lds[L::oKCJ + i] = fa[L::oFD + i];
+    if (tid == 0) misc[L::M_sumha] = fa[L::oFH];
     // ---------------- loop set-up ----------------
-    int *rpos = reinterpret_cast<int *>(lds + L::oRpos);
+    int *rpos = reinterpret_cast<int *>(lds + L::oRpos), *xdgt = reinterpret_cast<int *>(lds + L::oXdG);
     auto rhs_slot = [&](int ip) -> int {
         return ip < nJ ? L::oRhsJ + JS * (ip / 49) + ip % 49 : (ip < nJ + 7 ? L::oRhsU + (ip - nJ) : L::oRhsI + (ip - nJ - 7));
     };
-    double *rhsI = lds + L::oRhsI, *part = lds + L::oPart, *partU = lds + L::oPart + NSEG * 28, *yI = lds + L::oYI, *xt = lds + L::oXt,
+    auto node_slot = [&](int v) -> int {            // external arm variable -> slot in the node-ordered vectors
+        return v < 14 * N ? NS * (v / 14) + v % 14 : NS * ((v - 14 * N) / 7) + 14 + (v - 14 * N) % 7;
+    };
+    double *rhsI = lds + L::oRhsI, *part = lds + L::oPart, *partU = lds + L::oPart + NSEG * 28, *xt = lds + L::oXt,
            *wg = lds + L::oWg, *wvv = lds + L::oWv, *redB = lds + L::oRedB, *redT = lds + L::oRedT;
     {
+        // where the G lanes' entries of x~ go
+        const int wv = tid >> 6, ln = tid & 63;
+        int xd = NX;
+        if (wv < NSEG && ln < 49) xd = node_slot(ws.ext_of_int[49 * wv + ln]);
+        if (wv == NSEG - 1 && ln >= 56 && ln < 63) xd = node_slot(ws.ext_of_int[nJ + (ln - 56)]);
+        xdgt[tid] = xd;
         // loop-resident constants and the rhs of K_0 w = k
         for (int i = tid; i < L::oRedT + 8 - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;        // vectors, pads, partial sums
+        for (int i = tid; i < L::NXP; i += NT) lds[L::oWv + i] = 0.0;
         __syncthreads();
         for (int v = tid; v < na; v += NT) {
             double ha, rb, lo, hi;
             var_h(v, ha, rb, lo, hi);
             const double zv = zg_[v];
-            lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv; lds[L::oRb + v] = rb; lds[L::oRi + v] = 1.0 / rb; lds[L::oWv + v] = 0.0;
+            lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv; lds[L::oRb + v] = rb;
             rpos[v] = rhs_slot(int3_of_ext(NSEG, v));
         }
         for (int r = tid; r < ma; r += NT) {
             double lg, ug, rr, cf;
-            if (r < meq) { lg = ug = -ws.ceq[((size_t)b * NARM + arm) * meq + r]; rr = rho_eq; cf = lds[L::oCT + r]; }
+            if (r < meq) { lg = ug = -ws.ceq[((size_t)b * NARM + arm) * meq + r]; rr = rho_eq; cf = coef_T(r); }
             else {
                 const int q = (r - meq) & 7;
                 const double gv = ws.g[((size_t)b * NARM + arm) * 8 * N + (r - meq)];
@@ -548,26 +639,26 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 rr = (ug - lg < 1e-4) ? rho_eq : rho_in;
                 cf = gkl[(r - meq) * GS + 21];
             }
-            lds[L::oLg + r] = lg; lds[L::oUg + r] = ug; lds[L::oRr + r] = rr; lds[L::oRri + r] = 1.0 / rr; lds[L::oCf + r] = cf;
+            lds[L::oLg + r] = lg; lds[L::oUg + r] = ug; lds[L::oRr + r] = rr; lds[L::oCf + r] = cf;
         }
         if (tid == 0) {
             misc[L::M_lbT] = cfg.lbT - T; misc[L::M_ubT] = cfg.ubT - T;
             misc[L::M_rbT] = (cfg.ubT - cfg.lbT < 1e-4) ? rho_eq : rho_in;
         }
         __syncthreads();
-        for (int ip = tid; ip < na; ip += NT) lds[rhs_slot(ip)] = lds[L::oKT + ip];
+        for (int ip = tid; ip < na; ip += NT) lds[rhs_slot(ip)] = lds[L::lKT + ip];
         __syncthreads();
     }
     // after the solve of K_0 w = k: w and delta of the T border (one exchange between the arm workgroups)
     auto finish_border = [&]() {
         double sacc = 0.0;
-        for (int v = tid; v < na; v += NT) sacc += lds[L::oKT + int3_of_ext(NSEG, v)] * xt[v];
+        for (int v = tid; v < na; v += NT) sacc += lds[L::lKT + int3_of_ext(NSEG, v)] * xt[node_slot(v)];
         double sv[1] = {sacc};
         block_reduce<8, 1, false>(sv, redp, tid);
-        for (int v = tid; v < na; v += NT) wvv[v] = xt[v];
+        for (int v = tid; v < na; v += NT) wvv[node_slot(v)] = xt[node_slot(v)];
         if (tid == 0) {
             double kap[2] = {0.0, 0.0}, sh[2] = {0.0, 0.0}, dl[2] = {0.0, 0.0};
-            kap[arm] = lds[L::oKT + na]; sh[arm] = misc[L::M_sumha]; dl[arm] = sv[0];
+            kap[arm] = lds[L::lKT + na]; sh[arm] = misc[L::M_sumha]; dl[arm] = sv[0];
             if (NARM == 2) {
                 xch_post(xown + 0, kap[arm]); xch_post(xown + 1, sh[arm]); xch_post(xown + 2, dl[arm]);
                 kap[1 - arm] = xch_poll(xpar + 0, dead); sh[1 - arm] = xch_poll(xpar + 1, dead); dl[1 - arm] = xch_poll(xpar + 2, dead);
@@ -622,73 +713,118 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         const double ed = cfg.eps_abs + cfg.eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);      // ||q||_inf = 1
         return (mx[0] <= ep && mx[3] <= ed) ? 1 : 0;
     };
-    // Per-lane constants of the solve, rebuilt from LDS tables / arithmetic on an OPAQUE copy of the thread index in every
-    // iteration: everything derived from them (LDS addresses of the sparse K_JC entries, of the operands, ...) is loop invariant,
-    // and hoisted out of the loop it would occupy > 100 VGPRs and evict the factor rows to scratch.
-    struct LaneC { int lane, srow, spart, xdg, xds; uint32_t jcw, cjl, cjh; };
-    const int *patw = reinterpret_cast<const int *>(lds + L::oPat), *xdgt = reinterpret_cast<const int *>(lds + L::oXdG);
-    auto lane_consts = [&](int t) -> LaneC {
-        LaneC c;
-        c.lane = t & 63; c.srow = t >> 2; c.spart = t & 3; c.xdg = xdgt[t];
-        c.xds = (c.srow < nI && c.spart == 0) ? 42 * (c.srow / 14) + c.srow % 14 : na + 1;      // interface rows x_0, x_3, ... (pad slot otherwise)
-        c.jcw = c.lane < 49 ? (uint32_t)patw[c.lane] : 0xFFFFFFFFu;
-        c.cjl = c.lane < 28 ? (uint32_t)patw[49 + c.lane] : 0xFFFFFFFFu;
-        c.cjh = c.lane < 28 ? (uint32_t)patw[77 + c.lane] : 0xFFFFFFFFu;
+    // Per-lane constants of the solve: LDS addresses (in doubles).  Every access of the solve is such a base plus a compile-time
+    // offset (the sparse K_JC is stored with canonical slots and a column-form copy for exactly this), so it carries no index
+    // arithmetic, no pattern words and no selects; lanes without a job point at zero rows / pad slots.  The bases are cheap
+    // functions of the lane index and are re-derived from an OPAQUE copy of it in every iteration (hoisted out of the loop they
+    // would occupy twenty registers that the factor blocks need); the three that are not cheap are packed in two registers.
+    const int *patw = reinterpret_cast<const int *>(lds + L::oPat);
+    int pk_x, pk_y;                                  // x~ slots of the interior row (low) and of the interface row (high); y_C base column, rhs slot
+    {
+        const int ln = lane;
+        int srow = 4 * (tid >> 4) + (tid & 3);
+        if ((tid & 15) >= 4 || srow >= nI) srow = -1;                        // (not an output lane of S^-1)
+        const int xds = srow >= 0 ? NS * 3 * (srow / 14) + srow % 14 : NX;    // interface rows x_0, x_3, ...
+        pk_x = xdgt[tid] | (xds << 16);
+        pk_y = (ln < 49 ? (patw[ln] & 255) : 7) | ((tid < na ? rpos[tid] : 0) << 16);
+    }
+    struct LaneC1 {
+        int tslot, op1;               // tJ slot of the own row; operand block of G b_J
+        int kcj, tcc, partd;          // column form of K_JC, tJ + c % 14, destination in part
+        int p1k, p1t, p1d;            // dense blocks, two lanes per column (half a column of K_XU each): coefficients, operand, destination
+    };
+    struct LaneC3 { int rop, ysl; };  // operand of the S^-1 block, y_I slot
+    struct LaneC4 {
+        int xds, xdg;                 // destinations of the interface row and of the interior row in x~
+        int tslot, op4;               // tJ slot of the own row; operand block of the second G product
+        int bjr, kjr, ycb;            // own rhs entry, row of the sparse K_JC, y_C + base column
+        int p4k, p4y, p4d, p4r;       // dense blocks, four lanes per row (a quarter row of K_UX each); where the own row finds its dense part
+    };
+    // (each set is derived right in front of its phase from a fresh opaque copy of the lane index: short live ranges)
+    auto lane_c1 = [&](int t) -> LaneC1 {
+        asm volatile("" : "+v"(t));
+        LaneC1 c;
+        const int ln = t & 63, wv = wave, wg_ = wv < NSEG ? wv : 0;          // (waves without a segment: valid addresses, results unused)
+        const bool g_row = ln < 49, gu_quad = wv == NSEG - 1 && ln >= 56, gu_row = gu_quad && ln < 63;
+        const int tJ = L::oTJ + wv * L::TS;
+        c.tslot = g_row ? tJ + ln : (gu_row ? L::oTU + ln - 56 : tJ + 56);
+        c.op1 = (gu_quad ? L::oRhsU : L::oRhsJ + JS * wg_) + 13 * (ln & 3);
+        const int cl = ln < 28 ? ln : 27;
+        c.kcj = L::oKCJ + (wg_ * 28 + cl) * 8;
+        c.tcc = tJ + (cl < 14 ? cl : cl - 14);
+        c.partd = L::oPart + (ln < 28 ? wg_ * 28 + cl : NSEG * 28 + 14);     // (dummy slot behind partU)
+        const int c2 = ln >> 1, j = ln & 1;
+        const bool lastw = wv == NSEG - 1, useg = c2 < 14, uU = lastw && c2 >= 14 && c2 < 28;
+        c.p1k = useg ? L::oKUXT + (wg_ * 14 + c2) * 8 + 4 * j : (uU ? L::oKUXT + (NSEG * 14 + c2 - 14) * 8 + 4 * j : L::oZR);
+        c.p1t = (uU ? L::oTU : tJ) + 4 * j;
+        c.p1d = j ? L::oDP + NSEG * 14 : (useg ? L::oDP + wg_ * 14 + c2 : (uU ? L::oPart + NSEG * 28 + c2 - 14 : L::oDP + NSEG * 14));
         return c;
     };
-    // this lane's row of G_s and quarter row of S^-1 (k_qp3f left them in the factor workspace).  They are loaded again at the top
+    auto lane_c3 = [&](int t) -> LaneC3 {
+        asm volatile("" : "+v"(t));
+        LaneC3 c;
+        const int srow = 4 * (t >> 4) + (t & 3);
+        c.rop = L::oRIw + wave * L::RIW + SC * (t & 15);
+        c.ysl = L::oYI + (((t & 15) < 4 && srow < nI) ? srow : nI + 1);      // (lanes without an output row: pad slot)
+        return c;
+    };
+    auto lane_c4 = [&](int t, int px, int py) -> LaneC4 {
+        asm volatile("" : "+v"(t), "+v"(px), "+v"(py));
+        LaneC4 c;
+        const int ln = t & 63, wv = wave, wg_ = wv < NSEG ? wv : 0;
+        const bool g_row = ln < 49, gu_quad = wv == NSEG - 1 && ln >= 56, gu_row = gu_quad && ln < 63;
+        const int lr = g_row ? ln : (gu_row ? ln - 56 : 0), tJ = L::oTJ + wv * L::TS;
+        c.xds = L::oXt + (int)((unsigned)px >> 16);
+        c.xdg = L::oXt + (px & 0xFFFF);
+        c.tslot = g_row ? tJ + ln : (gu_row ? L::oTU + ln - 56 : tJ + 56);
+        c.op4 = (gu_quad ? L::oTU : tJ) + 13 * (ln & 3);
+        c.bjr = (gu_quad ? L::oRhsU : L::oRhsJ + JS * wg_) + lr;
+        c.kjr = L::lKJC + (g_row ? wg_ * 196 + ln * 4 : NSEG * 196);         // (others: the zero row)
+        c.ycb = L::oYI + 14 * wg_ + (py & 0xFFFF);
+        const int r4 = ln >> 2, j = ln & 3;
+        const bool lastw = wv == NSEG - 1, useg = r4 < 7, uU = lastw && r4 >= 7 && r4 < 14;
+        c.p4k = useg ? L::oKUXP + (wg_ * 7 + r4) * 16 + 4 * j : (uU ? L::oKUXP + (NSEG * 7 + r4 - 7) * 16 + 4 * j : L::oZR);
+        c.p4y = L::oYI + 14 * (uU ? NSEG : wg_) + 4 * j;
+        c.p4d = L::oDW + wv * 16 + ((j == 0 && (useg || uU)) ? r4 : 15);
+        c.p4r = ln < 7 ? L::oDW + wv * 16 + ln : (gu_row ? L::oDW + wv * 16 + 7 + lr : L::oZR);
+        return c;
+    };
+    // this lane's blocks of G_s and of S^-1 (k_qp3f left them in the factor workspace).  They are loaded again at the top
     // of every termination-test period, through an opaque pointer: a value defined right in front of the hot loop and dead
     // after it is kept in VGPRs by the register allocator.
-    double mm[49], sm[CP];
+    double mm[52], sm[4 * SC];
     auto load_rows = [&]() {
-        const double *fo = fa + L::AUX + (size_t)(wave * 49) * 64 + lane, *so = fa + L::AUX + 8 * 49 * 64 + tid;
+        const double *fo = fa + L::oFG + (size_t)(wave * 52) * 64 + lane, *so = fa + L::oFS + tid;
         asm volatile("" : "+v"(fo), "+v"(so));
 #pragma unroll
-        for (int j = 0; j < 49; j++) mm[j] = fo[j * 64];
+        for (int j = 0; j < 52; j++) mm[j] = fo[j * 64];
 #pragma unroll
-        for (int j = 0; j < CP; j++) sm[j] = so[j * 512];
+        for (int j = 0; j < 4 * SC; j++) sm[j] = so[j * 512];
     };
-    // One solve with K_0 (three barriers).  Branch-free per lane (selects and dummy slots instead of lane-dependent branches:
-    // with a dozen exec-masked blocks in the hot loop the register allocator gave up on keeping the rows in VGPRs).
-    auto solve = [&](const bool use_xT, const int it, const LaneC &c) {
-        const int ln = c.lane, wv = wave;
-        const bool g_row = ln < 49, gu_row = wv == NSEG - 1 && ln >= 49 && ln < 56;
-        const int lr = g_row ? ln : (gu_row ? ln - 49 : 0);                  // row inside its block
-        double *tJ = lds + L::oTJ + wv * 128;                  // wave-private: [0..49] segment operand / result, [64..113] U block, [120] dummy
-        const double *bj = lds + (gu_row ? L::oRhsU : L::oRhsJ + JS * wv);
-        const double *kjc_ = lds + L::oKJC + wv * 196, *kux_ = lds + L::oKUX + wv * 98, *kuX = lds + L::oKuX;
-        const int tslot = g_row ? ln : (gu_row ? 64 + ln - 49 : 120);
+    // One solve with K_0 (three barriers), straight-line code for every lane.
+    auto solve = [&](const bool use_xT, const int it, const int tl, const int px, const int py) {
+        const int wv = wave;
         // ---- P1: t = G b_J, part = K_CJ t; this arm's share of the T solve, s_a = (T column of A^T w) - w^T rhs ----
         if (wv < NSEG) {
-            tJ[tslot] = g_dot(mm, bj);
+            const LaneC1 c = lane_c1(tl);
+            lds[c.tslot] = g_blk(mm, lds + c.op1);
             wave_sync();
-            const int cl = ln < 28 ? ln : 27;
+            const double *kc = lds + c.kcj, *tc = lds + c.tcc;
+            double kq[7], tv[7], dk[4], dt[4];
+#pragma unroll
+            for (int d = 0; d < 7; d++) { kq[d] = ldv(kc + d); tv[d] = ldv(tc + 7 * (d - 1)); }      // rows c % 14 + 7 (d - 1) of the segment
+#pragma unroll
+            for (int d = 0; d < 4; d++) { dk[d] = ldv(lds + c.p1k + d); dt[d] = ldv(lds + c.p1t + d); }
             double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t ref = ((q < 4 ? c.cjl : c.cjh) >> (8 * (q & 3))) & 255u;
-                double kv = kjc_[(ref >> 2) * 4 + (ref & 3u)];           // (ref = 255: a valid address, value discarded)
-                kv = ref != 255u ? kv : 0.0;
-                acc += kv * tJ[(ref >> 2) & 63];
-                if (q == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const double f14 = ln < 14 ? 1.0 : 0.0;
-            const int c14 = ln < 14 ? ln : 13;
-            double accd = 0.0;
-#pragma unroll
-            for (int r = 0; r < 7; r++) { accd += kux_[r * 14 + c14] * tJ[r]; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
-            acc += f14 * accd;
-            part[ln < 28 ? wv * 28 + cl : NSEG * 28 + 14] = acc;              // (dummy slot behind partU)
-            if (wv == NSEG - 1) {
-                const int cc = (ln >= 32 && ln < 46) ? ln - 32 : 0;
-                double au = 0.0;
-#pragma unroll
-                for (int r = 0; r < 7; r++) { au += kuX[r * 14 + cc] * tJ[64 + r]; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
-                partU[(ln >= 32 && ln < 46) ? cc : 15] = au;                  // (15: dummy)
-            }
+            for (int d = 0; d < 7; d++) acc += kq[d] * tv[d];
+            lds[c.partd] = acc;
+            // dense blocks (K_XU t of the columns x_3s; for the last segment also the U block): half a column per lane
+            double ad = dk[0] * dt[0];
+            ad += dk[1] * dt[1]; ad += dk[2] * dt[2]; ad += dk[3] * dt[3];
+            lds[c.p1d] = ad + dpp_mov<0xB1>(ad);                                   // (odd lanes, lanes without a column: pad slot)
         }
-        if (use_xT && wv == 7 && ln == 63) {
+        if (use_xT && tid == 511) {
             double ssum = 0.0, bsum = 0.0;
 #pragma unroll
             for (int w8 = 0; w8 < 8; w8++) { ssum += redT[w8]; bsum += redB[w8]; }
@@ -700,128 +836,142 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         // ---- P3: r_I = b_I - part (every wave its own copy), y_I = S^-1 r_I ----
         double yi;
         {
-            double *rIw = lds + L::oRIw + wv * 4 * CP;
-            for (int i = ln; i < 4 * CP; i += 64) {
+            double *rIw = lds + L::oRIw + wv * L::RIW;
+            for (int i = lane; i < L::RIW; i += 64) {
                 double r = 0.0;
                 if (i < nI) {
                     const int sN = i / 14, cc = i % 14;
                     r = rhsI[i];
                     if (sN > 0) r -= part[(sN - 1) * 28 + 14 + cc];
-                    if (sN < NSEG) r -= part[sN * 28 + cc];
+                    if (sN < NSEG) r -= part[sN * 28 + cc] + lds[L::oDP + sN * 14 + cc];
                     else r -= partU[cc];
                 }
                 rIw[i] = r;
             }
             wave_sync();
-            const double *rv = rIw + c.spart * CP;
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int j0 = 0; j0 < CP / 2; j0 += 4) {
-                D2 v4[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) if (j0 + q < CP / 2) v4[q] = lds2(rv + 2 * (j0 + q));
-#pragma unroll
-                for (int q = 0; q < 4; q++) if (j0 + q < CP / 2) { a0 += sm[2 * (j0 + q)] * v4[q].x; a1 += sm[2 * (j0 + q) + 1] * v4[q].y; }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            yi = sum4(a0 + a1);
-            yI[(c.srow < nI && c.spart == 0) ? c.srow : nI + 1] = yi;          // (pad slot behind y_I)
+            const LaneC3 c = lane_c3(tl);
+            yi = s_blk<SC>(sm, lds + c.rop);
+            lds[c.ysl] = yi;                                                   // (lanes without an output row: pad slot nI + 1)
         }
         QB(2); __syncthreads(); QS(2);
         // ---- P4: x_J = G (b_J - K_JC y_I); x~ = y - w x~_T ----
         {
-            const double xT = use_xT ? border_xT(it, ln) : 0.0;
-            xt[c.xds] = yi - wvv[c.xds] * xT;                                  // interface rows (others: pad slot na + 1)
-            if (wv == 7 && ln == 63) xt[na] = xT;
+            const double xT = use_xT ? border_xT(it, lane) : 0.0;
+            const LaneC4 c = lane_c4(tl, px, py);
+            constexpr int dW = L::oWv - L::oXt;                                // w lives at a fixed distance from x~
+            lds[c.xds] = yi - lds[c.xds + dW] * xT;                            // interface rows (others: the pad slot)
+            if (tid < N) xt[NS * tid + 21] = xT;                               // x~_T, once per node: the 22nd operand of the path rows
             if (wv < NSEG) {
-                const double *yc = yI + 14 * wv;
-                double cr = bj[lr];
-                const double fs = g_row ? 1.0 : 0.0;
+                // dense blocks (rows u_3s x x_3s; for the last segment also the U block x x_{N-1}): a quarter row per lane
+                {
+                    double dk[4], dy[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t cc = (c.jcw >> (8 * q)) & 255u;
-                    double kv = kjc_[lr * 4 + q];
-                    kv = cc != 255u ? kv : 0.0;
-                    cr -= fs * kv * yc[cc & 31u];
+                    for (int d = 0; d < 4; d++) { dk[d] = ldv(lds + c.p4k + d); dy[d] = ldv(lds + c.p4y + d); }
+                    double ad = dk[0] * dy[0];
+                    ad += dk[1] * dy[1]; ad += dk[2] * dy[2]; ad += dk[3] * dy[3];
+                    lds[c.p4d] = sum4(ad);                                     // (lanes 1..3 of a quad, lanes without a row: pad slot)
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                // dense part: rows u_3s x x_3s of the segment, or the U block x x_{N-1}
-                const double fd = (ln < 7 || gu_row) ? 1.0 : 0.0;
-                const double *dp = gu_row ? kuX + lr * 14 : kux_ + (ln < 7 ? ln : 0) * 14, *yb = gu_row ? yI + 14 * NSEG : yc;
-                double cd = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < 14; cc++) { cd += dp[cc] * yb[cc]; if (cc % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
-                cr -= fd * cd;
-                tJ[tslot] = cr;
+                const double *kr = lds + c.kjr, *yc = lds + c.ycb;
+                const double k0 = ldv(kr), k1 = ldv(kr + 1), k2 = ldv(kr + 2), k3 = ldv(kr + 3);
+                const double y0 = ldv(yc), y1 = ldv(yc + 14), y2 = ldv(yc - 7), y3 = ldv(yc + 7);
+                double cr = ldv(lds + c.bjr);
+                cr -= k0 * y0;
+                cr -= k1 * y1;
+                cr -= k2 * y2;
+                cr -= k3 * y3;
                 wave_sync();
-                const double xj = g_dot(mm, gu_row ? tJ + 64 : tJ);
-                xt[c.xdg] = xj - wvv[c.xdg] * xT;                              // (inactive lanes: xdg = na + 1, the pad slot)
+                lds[c.tslot] = cr - ldv(lds + c.p4r);
+                wave_sync();
+                const double xj = g_blk(mm, lds + c.op4);
+                lds[c.xdg] = xj - lds[c.xdg + dW] * xT;                        // (lanes without a row: the pad slot)
             }
         }
         QB(3); __syncthreads(); QS(3);
     };
-    // lane si owns arm variables si, si + 512 and general rows si, si + 512 (ADMM state in registers, constants in LDS)
+    // lane t owns arm variables t, t + 512 and general rows t, t + 512 (ADMM state in registers, constants in LDS).  One packed
+    // word per variable: node slot (16 bits) | offset in the node (5) | column of D for the rows of its own segment, 16 = none
+    // (5) | the same for the previous segment (5) | has a -ts T term (1); one per row: first operand slot (16) | i = k % 3 (2).
     constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
     static_assert(NV <= 2 && NR <= 2, "two variables and two rows per lane at most");
     double xv0 = 0, zb0 = 0, yb0 = 0, xv1 = 0, zb1 = 0, yb1 = 0, zg0 = 0, yg0 = 0, zg1 = 0, yg1 = 0;
-    auto col_gather = [&](const double *w, int v) -> double {      // (A^T w)[v] without the T row
-        double sacc = 0.0;
-        int k, gcol;
-        if (v < 14 * N) {
-            k = v / 14; const int c = v % 14;
-            if (k % 3 != 0) {
-                const int j = k % 3, rA = 14 * 3 * (k / 3) + c;
-                sacc += cD[j] * w[rA] + cD[4 + j] * w[rA + 14] + cD[8 + j] * w[rA + 28];
-            } else {
-                if (k < N - 1) { const int rA = 14 * k + c; sacc += cD[0] * w[rA] + cD[4] * w[rA + 14] + cD[8] * w[rA + 28]; }
-                if (k > 0) { const int rB = 14 * (k - 3) + c; sacc += cD[3] * w[rB] + cD[7] * w[rB + 14] + cD[11] * w[rB + 28]; }
-            }
-            if (c >= 7 && k <= N - 2) sacc -= tsT * w[14 * k + c - 7];
-            gcol = k * 8 * GS + c;
-        } else {
-            k = (v - 14 * N) / 7; const int c = (v - 14 * N) % 7;
-            if (k <= N - 2) sacc -= tsT * w[14 * k + 7 + c];
-            gcol = k * 8 * GS + 14 + c;
-        }
-        const double *gc = gkl + gcol, *wp = w + meq + 8 * k;
-        __builtin_amdgcn_sched_barrier(0);
+    unsigned dv[NV], dr[NR];
 #pragma unroll
-        for (int q = 0; q < 8; q++) sacc += gc[q * GS] * wp[q];
-        __builtin_amdgcn_sched_barrier(0);
+    for (int h = 0; h < NV; h++) {
+        const int v = tid + 512 * h;
+        unsigned d = 0;
+        if (v < na) {
+            const bool isx = v < 14 * N;
+            const int k = isx ? v / 14 : (v - 14 * N) / 7, o = isx ? v % 14 : 14 + (v - 14 * N) % 7, j = k % 3;
+            const int ja = (isx && (j != 0 || k < N - 1)) ? j : 16, jb = (isx && j == 0 && k > 0) ? 3 : 16;
+            const int fT = (o >= 7 && k <= N - 2) ? 1 : 0;
+            d = (unsigned)(NS * k + o) | ((unsigned)o << 16) | ((unsigned)ja << 21) | ((unsigned)jb << 26) | ((unsigned)fT << 31);
+        }
+        dv[h] = d;
+    }
+#pragma unroll
+    for (int h = 0; h < NR; h++) {
+        const int r = tid + 512 * h;
+        unsigned d = 0;
+        if (r < meq) { const int k = r / 14, rr = r % 14; d = (unsigned)(NS * 3 * (k / 3) + rr) | ((unsigned)(k % 3) << 16); }
+        else if (r < ma) d = (unsigned)(NS * ((r - meq) >> 3));
+        dr[h] = d;
+    }
+    // (A^T w)[v] without the T row; w in node order
+    auto col_gather = [&](const double *w, unsigned d) -> double {
+        const int av = d & 0xFFFF, o = (d >> 16) & 31, ja = (d >> 21) & 31, jb = (d >> 26) & 31;
+        const int nb = av - o;
+        const int ia = av - NS * ja, ib = av - 3 * NS, it_ = av - 7;
+        const double *wa = w + (ia > 0 ? ia : 0), *wb = w + (ib > 0 ? ib : 0), *wt = w + (it_ > 0 ? it_ : 0);
+        const double *ca = cD + ja, *cb = cD + jb;                              // (16: the zero rows behind D)
+        const double ct = (d >> 31) ? -tsT : 0.0;
+        const double *gc = gkl + 8 * nb + o, *wp = w + nb + 14;
+        const double a0 = ldv(ca), a1 = ldv(ca + 4), a2 = ldv(ca + 8), u0 = ldv(wa), u1 = ldv(wa + NS), u2 = ldv(wa + 2 * NS);
+        const double b0 = ldv(cb), b1 = ldv(cb + 4), b2 = ldv(cb + 8), v0 = ldv(wb), v1 = ldv(wb + NS), v2 = ldv(wb + 2 * NS);
+        const double wtv = ldv(wt);
+        double sacc = a0 * u0 + a1 * u1 + a2 * u2;
+        sacc += b0 * v0 + b1 * v1 + b2 * v2;
+        sacc += ct * wtv;
+        double g8[8], w8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { g8[q] = ldv(gc + q * GS); w8[q] = ldv(wp + q); }
+#pragma unroll
+        for (int q = 0; q < 8; q++) sacc += g8[q] * w8[q];
         return sacc;
     };
-    auto row_dot = [&](const double *xe, int r) -> double {         // (A x)[r]; xe: external arm order, T at [na]
+    // (A x)[r]; x in node order (slot 21 of every node: x_T)
+    auto row_dot = [&](const double *xe, unsigned d, int r) -> double {
         double sacc;
+        const int a0 = d & 0xFFFF;
         if (r < meq) {
-            const int k = r / 14, rr = r % 14, i = k % 3, ix0 = 14 * 3 * (k / 3) + rr;
-            const int ixf = (rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7;
-            sacc = cD[4 * i] * xe[ix0] + cD[4 * i + 1] * xe[ix0 + 14] + cD[4 * i + 2] * xe[ix0 + 28] + cD[4 * i + 3] * xe[ix0 + 42] -
-                   tsT * xe[ixf] + lds[L::oCf + r] * xe[na];
+            const int i = (d >> 16) & 3;
+            const double *x0 = xe + a0, *cr = cD + 4 * i;
+            const double c0 = ldv(cr), c1 = ldv(cr + 1), c2 = ldv(cr + 2), c3 = ldv(cr + 3);
+            const double x_0 = ldv(x0), x_1 = ldv(x0 + NS), x_2 = ldv(x0 + 2 * NS), x_3 = ldv(x0 + 3 * NS), xf_ = ldv(x0 + NS * i + 7);
+            const double cf = ldv(lds + L::oCf + r), xT_ = ldv(xe + 21);
+            sacc = c0 * x_0 + c1 * x_1 + c2 * x_2 + c3 * x_3 - tsT * xf_ + cf * xT_;
         } else {
-            const int k = (r - meq) >> 3;
-            const double *gr = gkl + (r - meq) * GS, *xk = xe + 14 * k, *uk = xe + 14 * N + 7 * k;
-            sacc = gr[21] * xe[na];
-            // (chunks of seven terms: all 42 operand reads in flight at once would cost 84 VGPRs)
+            const double *gr = gkl + (r - meq) * GS, *xk = xe + a0;
+            sacc = 0.0;
+            // (three parts: all 22 operand pairs in flight at once would take 88 registers)
 #pragma unroll
-            for (int c = 0; c < 7; c++) sacc += gr[c] * xk[c];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int hf = 0; hf < 3; hf++) {
+                constexpr int HN[3] = {8, 8, 6};
+                double gq[8], xq[8];
 #pragma unroll
-            for (int c = 7; c < 14; c++) sacc += gr[c] * xk[c];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < HN[hf]; c++) { gq[c] = ldv(gr + 8 * hf + c); xq[c] = ldv(xk + 8 * hf + c); }
 #pragma unroll
-            for (int c = 0; c < 7; c++) sacc += gr[14 + c] * uk[c];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < HN[hf]; c++) sacc += gq[c] * xq[c];
+            }
         }
         return sacc;
     };
-    auto wave_total = [&](double x) -> double {                     // sum over the 64 lanes, valid in every lane
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-        return x;
+    auto w_slot = [&](unsigned d, int r) -> int {                              // slot of row r in the node-ordered w
+        return r < meq ? (int)(d & 0xFFFF) + NS * (int)((d >> 16) & 3) : (int)(d & 0xFFFF) + 14 + ((r - meq) & 7);
     };
-    double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests
+    const double inv_eq = 1.0 / rho_eq, inv_in = 1.0 / rho_in;     // (the two values 1 / rho takes; the oracle divides, both round the same way)
+    double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests (node order)
     load_rows();
-    solve(false, 0, lane_consts(tid));                // K_0 w = k (the T border)
+    solve(false, 0, tid, pk_x, pk_y);                 // K_0 w = k (the T border)
     finish_border();
 #ifdef MPCMP_STAMPS
     for (int k = 0; k < 8; k++) st_acc[k] = st_busy[k] = 0;
@@ -834,9 +984,14 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         const int cnt = cfg.qp_iters - it < cfg.check_every ? cfg.qp_iters - it : cfg.check_every;
         load_rows();
         for (int k = 0; k < cnt; k++) {
-            int sio = tid;
-            asm volatile("" : "+v"(sio));
-            const LaneC lc = lane_consts(sio);
+            // opaque copies of the lane index and of the packed words: what is derived from them stays inside the iteration
+            int sio = tid, pkx = pk_x, pky = pk_y;
+            unsigned dvo[NV], dro[NR];
+            asm volatile("" : "+v"(sio), "+v"(pkx), "+v"(pky));
+#pragma unroll
+            for (int h = 0; h < NV; h++) { dvo[h] = dv[h]; asm volatile("" : "+v"(dvo[h])); }
+#pragma unroll
+            for (int h = 0; h < NR; h++) { dro[h] = dr[h]; asm volatile("" : "+v"(dro[h])); }
             // ---- A: rhs = sigma x - q + rho_b z_b - y_b + A^T w ----
             {
                 double bp = 0.0;
@@ -845,16 +1000,16 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     const int v = sio + 512 * h;
                     if (v < na) {
                         const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
-                        const double r = (sigma * xx + (lds[L::oRb + v] * zz - yy)) + col_gather(wg, v);
-                        lds[rpos[v]] = r;
-                        bp += wvv[v] * r;
+                        const double r = (sigma * xx + (lds[L::oRb + v] * zz - yy)) + col_gather(wg, dvo[h]);
+                        lds[h ? rpos[v] : (int)((unsigned)pky >> 16)] = r;
+                        bp += wvv[dvo[h] & 0xFFFF] * r;
                     }
                 }
-                bp = wave_total(bp);
-                if (lc.lane == 0) redB[wave] = bp;
+                bp = wave_sum(bp);                             // (valid in lanes 0..15)
+                if (lane == 0) redB[wave] = bp;
             }
             QB(0); __syncthreads(); QS(0);
-            solve(true, it + 1 + k, lc);
+            solve(true, it + 1 + k, sio, pkx, pky);
             // ---- E: z~ = A x~, relaxation, projection, dual update ----
             {
                 double tp = 0.0;
@@ -864,33 +1019,33 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     if (r < ma) {
                         double &zg = h ? zg1 : zg0, &yg = h ? yg1 : yg0;
                         const double rr = lds[L::oRr + r];
-                        const double zt = row_dot(xt, r);
+                        const double zt = row_dot(xt, dro[h], r);
                         const double zr = alpha * zt + (1.0 - alpha) * zg;
-                        const double zn = clip(zr + yg * lds[L::oRri + r], lds[L::oLg + r], lds[L::oUg + r]);
+                        const double zn = clip(zr + yg * (rr == rho_eq ? inv_eq : inv_in), lds[L::oLg + r], lds[L::oUg + r]);
                         yg += rr * (zr - zn);
                         zg = zn;
                         const double w = rr * zg - yg;
-                        wg[r] = w;
+                        wg[w_slot(dro[h], r)] = w;
                         tp += lds[L::oCf + r] * w;
                     }
                 }
-                tp = wave_total(tp);
-                if (lc.lane == 0) redT[wave] = tp;            // (read by the next iteration's P1: two barriers away)
+                tp = wave_sum(tp);
+                if (lane == 0) redT[wave] = tp;               // (read by the next iteration's P1: two barriers away)
 #pragma unroll
                 for (int h = 0; h < NV; h++) {
                     const int v = sio + 512 * h;
                     if (v < na) {
                         double &xx = h ? xv1 : xv0, &zz = h ? zb1 : zb0, &yy = h ? yb1 : yb0;
-                        const double xtv = xt[v], rb = lds[L::oRb + v];
+                        const double xtv = xt[dvo[h] & 0xFFFF], rb = lds[L::oRb + v];
                         xx = alpha * xtv + (1.0 - alpha) * xx;
                         const double zr = alpha * xtv + (1.0 - alpha) * zz;
-                        const double zn = clip(zr + yy * lds[L::oRi + v], lds[L::oLb + v], lds[L::oUb + v]);
+                        const double zn = clip(zr + yy * (rb == rho_eq ? inv_eq : inv_in), lds[L::oLb + v], lds[L::oUb + v]);
                         yy += rb * (zr - zn);
                         zz = zn;
                     }
                 }
                 if (sio == 511) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
-                    const double xtv = xt[na], rb = misc[L::M_rbT];
+                    const double xtv = xt[21], rb = misc[L::M_rbT];
                     double xx = misc[L::M_xT], zz = misc[L::M_zbT], yy = misc[L::M_ybT];
                     xx = alpha * xtv + (1.0 - alpha) * xx;
                     const double zr = alpha * xtv + (1.0 - alpha) * zz;
@@ -909,10 +1064,12 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             asm volatile("" : "+v"(sio));
             // ---- termination test: r_prim = ||[A;I]x - z||inf, r_dual = ||Hx + q + [A;I]^T y||inf (oracle/ocp.c admm) ----
             double sums[2] = {0.0, 0.0};              // T row: sum coefT_r y_r, sum ha_i x_i of this arm
+            for (int i = sio; i < NX; i += 512) ys[i] = 0.0;          // (the unused slots of the node-ordered dual vector)
+            __syncthreads();
 #pragma unroll
             for (int h = 0; h < NR; h++) {
                 const int r = sio + 512 * h;
-                if (r < ma) { const double yg = h ? yg1 : yg0; ys[r] = yg; sums[0] += lds[L::oCf + r] * yg; }
+                if (r < ma) { const double yg = h ? yg1 : yg0; ys[w_slot(dr[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg; }
             }
 #pragma unroll
             for (int h = 0; h < NV; h++) {
@@ -921,18 +1078,18 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     const double xx = h ? xv1 : xv0;
                     double ha, rb, lo, hi;
                     var_h(v, ha, rb, lo, hi);
-                    xt[v] = xx; sums[1] += ha * xx;
+                    xt[dv[h] & 0xFFFF] = xx; sums[1] += ha * xx;
                 }
             }
-            if (sio == 511) xt[na] = misc[L::M_xT];
+            if (sio < N) xt[NS * sio + 21] = misc[L::M_xT];
             block_reduce<8, 2, false>(sums, redp, tid);          // (its barriers publish xt / ys)
             double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
-            const double xTc = xt[na];
+            const double xTc = xt[21];
 #pragma unroll
             for (int h = 0; h < NR; h++) {
                 const int r = sio + 512 * h;
                 if (r < ma) {
-                    const double zg = h ? zg1 : zg0, ax = row_dot(xt, r);
+                    const double zg = h ? zg1 : zg0, ax = row_dot(xt, dr[h], r);
                     mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
                 }
             }
@@ -943,7 +1100,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
                     double ha, rb, lo, hi;
                     var_h(v, ha, rb, lo, hi);
-                    const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, v) + yy;
+                    const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, dv[h]) + yy;
                     mx[0] = fmax(mx[0], fabs(xx - zz)); mx[1] = fmax(mx[1], fabs(xx)); mx[2] = fmax(mx[2], fabs(zz));
                     mx[3] = fmax(mx[3], fabs(hx + aty)); mx[4] = fmax(mx[4], fabs(hx)); mx[5] = fmax(mx[5], fabs(aty));
                 }

@@ -14,6 +14,7 @@
 // plus at most four further entries per row (dynamics rows), stored sparsely — the solve never needs E_s = G_s K_JC explicitly:
 //     t = G b_J;   r_I = b_I - K_CJ t;   y_I = S^-1 r_I;   x_J = G (b_J - K_JC y_I).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <vector>
 #include "structure.hpp"
@@ -100,10 +101,30 @@ inline bool build_tables3(int nseg, Tables3 &T) {
                 }
         }
     }
+    // canonical slot order: [base, base + 14, base - 7, base + 7] (-1: no such entry), so that the loop kernel addresses a row's
+    // C-entries from ONE lane-dependent base plus immediate offsets.  u_3s rows (lr < 7) keep their x_3s entry in the dense
+    // block: slot 0 names it as a placeholder (no term is ever assembled there, the coefficient stays 0).
+    for (int lr = 0; lr < 49; lr++) {
+        std::vector<int> v = slots[lr];
+        std::sort(v.begin(), v.end());
+        std::vector<int> canon;
+        if (v.size() == 1 && lr < 7 && v[0] >= 14) canon = {v[0] - 14, v[0]};                                           // u_3s
+        else if (v.size() == 2 && v[1] == v[0] + 14) canon = {v[0], v[1]};                                              // u_3s+1, u_3s+2
+        else if (v.size() == 3 && v[1] == v[0] + 7 && v[2] == v[0] + 14) canon = {v[0], v[2], -1, v[1]};                // positions
+        else if (v.size() == 4 && v[1] == v[0] + 7 && v[2] == v[0] + 14 && v[3] == v[0] + 21) canon = {v[1], v[3], v[0], v[2]};   // velocities
+        else return false;
+        slots[lr] = canon;
+        // the column form (kcj) of the loop kernel assumes: an entry of C-column c sits in one of the rows c % 14 + 7 d, d = -1..5
+        for (int col : canon) {
+            if (col < 0) continue;
+            const int d = lr - col % 14;
+            if (d % 7 != 0 || d < -7 || d > 35) return false;
+        }
+    }
     for (int lr = 0; lr < 49; lr++) {
         if (slots[lr].size() > 4) return false;
         uint32_t w = 0xFFFFFFFFu;
-        for (size_t q = 0; q < slots[lr].size(); q++) w = (w & ~(0xFFu << (8 * q))) | ((uint32_t)slots[lr][q] << (8 * q));
+        for (size_t q = 0; q < slots[lr].size(); q++) if (slots[lr][q] >= 0) w = (w & ~(0xFFu << (8 * q))) | ((uint32_t)slots[lr][q] << (8 * q));
         T.pat.jc[lr] = w;
     }
     for (int c = 0; c < 28; c++) {
