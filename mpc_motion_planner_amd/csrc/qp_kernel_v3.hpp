@@ -56,7 +56,8 @@ struct Qp3 {
     static constexpr int NX = NS * D::N, NXP = (NX + 2 + 1) / 2 * 2; // (slot NX: pad for lanes without a job)
     static constexpr int JS = 52;                                   // stride of one segment's part of rhs (49 + zero pad: 4 x 13 column groups)
     static constexpr int SC = (D::nI + 15) / 16;                    // columns of S^-1 per lane (16 lanes per group of four rows)
-    static constexpr int RIW = 16 * SC;                             // padded length of r_I
+    static constexpr int RIW = 128;                                 // padded length of r_I (>= 16 SC, two passes of a wave)
+    static_assert(16 * SC <= RIW && D::nI <= RIW, "r_I padding");
     static constexpr int NAP = (D::na + 2 + 1) / 2 * 2;             // na + T slot, even
     static constexpr int MAP = (D::ma + 1) / 2 * 2;
     static constexpr int NB = NSEG + 1;                             // blocks of the interior sweep (segments + padded K_UU)
@@ -101,20 +102,24 @@ struct Qp3 {
     static constexpr int oRpos = oCf + MAP;                         // [na] ints: LDS slot of the variable's rhs entry
     static constexpr int oRhsJ = oRpos + e2((D::na + 1) / 2);       // [NSEG][JS]
     static constexpr int oRhsU = oRhsJ + NSEG * JS;                 // [JS] (7 used, rest zero)
-    static constexpr int oRhsI = oRhsU + JS;                        // [nI]
+    static constexpr int oRhsI = oRhsU + JS;                        // [RIW] (zero beyond nI)
     static constexpr int TS = 64;                                   // wave-private vector of a G wave: [0..51] operand / result, [56] dummy
-    static constexpr int oTJ = oRhsI + e2(D::nI);                   // [8][TS], then the U block of the last segment's wave [TS]
+    static constexpr int oTJ = oRhsI + RIW;                   // [8][TS], then the U block of the last segment's wave [TS]
     static constexpr int oTU = oTJ + 8 * TS;
     static constexpr int oDW = oTU + TS;                            // [8][16] wave-private: dense parts of the rows u_3s ([0..6]) and of the U block ([7..13])
-    static constexpr int oDP = oDW + 128;                           // [NSEG][14] dense part of K_CJ t (columns x_3s), + pad slot
-    static constexpr int oPart = oDP + e2(NSEG * 14 + 2);           // [NSEG][28] sparse part of K_CJ t per segment, [14] of the U block
-    static constexpr int oRIw = oPart + e2(NSEG * 28 + 16);         // [8][RIW] wave-private r_I; y (duals) at checks
+    // K_CJ t, indexed like r_I (interface entry i = 14 node + component), so that r_I = b_I - PA - PB - DP is straight-line code:
+    static constexpr int oPA = oDW + 128;                           // [RIW] sparse part from the segment the node opens (x_3s); node NSEG: the U block
+    static constexpr int oPB = oPA + RIW;                           // [RIW] sparse part from the segment the node closes (x_3s+3)
+    static constexpr int oDP = oPB + RIW;                           // [RIW] dense part (columns x_3s)
+    static constexpr int oPD = oDP + RIW;                           // [2] pad slot for lanes without an entry
+    static constexpr int oRIw = oPD + 2;                            // [8][RIW] wave-private r_I; y (duals) at checks
     static constexpr int oYI = oRIw + cmax(8 * RIW, NXP);           // [nI] + pad slot
     static constexpr int oXt = oYI + e2(D::nI + 2);                 // [NXP] x~ in node order
     static constexpr int oWg = oXt + NXP;                           // [NXP] w = rho z - y in node order
     static constexpr int oRedB = oWg + NXP;                         // [8] per-wave partial sums of w^T rhs
     static constexpr int oRedT = oRedB + 8;                         // [8] per-wave partial sums of the T column of A^T w
-    static constexpr int lEnd = oRedT + 8;
+    static constexpr int oS1 = oRedT + 8;                           // [5][32] ADMM state of the second variable / row of the lanes that own two (N = 25)
+    static constexpr int lEnd = oS1 + 160;
     static constexpr int sizeF = fEnd, sizeL = lEnd;
     static_assert(sizeF * 8 <= 160 * 1024 - 512 && sizeL * 8 <= 160 * 1024 - 512, "LDS budget");
     // factor workspace (doubles per arm): the sparse K_JC [KJN], the T column [NAP], sum|ha| [8], the derived copies [DER], then
@@ -157,7 +162,11 @@ __device__ __forceinline__ double g_dot(const double (&m)[49], const double *op)
 #ifdef MPCMP_STAMPS
 #define QS(k) do { const unsigned long long n_ = clock64(); st_acc[k] += n_ - st_t; st_t = n_; } while (0)
 #define QB(k) do { st_busy[k] += clock64() - st_t; } while (0)
+#define QM(k) do { const unsigned long long n_ = clock64(); st_busy[k] += n_ - st_m; st_m = n_; } while (0)     /* sub-phase marks */
+#define QM0() do { st_m = clock64(); } while (0)
 #else
+#define QM(k) do { } while (0)
+#define QM0() do { } while (0)
 #define QS(k) do { } while (0)
 #define QB(k) do { } while (0)
 #endif
@@ -176,13 +185,26 @@ __device__ __forceinline__ v2d ldv2(const double *p) { return *(vlds2_t)p; }    
 // 4 x 13 block of rows 4g + (m ^ pos), pos = 0..3, and columns 13m .. 13m + 12, reads only ITS 13 operand entries (a row per
 // lane needs all 49 through LDS broadcasts), and a reduce-scatter over the quad (three DPP exchanges; the row order m ^ pos makes
 // them select-free) leaves row 4g + m in lane 4g + m.
+template <bool TWO_BATCHES = false>
 __device__ __forceinline__ double g_blk(const double (&m)[52], const double *op) {
-    double o[13];
-#pragma unroll
-    for (int j = 0; j < 13; j++) o[j] = ldv(op + j);
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    if (!TWO_BATCHES) {
+        double o[13];
 #pragma unroll
-    for (int j = 0; j < 13; j++) { p0 += m[j] * o[j]; p1 += m[13 + j] * o[j]; p2 += m[26 + j] * o[j]; p3 += m[39 + j] * o[j]; }
+        for (int j = 0; j < 13; j++) o[j] = ldv(op + j);
+#pragma unroll
+        for (int j = 0; j < 13; j++) { p0 += m[j] * o[j]; p1 += m[13 + j] * o[j]; p2 += m[26 + j] * o[j]; p3 += m[39 + j] * o[j]; }
+    } else {                                        // (N = 25: every register counts)
+        double o[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) o[j] = ldv(op + j);
+#pragma unroll
+        for (int j = 0; j < 7; j++) { p0 += m[j] * o[j]; p1 += m[13 + j] * o[j]; p2 += m[26 + j] * o[j]; p3 += m[39 + j] * o[j]; }
+#pragma unroll
+        for (int j = 0; j < 6; j++) o[j] = ldv(op + 7 + j);
+#pragma unroll
+        for (int j = 0; j < 6; j++) { p0 += m[7 + j] * o[j]; p1 += m[20 + j] * o[j]; p2 += m[33 + j] * o[j]; p3 += m[46 + j] * o[j]; }
+    }
     const double q0 = p0 + dpp_mov<0x4E>(p2), q1 = p1 + dpp_mov<0x4E>(p3);          // lanes m, m ^ 2
     return q0 + dpp_mov<0xB1>(q1);                                                  // lanes m, m ^ 1
 }
@@ -593,8 +615,9 @@ template <int NSEG, int NARM>
 __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, const double *__restrict__ fac) {
     QP3_PROLOGUE(512, false)
     constexpr int NS = L::NS, NX = L::NX;
+    constexpr bool SMALL = NSEG >= 8;                // N = 25: smaller batches of LDS reads in flight (register budget)
 #ifdef MPCMP_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_busy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_busy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64(), st_m = 0;
 #endif
     // ---------------- the factor, as the factorisation kernel left it ----------------
     const double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
@@ -609,7 +632,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     auto node_slot = [&](int v) -> int {            // external arm variable -> slot in the node-ordered vectors
         return v < 14 * N ? NS * (v / 14) + v % 14 : NS * ((v - 14 * N) / 7) + 14 + (v - 14 * N) % 7;
     };
-    double *rhsI = lds + L::oRhsI, *part = lds + L::oPart, *partU = lds + L::oPart + NSEG * 28, *xt = lds + L::oXt,
+    double *xt = lds + L::oXt,
            *wg = lds + L::oWg, *wvv = lds + L::oWv, *redB = lds + L::oRedB, *redT = lds + L::oRedT;
     {
         // where the G lanes' entries of x~ go
@@ -619,7 +642,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         if (wv == NSEG - 1 && ln >= 56 && ln < 63) xd = node_slot(ws.ext_of_int[nJ + (ln - 56)]);
         xdgt[tid] = xd;
         // loop-resident constants and the rhs of K_0 w = k
-        for (int i = tid; i < L::oRedT + 8 - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;        // vectors, pads, partial sums
+        for (int i = tid; i < L::lEnd - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;              // vectors, pads, partial sums, second-pass state
         for (int i = tid; i < L::NXP; i += NT) lds[L::oWv + i] = 0.0;
         __syncthreads();
         for (int v = tid; v < na; v += NT) {
@@ -730,7 +753,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     }
     struct LaneC1 {
         int tslot, op1;               // tJ slot of the own row; operand block of G b_J
-        int kcj, tcc, partd;          // column form of K_JC, tJ + c % 14, destination in part
+        int kcj, tcc, partd;          // column form of K_JC, tJ + c % 14, destination in PA / PB
         int p1k, p1t, p1d;            // dense blocks, two lanes per column (half a column of K_XU each): coefficients, operand, destination
     };
     struct LaneC3 { int rop, ysl; };  // operand of the S^-1 block, y_I slot
@@ -752,12 +775,12 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         const int cl = ln < 28 ? ln : 27;
         c.kcj = L::oKCJ + (wg_ * 28 + cl) * 8;
         c.tcc = tJ + (cl < 14 ? cl : cl - 14);
-        c.partd = L::oPart + (ln < 28 ? wg_ * 28 + cl : NSEG * 28 + 14);     // (dummy slot behind partU)
+        c.partd = ln < 14 ? L::oPA + 14 * wg_ + ln : (ln < 28 ? L::oPB + 14 * wg_ + ln : L::oPD);      // (others: pad slot)
         const int c2 = ln >> 1, j = ln & 1;
         const bool lastw = wv == NSEG - 1, useg = c2 < 14, uU = lastw && c2 >= 14 && c2 < 28;
         c.p1k = useg ? L::oKUXT + (wg_ * 14 + c2) * 8 + 4 * j : (uU ? L::oKUXT + (NSEG * 14 + c2 - 14) * 8 + 4 * j : L::oZR);
         c.p1t = (uU ? L::oTU : tJ) + 4 * j;
-        c.p1d = j ? L::oDP + NSEG * 14 : (useg ? L::oDP + wg_ * 14 + c2 : (uU ? L::oPart + NSEG * 28 + c2 - 14 : L::oDP + NSEG * 14));
+        c.p1d = j ? L::oPD : (useg ? L::oDP + wg_ * 14 + c2 : (uU ? L::oPA + NSEG * 14 + c2 - 14 : L::oPD));
         return c;
     };
     auto lane_c3 = [&](int t) -> LaneC3 {
@@ -807,7 +830,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         // ---- P1: t = G b_J, part = K_CJ t; this arm's share of the T solve, s_a = (T column of A^T w) - w^T rhs ----
         if (wv < NSEG) {
             const LaneC1 c = lane_c1(tl);
-            lds[c.tslot] = g_blk(mm, lds + c.op1);
+            lds[c.tslot] = g_blk<SMALL>(mm, lds + c.op1);
             wave_sync();
             const double *kc = lds + c.kcj, *tc = lds + c.tcc;
             double kq[7], tv[7], dk[4], dt[4];
@@ -815,13 +838,10 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             for (int d = 0; d < 7; d++) { kq[d] = ldv(kc + d); tv[d] = ldv(tc + 7 * (d - 1)); }      // rows c % 14 + 7 (d - 1) of the segment
 #pragma unroll
             for (int d = 0; d < 4; d++) { dk[d] = ldv(lds + c.p1k + d); dt[d] = ldv(lds + c.p1t + d); }
-            double acc = 0.0;
-#pragma unroll
-            for (int d = 0; d < 7; d++) acc += kq[d] * tv[d];
+            const double acc = ((kq[0] * tv[0] + kq[1] * tv[1]) + (kq[2] * tv[2] + kq[3] * tv[3])) + ((kq[4] * tv[4] + kq[5] * tv[5]) + kq[6] * tv[6]);
             lds[c.partd] = acc;
             // dense blocks (K_XU t of the columns x_3s; for the last segment also the U block): half a column per lane
-            double ad = dk[0] * dt[0];
-            ad += dk[1] * dt[1]; ad += dk[2] * dt[2]; ad += dk[3] * dt[3];
+            const double ad = (dk[0] * dt[0] + dk[1] * dt[1]) + (dk[2] * dt[2] + dk[3] * dt[3]);
             lds[c.p1d] = ad + dpp_mov<0xB1>(ad);                                   // (odd lanes, lanes without a column: pad slot)
         }
         if (use_xT && tid == 511) {
@@ -836,54 +856,55 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         // ---- P3: r_I = b_I - part (every wave its own copy), y_I = S^-1 r_I ----
         double yi;
         {
+            QM0();
             double *rIw = lds + L::oRIw + wv * L::RIW;
-            for (int i = lane; i < L::RIW; i += 64) {
-                double r = 0.0;
-                if (i < nI) {
-                    const int sN = i / 14, cc = i % 14;
-                    r = rhsI[i];
-                    if (sN > 0) r -= part[(sN - 1) * 28 + 14 + cc];
-                    if (sN < NSEG) r -= part[sN * 28 + cc] + lds[L::oDP + sN * 14 + cc];
-                    else r -= partU[cc];
+            {
+                int l8 = lane;
+                asm volatile("" : "+v"(l8));
+                const double *src = lds + L::oRhsI + l8;
+                double rv[8];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    rv[4 * u] = ldv(src + 64 * u); rv[4 * u + 1] = ldv(src + (L::oPA - L::oRhsI) + 64 * u);
+                    rv[4 * u + 2] = ldv(src + (L::oPB - L::oRhsI) + 64 * u); rv[4 * u + 3] = ldv(src + (L::oDP - L::oRhsI) + 64 * u);
                 }
-                rIw[i] = r;
+                rIw[l8] = ((rv[0] - rv[1]) - rv[2]) - rv[3];
+                rIw[l8 + 64] = ((rv[4] - rv[5]) - rv[6]) - rv[7];
             }
             wave_sync();
+            QM(5);
             const LaneC3 c = lane_c3(tl);
             yi = s_blk<SC>(sm, lds + c.rop);
+            QM(6);
             lds[c.ysl] = yi;                                                   // (lanes without an output row: pad slot nI + 1)
         }
         QB(2); __syncthreads(); QS(2);
         // ---- P4: x_J = G (b_J - K_JC y_I); x~ = y - w x~_T ----
         {
-            const double xT = use_xT ? border_xT(it, lane) : 0.0;
+            // (every LDS read that does not depend on this phase's own writes is issued first: one round trip, not five)
             const LaneC4 c = lane_c4(tl, px, py);
             constexpr int dW = L::oWv - L::oXt;                                // w lives at a fixed distance from x~
-            lds[c.xds] = yi - lds[c.xds + dW] * xT;                            // interface rows (others: the pad slot)
+            const double wds = ldv(lds + c.xds + dW), wdg = ldv(lds + c.xdg + dW);
+            double dk[4], dy[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) { dk[d] = ldv(lds + c.p4k + d); dy[d] = ldv(lds + c.p4y + d); }
+            const double *kr = lds + c.kjr, *yc = lds + c.ycb;
+            const double k0 = ldv(kr), k1 = ldv(kr + 1), k2 = ldv(kr + 2), k3 = ldv(kr + 3);
+            const double y0 = ldv(yc), y1 = ldv(yc + 14), y2 = ldv(yc - 7), y3 = ldv(yc + 7);
+            double cr = ldv(lds + c.bjr);
+            const double xT = use_xT ? border_xT(it, lane) : 0.0;
+            lds[c.xds] = yi - wds * xT;                                        // interface rows (others: the pad slot)
             if (tid < N) xt[NS * tid + 21] = xT;                               // x~_T, once per node: the 22nd operand of the path rows
             if (wv < NSEG) {
                 // dense blocks (rows u_3s x x_3s; for the last segment also the U block x x_{N-1}): a quarter row per lane
-                {
-                    double dk[4], dy[4];
-#pragma unroll
-                    for (int d = 0; d < 4; d++) { dk[d] = ldv(lds + c.p4k + d); dy[d] = ldv(lds + c.p4y + d); }
-                    double ad = dk[0] * dy[0];
-                    ad += dk[1] * dy[1]; ad += dk[2] * dy[2]; ad += dk[3] * dy[3];
-                    lds[c.p4d] = sum4(ad);                                     // (lanes 1..3 of a quad, lanes without a row: pad slot)
-                }
-                const double *kr = lds + c.kjr, *yc = lds + c.ycb;
-                const double k0 = ldv(kr), k1 = ldv(kr + 1), k2 = ldv(kr + 2), k3 = ldv(kr + 3);
-                const double y0 = ldv(yc), y1 = ldv(yc + 14), y2 = ldv(yc - 7), y3 = ldv(yc + 7);
-                double cr = ldv(lds + c.bjr);
-                cr -= k0 * y0;
-                cr -= k1 * y1;
-                cr -= k2 * y2;
-                cr -= k3 * y3;
+                const double ad = (dk[0] * dy[0] + dk[1] * dy[1]) + (dk[2] * dy[2] + dk[3] * dy[3]);
+                lds[c.p4d] = sum4(ad);                                         // (lanes 1..3 of a quad, lanes without a row: pad slot)
+                cr -= (k0 * y0 + k1 * y1) + (k2 * y2 + k3 * y3);
                 wave_sync();
                 lds[c.tslot] = cr - ldv(lds + c.p4r);
                 wave_sync();
-                const double xj = g_blk(mm, lds + c.op4);
-                lds[c.xdg] = xj - lds[c.xdg + dW] * xT;                        // (lanes without a row: the pad slot)
+                const double xj = g_blk<SMALL>(mm, lds + c.op4);
+                lds[c.xdg] = xj - wdg * xT;                                    // (lanes without a row: the pad slot)
             }
         }
         QB(3); __syncthreads(); QS(3);
@@ -893,7 +914,13 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // (5) | the same for the previous segment (5) | has a -ts T term (1); one per row: first operand slot (16) | i = k % 3 (2).
     constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
     static_assert(NV <= 2 && NR <= 2, "two variables and two rows per lane at most");
-    double xv0 = 0, zb0 = 0, yb0 = 0, xv1 = 0, zb1 = 0, yb1 = 0, zg0 = 0, yg0 = 0, zg1 = 0, yg1 = 0;
+    // Rows in lane order: the 8 N path rows first (44 LDS reads each), then the dynamics rows (7 reads): the few lanes that own a
+    // second row (N = 25: 24 of them) get a cheap one.  The state of a lane's second variable / row lives in LDS (the 10 registers
+    // it would take in EVERY lane are needed elsewhere).
+    auto row_of = [&](int q) -> int { return q < 8 * N ? meq + q : q - 8 * N; };
+    double xv0 = 0, zb0 = 0, yb0 = 0, zg0 = 0, yg0 = 0;
+    double *s1x = lds + L::oS1, *s1z = s1x + 32, *s1y = s1x + 64, *s1zg = s1x + 96, *s1yg = s1x + 128;
+    static_assert(na - 512 <= 32 && ma - 512 <= 32, "second-pass state");
     unsigned dv[NV], dr[NR];
 #pragma unroll
     for (int h = 0; h < NV; h++) {
@@ -910,7 +937,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     }
 #pragma unroll
     for (int h = 0; h < NR; h++) {
-        const int r = tid + 512 * h;
+        const int r = tid + 512 * h < ma ? row_of(tid + 512 * h) : ma;
         unsigned d = 0;
         if (r < meq) { const int k = r / 14, rr = r % 14; d = (unsigned)(NS * 3 * (k / 3) + rr) | ((unsigned)(k % 3) << 16); }
         else if (r < ma) d = (unsigned)(NS * ((r - meq) >> 3));
@@ -928,18 +955,20 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         const double a0 = ldv(ca), a1 = ldv(ca + 4), a2 = ldv(ca + 8), u0 = ldv(wa), u1 = ldv(wa + NS), u2 = ldv(wa + 2 * NS);
         const double b0 = ldv(cb), b1 = ldv(cb + 4), b2 = ldv(cb + 8), v0 = ldv(wb), v1 = ldv(wb + NS), v2 = ldv(wb + 2 * NS);
         const double wtv = ldv(wt);
-        double sacc = a0 * u0 + a1 * u1 + a2 * u2;
-        sacc += b0 * v0 + b1 * v1 + b2 * v2;
-        sacc += ct * wtv;
-        double g8[8], w8[8];
+        double sacc = ((a0 * u0 + a1 * u1) + (a2 * u2 + ct * wtv)) + ((b0 * v0 + b1 * v1) + b2 * v2);
+        constexpr int QB_ = SMALL ? 4 : 8;
 #pragma unroll
-        for (int q = 0; q < 8; q++) { g8[q] = ldv(gc + q * GS); w8[q] = ldv(wp + q); }
+        for (int q0 = 0; q0 < 8; q0 += QB_) {
+            double g8[QB_], w8[QB_];
 #pragma unroll
-        for (int q = 0; q < 8; q++) sacc += g8[q] * w8[q];
+            for (int q = 0; q < QB_; q++) { g8[q] = ldv(gc + (q0 + q) * GS); w8[q] = ldv(wp + q0 + q); }
+#pragma unroll
+            for (int q = 0; q < QB_; q++) sacc += g8[q] * w8[q];
+        }
         return sacc;
     };
     // (A x)[r]; x in node order (slot 21 of every node: x_T)
-    auto row_dot = [&](const double *xe, unsigned d, int r) -> double {
+    auto row_dot = [&](const double *xe, unsigned d, int r, double cf) -> double {
         double sacc;
         const int a0 = d & 0xFFFF;
         if (r < meq) {
@@ -947,20 +976,20 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             const double *x0 = xe + a0, *cr = cD + 4 * i;
             const double c0 = ldv(cr), c1 = ldv(cr + 1), c2 = ldv(cr + 2), c3 = ldv(cr + 3);
             const double x_0 = ldv(x0), x_1 = ldv(x0 + NS), x_2 = ldv(x0 + 2 * NS), x_3 = ldv(x0 + 3 * NS), xf_ = ldv(x0 + NS * i + 7);
-            const double cf = ldv(lds + L::oCf + r), xT_ = ldv(xe + 21);
-            sacc = c0 * x_0 + c1 * x_1 + c2 * x_2 + c3 * x_3 - tsT * xf_ + cf * xT_;
+            const double xT_ = ldv(xe + 21);
+            sacc = ((c0 * x_0 + c1 * x_1) + (c2 * x_2 + c3 * x_3)) + (cf * xT_ - tsT * xf_);
         } else {
             const double *gr = gkl + (r - meq) * GS, *xk = xe + a0;
             sacc = 0.0;
-            // (three parts: all 22 operand pairs in flight at once would take 88 registers)
+            // (in parts: all 22 operand pairs in flight at once would take 88 registers)
+            constexpr int RB_ = SMALL ? 4 : 8;
 #pragma unroll
-            for (int hf = 0; hf < 3; hf++) {
-                constexpr int HN[3] = {8, 8, 6};
-                double gq[8], xq[8];
+            for (int c0 = 0; c0 < 22; c0 += RB_) {
+                double gq[RB_], xq[RB_];
 #pragma unroll
-                for (int c = 0; c < HN[hf]; c++) { gq[c] = ldv(gr + 8 * hf + c); xq[c] = ldv(xk + 8 * hf + c); }
+                for (int c = 0; c < RB_; c++) if (c0 + c < 22) { gq[c] = ldv(gr + c0 + c); xq[c] = ldv(xk + c0 + c); }
 #pragma unroll
-                for (int c = 0; c < HN[hf]; c++) sacc += gq[c] * xq[c];
+                for (int c = 0; c < RB_; c++) if (c0 + c < 22) sacc += gq[c] * xq[c];
             }
         }
         return sacc;
@@ -999,10 +1028,11 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 for (int h = 0; h < NV; h++) {
                     const int v = sio + 512 * h;
                     if (v < na) {
-                        const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
-                        const double r = (sigma * xx + (lds[L::oRb + v] * zz - yy)) + col_gather(wg, dvo[h]);
+                        const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : zb0, yy = h ? s1y[sio] : yb0;
+                        const double rbv = ldv(lds + L::oRb + v), wv_ = ldv(wvv + (dvo[h] & 0xFFFF));     // (issued with the gather's reads)
+                        const double r = (sigma * xx + (rbv * zz - yy)) + col_gather(wg, dvo[h]);
                         lds[h ? rpos[v] : (int)((unsigned)pky >> 16)] = r;
-                        bp += wvv[dvo[h] & 0xFFFF] * r;
+                        bp += wv_ * r;
                     }
                 }
                 bp = wave_sum(bp);                             // (valid in lanes 0..15)
@@ -1013,37 +1043,56 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             // ---- E: z~ = A x~, relaxation, projection, dual update ----
             {
                 double tp = 0.0;
-#pragma unroll
-                for (int h = 0; h < NR; h++) {
-                    const int r = sio + 512 * h;
-                    if (r < ma) {
-                        double &zg = h ? zg1 : zg0, &yg = h ? yg1 : yg0;
-                        const double rr = lds[L::oRr + r];
-                        const double zt = row_dot(xt, dro[h], r);
-                        const double zr = alpha * zt + (1.0 - alpha) * zg;
-                        const double zn = clip(zr + yg * (rr == rho_eq ? inv_eq : inv_in), lds[L::oLg + r], lds[L::oUg + r]);
-                        yg += rr * (zr - zn);
-                        zg = zn;
-                        const double w = rr * zg - yg;
-                        wg[w_slot(dro[h], r)] = w;
-                        tp += lds[L::oCf + r] * w;
+                {   // first row and first variable of the lane: every constant it needs is read up front (lanes without one read
+                    // valid neighbouring words)
+                    const int r = sio < ma ? row_of(sio) : 0;
+                    const double rr = ldv(lds + L::oRr + r), lg = ldv(lds + L::oLg + r), ug = ldv(lds + L::oUg + r), cf = ldv(lds + L::oCf + r);
+                    const double xtv = ldv(xt + (dvo[0] & 0xFFFF)), rb = ldv(lds + L::oRb + sio), lb = ldv(lds + L::oLb + sio), ub = ldv(lds + L::oUb + sio);
+                    if (sio < ma) {
+                        const double zt = row_dot(xt, dro[0], r, cf);
+                        const double zr = alpha * zt + (1.0 - alpha) * zg0;
+                        const double zn = clip(zr + yg0 * (rr == rho_eq ? inv_eq : inv_in), lg, ug);
+                        yg0 += rr * (zr - zn);
+                        zg0 = zn;
+                        const double w = rr * zg0 - yg0;
+                        wg[w_slot(dro[0], r)] = w;
+                        tp += cf * w;
                     }
+                    if (sio < na) {
+                        xv0 = alpha * xtv + (1.0 - alpha) * xv0;
+                        const double zr = alpha * xtv + (1.0 - alpha) * zb0;
+                        const double zn = clip(zr + yb0 * (rb == rho_eq ? inv_eq : inv_in), lb, ub);
+                        yb0 += rb * (zr - zn);
+                        zb0 = zn;
+                    }
+                }
+                if (NR == 2 && sio + 512 < ma) {              // second row (N = 25: 24 lanes), state in LDS
+                    const int r = row_of(sio + 512);
+                    double zg = s1zg[sio], yg = s1yg[sio];
+                    const double rr = lds[L::oRr + r], cf = lds[L::oCf + r];
+                    const double zt = row_dot(xt, dro[NR - 1], r, cf);
+                    const double zr = alpha * zt + (1.0 - alpha) * zg;
+                    const double zn = clip(zr + yg * (rr == rho_eq ? inv_eq : inv_in), lds[L::oLg + r], lds[L::oUg + r]);
+                    yg += rr * (zr - zn);
+                    zg = zn;
+                    s1zg[sio] = zg; s1yg[sio] = yg;
+                    const double w = rr * zg - yg;
+                    wg[w_slot(dro[NR - 1], r)] = w;
+                    tp += cf * w;
+                }
+                if (NV == 2 && sio + 512 < na) {              // second variable (N = 25: 13 lanes)
+                    const int v = sio + 512;
+                    double xx = s1x[sio], zz = s1z[sio], yy = s1y[sio];
+                    const double xtv = xt[dvo[NV - 1] & 0xFFFF], rb = lds[L::oRb + v];
+                    xx = alpha * xtv + (1.0 - alpha) * xx;
+                    const double zr = alpha * xtv + (1.0 - alpha) * zz;
+                    const double zn = clip(zr + yy * (rb == rho_eq ? inv_eq : inv_in), lds[L::oLb + v], lds[L::oUb + v]);
+                    yy += rb * (zr - zn);
+                    zz = zn;
+                    s1x[sio] = xx; s1z[sio] = zz; s1y[sio] = yy;
                 }
                 tp = wave_sum(tp);
                 if (lane == 0) redT[wave] = tp;               // (read by the next iteration's P1: two barriers away)
-#pragma unroll
-                for (int h = 0; h < NV; h++) {
-                    const int v = sio + 512 * h;
-                    if (v < na) {
-                        double &xx = h ? xv1 : xv0, &zz = h ? zb1 : zb0, &yy = h ? yb1 : yb0;
-                        const double xtv = xt[dvo[h] & 0xFFFF], rb = lds[L::oRb + v];
-                        xx = alpha * xtv + (1.0 - alpha) * xx;
-                        const double zr = alpha * xtv + (1.0 - alpha) * zz;
-                        const double zn = clip(zr + yy * (rb == rho_eq ? inv_eq : inv_in), lds[L::oLb + v], lds[L::oUb + v]);
-                        yy += rb * (zr - zn);
-                        zz = zn;
-                    }
-                }
                 if (sio == 511) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
                     const double xtv = xt[21], rb = misc[L::M_rbT];
                     double xx = misc[L::M_xT], zz = misc[L::M_zbT], yy = misc[L::M_ybT];
@@ -1068,14 +1117,16 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             __syncthreads();
 #pragma unroll
             for (int h = 0; h < NR; h++) {
-                const int r = sio + 512 * h;
-                if (r < ma) { const double yg = h ? yg1 : yg0; ys[w_slot(dr[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg; }
+                if (sio + 512 * h < ma) {
+                    const int r = row_of(sio + 512 * h);
+                    const double yg = h ? s1yg[sio] : yg0; ys[w_slot(dr[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg;
+                }
             }
 #pragma unroll
             for (int h = 0; h < NV; h++) {
                 const int v = sio + 512 * h;
                 if (v < na) {
-                    const double xx = h ? xv1 : xv0;
+                    const double xx = h ? s1x[sio] : xv0;
                     double ha, rb, lo, hi;
                     var_h(v, ha, rb, lo, hi);
                     xt[dv[h] & 0xFFFF] = xx; sums[1] += ha * xx;
@@ -1087,9 +1138,9 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             const double xTc = xt[21];
 #pragma unroll
             for (int h = 0; h < NR; h++) {
-                const int r = sio + 512 * h;
-                if (r < ma) {
-                    const double zg = h ? zg1 : zg0, ax = row_dot(xt, dr[h], r);
+                if (sio + 512 * h < ma) {
+                    const int r = row_of(sio + 512 * h);
+                    const double zg = h ? s1zg[sio] : zg0, ax = row_dot(xt, dr[h], r, lds[L::oCf + r]);
                     mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
                 }
             }
@@ -1097,7 +1148,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             for (int h = 0; h < NV; h++) {
                 const int v = sio + 512 * h;
                 if (v < na) {
-                    const double xx = h ? xv1 : xv0, zz = h ? zb1 : zb0, yy = h ? yb1 : yb0;
+                    const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : zb0, yy = h ? s1y[sio] : yb0;
                     double ha, rb, lo, hi;
                     var_h(v, ha, rb, lo, hi);
                     const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, dv[h]) + yy;
@@ -1114,14 +1165,13 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     for (int h = 0; h < NV; h++) {
         const int v = tid + 512 * h;
         if (v < na) {
-            ws.p[(size_t)b * n_tot + arm * na + v] = h ? xv1 : xv0;
-            ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? yb1 : yb0;
+            ws.p[(size_t)b * n_tot + arm * na + v] = h ? s1x[tid] : xv0;
+            ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? s1y[tid] : yb0;
         }
     }
 #pragma unroll
     for (int h = 0; h < NR; h++) {
-        const int r = tid + 512 * h;
-        if (r < ma) ws.y[(size_t)b * mn_tot + arm * ma + r] = h ? yg1 : yg0;
+        if (tid + 512 * h < ma) ws.y[(size_t)b * mn_tot + arm * ma + row_of(tid + 512 * h)] = h ? s1yg[tid] : yg0;
     }
     if (tid == 511 && arm == 0) {
         ws.p[(size_t)b * n_tot + NARM * na] = misc[L::M_xT];

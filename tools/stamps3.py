@@ -48,4 +48,4 @@ print("%-52s %9.1f cycles / iteration" % ("loop total", (st[:, 0:6].sum(axis=1) 
 busy = st[:, 16:144].reshape(B, 16, 8)
 print("per-wave busy cycles / iteration in phases A, P1, P3, P4, E (waves 0-7: G role, 8-15: S role)")
 for w in range(16):
-    print("  wave %2d  " % w + "  ".join("%8.1f" % (busy[:, w, ph] / its).mean() for ph in range(5)))
+    print("  wave %2d  " % w + "  ".join("%8.1f" % (busy[:, w, ph] / its).mean() for ph in range(5)) + "   | P3 parts: r_I build %7.1f  S^-1 block %7.1f" % ((busy[:, w, 5] / its).mean(), (busy[:, w, 6] / its).mean()))
