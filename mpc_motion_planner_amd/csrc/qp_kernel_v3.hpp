@@ -119,7 +119,10 @@ struct Qp3 {
     static constexpr int oRedB = oWg + NXP;                         // [8] per-wave partial sums of w^T rhs
     static constexpr int oRedT = oRedB + 8;                         // [8] per-wave partial sums of the T column of A^T w
     static constexpr int oS1 = oRedT + 8;                           // [5][32] ADMM state of the second variable / row of the lanes that own two (N = 25)
-    static constexpr int lEnd = oS1 + 160;
+    static constexpr bool LCT = NSEG < 8;                           // lane-constant table (N = 25 has no LDS left for it)
+    static constexpr int NLC = 21;                                  // fields of LaneC1 + LaneC3 + LaneC4
+    static constexpr int oLCT = oS1 + 160;                          // [NLC][512] 16-bit words
+    static constexpr int lEnd = oLCT + (LCT ? NLC * 128 : 0);
     static constexpr int sizeF = fEnd, sizeL = lEnd;
     static_assert(sizeF * 8 <= 160 * 1024 - 512 && sizeL * 8 <= 160 * 1024 - 512, "LDS budget");
     // factor workspace (doubles per arm): the sparse K_JC [KJN], the T column [NAP], sum|ha| [8], the derived copies [DER], then
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         if (wv == NSEG - 1 && ln >= 56 && ln < 63) xd = node_slot(ws.ext_of_int[nJ + (ln - 56)]);
         xdgt[tid] = xd;
         // loop-resident constants and the rhs of K_0 w = k
-        for (int i = tid; i < L::lEnd - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;              // vectors, pads, partial sums, second-pass state
+        for (int i = tid; i < L::oLCT - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;              // vectors, pads, partial sums, second-pass state
         for (int i = tid; i < L::NXP; i += NT) lds[L::oWv + i] = 0.0;
         __syncthreads();
         for (int v = tid; v < na; v += NT) {
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         int p4k, p4y, p4d, p4r;       // dense blocks, four lanes per row (a quarter row of K_UX each); where the own row finds its dense part
     };
     // (each set is derived right in front of its phase from a fresh opaque copy of the lane index: short live ranges)
-    auto lane_c1 = [&](int t) -> LaneC1 {
+    auto calc_c1 = [&](int t) -> LaneC1 {
         asm volatile("" : "+v"(t));
         LaneC1 c;
         const int ln = t & 63, wv = wave, wg_ = wv < NSEG ? wv : 0;          // (waves without a segment: valid addresses, results unused)
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         c.p1d = j ? L::oPD : (useg ? L::oDP + wg_ * 14 + c2 : (uU ? L::oPA + NSEG * 14 + c2 - 14 : L::oPD));
         return c;
     };
-    auto lane_c3 = [&](int t) -> LaneC3 {
+    auto calc_c3 = [&](int t) -> LaneC3 {
         asm volatile("" : "+v"(t));
         LaneC3 c;
         const int srow = 4 * (t >> 4) + (t & 3);
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         c.ysl = L::oYI + (((t & 15) < 4 && srow < nI) ? srow : nI + 1);      // (lanes without an output row: pad slot)
         return c;
     };
-    auto lane_c4 = [&](int t, int px, int py) -> LaneC4 {
+    auto calc_c4 = [&](int t, int px, int py) -> LaneC4 {
         asm volatile("" : "+v"(t), "+v"(px), "+v"(py));
         LaneC4 c;
         const int ln = t & 63, wv = wave, wg_ = wv < NSEG ? wv : 0;
@@ -812,6 +815,40 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         c.p4r = ln < 7 ? L::oDW + wv * 16 + ln : (gu_row ? L::oDW + wv * 16 + 7 + lr : L::oZR);
         return c;
     };
+    // N = 19: the same constants from a table in LDS (one 2-byte read each instead of ~8 vector instructions: the loop is bound
+    // by instruction issue, and the LDS has room for 21 KB more); N = 25 re-derives them (no LDS left).
+    unsigned short *lct = reinterpret_cast<unsigned short *>(lds + L::oLCT);
+    if (L::LCT) {
+        const LaneC1 a = calc_c1(tid); const LaneC3 b3 = calc_c3(tid); const LaneC4 d = calc_c4(tid, pk_x, pk_y);
+        const int f[L::NLC] = {a.tslot, a.op1, a.kcj, a.tcc, a.partd, a.p1k, a.p1t, a.p1d, b3.rop, b3.ysl,
+                               d.xds, d.xdg, d.tslot, d.op4, d.bjr, d.kjr, d.ycb, d.p4k, d.p4y, d.p4d, d.p4r};
+#pragma unroll
+        for (int q = 0; q < L::NLC; q++) lct[q * 512 + tid] = (unsigned short)f[q];
+    }
+    auto lct_get = [&](int t, int q) -> int { return (int)*(const volatile __attribute__((address_space(3))) unsigned short *)(lct + q * 512 + t); };
+    auto lane_c1 = [&](int t) -> LaneC1 {
+        if (!L::LCT) return calc_c1(t);
+        asm volatile("" : "+v"(t));
+        LaneC1 c;
+        c.tslot = lct_get(t, 0); c.op1 = lct_get(t, 1); c.kcj = lct_get(t, 2); c.tcc = lct_get(t, 3); c.partd = lct_get(t, 4);
+        c.p1k = lct_get(t, 5); c.p1t = lct_get(t, 6); c.p1d = lct_get(t, 7);
+        return c;
+    };
+    auto lane_c3 = [&](int t) -> LaneC3 {
+        if (!L::LCT) return calc_c3(t);
+        asm volatile("" : "+v"(t));
+        LaneC3 c;
+        c.rop = lct_get(t, 8); c.ysl = lct_get(t, 9);
+        return c;
+    };
+    auto lane_c4 = [&](int t, int px, int py) -> LaneC4 {
+        if (!L::LCT) return calc_c4(t, px, py);
+        asm volatile("" : "+v"(t));
+        LaneC4 c;
+        c.xds = lct_get(t, 10); c.xdg = lct_get(t, 11); c.tslot = lct_get(t, 12); c.op4 = lct_get(t, 13); c.bjr = lct_get(t, 14);
+        c.kjr = lct_get(t, 15); c.ycb = lct_get(t, 16); c.p4k = lct_get(t, 17); c.p4y = lct_get(t, 18); c.p4d = lct_get(t, 19); c.p4r = lct_get(t, 20);
+        return c;
+    };
     // this lane's blocks of G_s and of S^-1 (k_qp3f left them in the factor workspace).  They are loaded again at the top
     // of every termination-test period, through an opaque pointer: a value defined right in front of the hot loop and dead
     // after it is kept in VGPRs by the register allocator.
@@ -825,11 +862,13 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         for (int j = 0; j < 4 * SC; j++) sm[j] = so[j * 512];
     };
     // One solve with K_0 (three barriers), straight-line code for every lane.
-    auto solve = [&](const bool use_xT, const int it, const int tl, const int px, const int py) {
+    // (c1: the lane constants of P1, fetched by the caller in front of the barrier that opens P1; those of P3 and P4 are fetched
+    // in front of their barriers as well: a table read is then not one more LDS round trip at the head of the phase)
+    auto solve = [&](const bool use_xT, const int it, const int tl, const int px, const int py, const LaneC1 &c1) {
         const int wv = wave;
         // ---- P1: t = G b_J, part = K_CJ t; this arm's share of the T solve, s_a = (T column of A^T w) - w^T rhs ----
         if (wv < NSEG) {
-            const LaneC1 c = lane_c1(tl);
+            const LaneC1 &c = c1;
             lds[c.tslot] = g_blk<SMALL>(mm, lds + c.op1);
             wave_sync();
             const double *kc = lds + c.kcj, *tc = lds + c.tcc;
@@ -852,8 +891,13 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             misc[L::M_s0 + arm] = sa;
             if (NARM == 2) xch_post(xown + 8 + it, sa);
         }
+        const LaneC3 c3 = lane_c3(tl);
         QB(1); __syncthreads(); QS(1);
         // ---- P3: r_I = b_I - part (every wave its own copy), y_I = S^-1 r_I ----
+        if (use_xT && wv == 7) {                                               // x~_T of the bordered solve, once per workgroup
+            const double xT7 = border_xT(it, lane);
+            if (lane == 63) misc[L::M_xtT] = xT7;
+        }
         double yi;
         {
             QM0();
@@ -873,16 +917,17 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             }
             wave_sync();
             QM(5);
-            const LaneC3 c = lane_c3(tl);
+            const LaneC3 &c = c3;
             yi = s_blk<SC>(sm, lds + c.rop);
             QM(6);
             lds[c.ysl] = yi;                                                   // (lanes without an output row: pad slot nI + 1)
         }
+        const LaneC4 c4 = lane_c4(tl, px, py);
         QB(2); __syncthreads(); QS(2);
         // ---- P4: x_J = G (b_J - K_JC y_I); x~ = y - w x~_T ----
         {
             // (every LDS read that does not depend on this phase's own writes is issued first: one round trip, not five)
-            const LaneC4 c = lane_c4(tl, px, py);
+            const LaneC4 &c = c4;
             constexpr int dW = L::oWv - L::oXt;                                // w lives at a fixed distance from x~
             const double wds = ldv(lds + c.xds + dW), wdg = ldv(lds + c.xdg + dW);
             double dk[4], dy[4];
@@ -892,7 +937,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             const double k0 = ldv(kr), k1 = ldv(kr + 1), k2 = ldv(kr + 2), k3 = ldv(kr + 3);
             const double y0 = ldv(yc), y1 = ldv(yc + 14), y2 = ldv(yc - 7), y3 = ldv(yc + 7);
             double cr = ldv(lds + c.bjr);
-            const double xT = use_xT ? border_xT(it, lane) : 0.0;
+            const double xT = use_xT ? ldv(misc + L::M_xtT) : 0.0;
             lds[c.xds] = yi - wds * xT;                                        // interface rows (others: the pad slot)
             if (tid < N) xt[NS * tid + 21] = xT;                               // x~_T, once per node: the 22nd operand of the path rows
             if (wv < NSEG) {
@@ -955,7 +1000,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         const double a0 = ldv(ca), a1 = ldv(ca + 4), a2 = ldv(ca + 8), u0 = ldv(wa), u1 = ldv(wa + NS), u2 = ldv(wa + 2 * NS);
         const double b0 = ldv(cb), b1 = ldv(cb + 4), b2 = ldv(cb + 8), v0 = ldv(wb), v1 = ldv(wb + NS), v2 = ldv(wb + 2 * NS);
         const double wtv = ldv(wt);
-        double sacc = ((a0 * u0 + a1 * u1) + (a2 * u2 + ct * wtv)) + ((b0 * v0 + b1 * v1) + b2 * v2);
+        double sacc = (a0 * u0 + a1 * u1) + (a2 * u2 + ct * wtv), sac2 = (b0 * v0 + b1 * v1) + b2 * v2;
         constexpr int QB_ = SMALL ? 4 : 8;
 #pragma unroll
         for (int q0 = 0; q0 < 8; q0 += QB_) {
@@ -963,9 +1008,9 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
 #pragma unroll
             for (int q = 0; q < QB_; q++) { g8[q] = ldv(gc + (q0 + q) * GS); w8[q] = ldv(wp + q0 + q); }
 #pragma unroll
-            for (int q = 0; q < QB_; q++) sacc += g8[q] * w8[q];
+            for (int q = 0; q < QB_; q += 2) { sacc += g8[q] * w8[q]; sac2 += g8[q + 1] * w8[q + 1]; }
         }
-        return sacc;
+        return sacc + sac2;
     };
     // (A x)[r]; x in node order (slot 21 of every node: x_T)
     auto row_dot = [&](const double *xe, unsigned d, int r, double cf) -> double {
@@ -981,6 +1026,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         } else {
             const double *gr = gkl + (r - meq) * GS, *xk = xe + a0;
             sacc = 0.0;
+            double sac2 = 0.0;
             // (in parts: all 22 operand pairs in flight at once would take 88 registers)
             constexpr int RB_ = SMALL ? 4 : 8;
 #pragma unroll
@@ -988,9 +1034,14 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 double gq[RB_], xq[RB_];
 #pragma unroll
                 for (int c = 0; c < RB_; c++) if (c0 + c < 22) { gq[c] = ldv(gr + c0 + c); xq[c] = ldv(xk + c0 + c); }
+                // (two accumulation chains: a single dependent FP64 FMA chain does not fill the pipeline at two waves per SIMD)
 #pragma unroll
-                for (int c = 0; c < RB_; c++) if (c0 + c < 22) sacc += gq[c] * xq[c];
+                for (int c = 0; c < RB_; c += 2) {
+                    if (c0 + c < 22) sacc += gq[c] * xq[c];
+                    if (c0 + c + 1 < 22) sac2 += gq[c + 1] * xq[c + 1];
+                }
             }
+            sacc += sac2;
         }
         return sacc;
     };
@@ -1000,7 +1051,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     const double inv_eq = 1.0 / rho_eq, inv_in = 1.0 / rho_in;     // (the two values 1 / rho takes; the oracle divides, both round the same way)
     double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests (node order)
     load_rows();
-    solve(false, 0, tid, pk_x, pk_y);                 // K_0 w = k (the T border)
+    solve(false, 0, tid, pk_x, pk_y, lane_c1(tid));   // K_0 w = k (the T border)
     finish_border();
 #ifdef MPCMP_STAMPS
     for (int k = 0; k < 8; k++) st_acc[k] = st_busy[k] = 0;
@@ -1038,8 +1089,9 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 bp = wave_sum(bp);                             // (valid in lanes 0..15)
                 if (lane == 0) redB[wave] = bp;
             }
+            const LaneC1 c1 = lane_c1(sio);
             QB(0); __syncthreads(); QS(0);
-            solve(true, it + 1 + k, sio, pkx, pky);
+            solve(true, it + 1 + k, sio, pkx, pky, c1);
             // ---- E: z~ = A x~, relaxation, projection, dual update ----
             {
                 double tp = 0.0;
