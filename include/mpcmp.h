@@ -88,6 +88,12 @@ typedef struct {
 /* ---- configuration helpers (host, no GPU needed) ---- */
 int mpcmp_default_model(mpcmp_model *m);                                    /* Panda arm, panda_arm.urdf */
 int mpcmp_model_from_urdf(const char *urdf_path, mpcmp_model *m);           /* MotionPlanner(std::string urdf_path), motionPlanner.cpp:3 */
+/* General form (robot_utils/pandaWrapper.cpp:3-12 hands any URDF to Pinocchio): every serial chain of seven revolute joints that
+ * hangs on the root link, in file order.  Fixed joints anywhere (rotated or not) are folded into the next joint placement and
+ * their links lumped into the body of the joint frame they hang on; a chain's base placement is folded into its first joint;
+ * rotated inertial frames and joint axes other than +z are handled.  *n_chains <= max_chains models are written; the result
+ * feeds mpcmp_create_multi.  MPCMP_EINVAL (see mpcmp_last_error(NULL)): unsupported joint type, branching chain, != 7 joints. */
+int mpcmp_models_from_urdf(const char *urdf_path, int max_chains, mpcmp_model *models, int *n_chains);
 int mpcmp_default_limits(double *qmin, double *qmax, double *vmax, double *amax, double *jmax,
                          double *taumax);                                    /* pandaWrapper.hpp:29-34 */
 int mpcmp_default_config(mpcmp_config *c, int num_seg, int sqp_iters);      /* motionPlanner.cpp:15-24 */

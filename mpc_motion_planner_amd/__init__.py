@@ -9,10 +9,10 @@ reference and here; they are not part of the batched solve.)
 """
 from .capi import (Config, Info, Model, INFO_DTYPE, MpcmpError, DUAL_BASES, arm_models, build_library, default_config, default_limits,
                    default_model, forward_velocities, inverse_kinematic, inverse_velocities, lib, library_path,
-                   model_from_urdf, num_nodes, time_nodes, tool_jacobian)
+                   model_from_urdf, models_from_urdf, num_nodes, time_nodes, tool_jacobian)
 from .planner import BatchMotionPlanner, Solver
 
 __all__ = ["Config", "Info", "Model", "INFO_DTYPE", "MpcmpError", "build_library", "default_config",
-           "default_limits", "default_model", "lib", "library_path", "model_from_urdf", "num_nodes",
+           "default_limits", "default_model", "lib", "library_path", "model_from_urdf", "models_from_urdf", "num_nodes",
            "time_nodes", "BatchMotionPlanner", "Solver", "forward_velocities", "inverse_kinematic",
            "inverse_velocities", "tool_jacobian", "arm_models", "DUAL_BASES"]

@@ -42,7 +42,7 @@ INFO_DTYPE = np.dtype([("T", "f8"), ("viol_l1", "f8"), ("defect_inf", "f8"), ("p
                        ("sqp_iters", "i4"), ("status", "i4"), ("pad", "i4")])
 
 # every symbol include/mpcmp.h declares (the CPU test suite checks the library exports all of them)
-SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_default_limits", "mpcmp_default_config",
+SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_models_from_urdf", "mpcmp_default_limits", "mpcmp_default_config",
            "mpcmp_set_margins", "mpcmp_set_min_height", "mpcmp_num_nodes", "mpcmp_time_nodes", "mpcmp_version",
            "mpcmp_create", "mpcmp_create_multi", "mpcmp_destroy", "mpcmp_set_config", "mpcmp_last_error", "mpcmp_solve_batch",
            "mpcmp_solve_batch_device", "mpcmp_warm_start_batch", "mpcmp_rnea_batch",
@@ -125,6 +125,17 @@ DUAL_BASES = ((0.0, (0.0, 0.0, 0.0)), (np.pi, (1.0, 0.0, 0.0)))      # two Panda
 
 def model_from_urdf(path):
     m = Model(); check(lib().mpcmp_model_from_urdf(path.encode(), C.byref(m))); return m
+
+
+def models_from_urdf(path, max_chains=8):
+    """Every serial 7-joint chain of the URDF (file order) as a ctypes array of Models, ready for Solver(models=...):
+    fixed joints, base placements, rotated inertial frames and joint axes other than +z are folded in (mpcmp.h)."""
+    arr = (Model * max_chains)(); n = C.c_int(0)
+    check(lib().mpcmp_models_from_urdf(path.encode(), max_chains, arr, C.byref(n)))
+    out = (Model * n.value)()
+    for i in range(n.value):
+        out[i] = arr[i]
+    return out
 
 
 # ---- scenario helpers of the robot wrapper (host side; robot_utils/pandaWrapper.cpp:14-107) ----

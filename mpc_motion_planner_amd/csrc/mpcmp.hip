@@ -10,6 +10,9 @@
 #include <sstream>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <array>
+#include <functional>
 #include <map>
 
 #include "../../include/mpcmp.h"
@@ -273,10 +276,17 @@ extern "C" int mpcmp_default_model(mpcmp_model *m) {
     return MPCMP_OK;
 }
 
-// ---- minimal URDF reader for a serial chain of revolute-z joints followed by fixed links --------
+// ---- URDF reader: any number of serial 7-joint chains on one base (robot_utils/pandaWrapper.cpp:3-12 takes any URDF) --------
+// What the kernels need of a robot is, per chain, seven revolute joints about the z axis of their own frame, the placement of
+// each joint in its parent joint's frame, one rigid body per joint frame and the two named frames behind the last joint.  A URDF
+// is brought into that form here: fixed joints (before, between and behind the revolute joints, rotated or not) are folded into
+// the next joint's placement and their links lumped into the body of the joint frame they hang on; a chain's base placement is
+// folded into its first joint; rotated inertial frames rotate the inertia tensor; a joint axis other than +z is absorbed by a
+// constant rotation of the child frame.
 namespace {
-struct UrdfLink { double mass = 0, com[3] = {0, 0, 0}, I[9] = {0}; bool has_inertial = false; };
-struct UrdfJoint { std::string type, parent, child; double xyz[3] = {0, 0, 0}, rpy[3] = {0, 0, 0}, axis[3] = {0, 0, 1}; };
+struct UrdfLink { double mass = 0, com[3] = {0, 0, 0}, I[9] = {0}, irpy[3] = {0, 0, 0}; bool has_inertial = false; };
+struct UrdfJoint { std::string name, type, parent, child; double xyz[3] = {0, 0, 0}, rpy[3] = {0, 0, 0}, axis[3] = {0, 0, 1}; };
+struct Xf { double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0}; };       // rigid transform, parent <- child
 
 static std::string attr(const std::string &tag, const std::string &key) {
     size_t p = 0;
@@ -294,19 +304,84 @@ static void parse3(const std::string &s, double *o) {
     std::istringstream is(s);
     is >> o[0] >> o[1] >> o[2];
 }
+static bool is_identity(const double *R) {
+    return R[0] == 1 && R[4] == 1 && R[8] == 1 && R[1] == 0 && R[2] == 0 && R[3] == 0 && R[5] == 0 && R[6] == 0 && R[7] == 0;
+}
+static void matmul3(const double *A, const double *B, double *Cm) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Cm[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+// (identity factors are skipped, so that a URDF without rotated fixed joints gives bit-for-bit the numbers it holds)
+static Xf compose(const Xf &a, const Xf &b) {
+    Xf o;
+    if (is_identity(a.R)) { std::memcpy(o.R, b.R, sizeof o.R); for (int d = 0; d < 3; d++) o.t[d] = a.t[d] + b.t[d]; }
+    else {
+        if (is_identity(b.R)) std::memcpy(o.R, a.R, sizeof o.R); else matmul3(a.R, b.R, o.R);
+        for (int d = 0; d < 3; d++) o.t[d] = a.t[d] + (a.R[3 * d] * b.t[0] + a.R[3 * d + 1] * b.t[1] + a.R[3 * d + 2] * b.t[2]);
+    }
+    return o;
+}
+static void rotate_inertia(const double *R, const double *I, double *o) {          // R I R^T
+    if (is_identity(R)) { std::memcpy(o, I, 9 * sizeof(double)); return; }
+    double RI[9], Rt[9];
+    matmul3(R, I, RI);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * c + r];
+    matmul3(RI, Rt, o);
+}
+// rotation that takes +z to the (normalised) axis a
+static bool axis_rotation(const double *a_in, double *R) {
+    const double n = std::sqrt(a_in[0] * a_in[0] + a_in[1] * a_in[1] + a_in[2] * a_in[2]);
+    if (!(n > 0)) return false;
+    const double a[3] = {a_in[0] / n, a_in[1] / n, a_in[2] / n};
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (a[0] == 0 && a[1] == 0 && a[2] == 1) { std::memcpy(R, I3, sizeof I3); return true; }
+    if (a[0] == 0 && a[1] == 0 && a[2] == -1) { const double F[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1}; std::memcpy(R, F, sizeof F); return true; }
+    // Rodrigues: axis v = z x a, sin = |v|, cos = a_z
+    const double v[3] = {-a[1], a[0], 0.0}, c = a[2], k = 1.0 / (1.0 + c);
+    const double V[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    double V2[9];
+    matmul3(V, V, V2);
+    for (int i = 0; i < 9; i++) R[i] = I3[i] + V[i] + k * V2[i];
+    return true;
+}
+struct BodyAcc { std::vector<double> m; std::vector<std::array<double, 3>> c; std::vector<std::array<double, 9>> I; };
+struct ChainAcc {
+    std::string first_joint;
+    std::vector<Xf> placement;                      // joint i in joint i - 1 (the first: in the base / world frame)
+    std::vector<BodyAcc> bodies;                    // per joint frame
+    std::vector<std::vector<std::array<double, 3>>> frames;     // fixed descendants of each joint frame (origins, in order of discovery)
+};
+// same arithmetic, in the same order, as lump_last_body for three bodies
+static void lump(const BodyAcc &b, double &M, double *c, double *It) {
+    const size_t n = b.m.size();
+    M = b.m[0];
+    for (size_t k = 1; k < n; k++) M = M + b.m[k];
+    c[0] = c[1] = c[2] = 0;
+    for (size_t k = 0; k < n; k++) for (int d = 0; d < 3; d++) c[d] += b.m[k] * b.c[k][d];
+    for (int d = 0; d < 3; d++) c[d] /= M;
+    for (int i = 0; i < 9; i++) It[i] = 0;
+    for (size_t k = 0; k < n; k++) {
+        const double d[3] = {b.c[k][0] - c[0], b.c[k][1] - c[1], b.c[k][2] - c[2]};
+        const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        for (int r = 0; r < 3; r++) for (int s2 = 0; s2 < 3; s2++)
+            It[3 * r + s2] += b.I[k][3 * r + s2] + b.m[k] * ((r == s2 ? d2 : 0.0) - d[r] * d[s2]);
+    }
+}
 }  // namespace
 
-extern "C" int mpcmp_model_from_urdf(const char *path, mpcmp_model *m) {
-    if (!path || !m) return MPCMP_EINVAL;
+extern "C" int mpcmp_models_from_urdf(const char *path, int max_chains, mpcmp_model *models, int *n_chains) {
+    if (!path || !models || !n_chains || max_chains < 1) return MPCMP_EINVAL;
+    *n_chains = 0;
     std::ifstream f(path);
     if (!f) { g_err = std::string("cannot open URDF ") + path; return MPCMP_EINVAL; }
     std::stringstream ss; ss << f.rdbuf();
     const std::string xml = ss.str();
     std::map<std::string, UrdfLink> links;
+    std::vector<std::string> link_order;
     std::vector<UrdfJoint> joints;
     size_t pos = 0;
     std::string cur_link; UrdfJoint cur_joint; bool in_link = false, in_joint = false, in_inertial = false;
     while ((pos = xml.find('<', pos)) != std::string::npos) {
+        if (xml.compare(pos, 4, "<!--") == 0) { const size_t e = xml.find("-->", pos); if (e == std::string::npos) break; pos = e + 3; continue; }
         const size_t end = xml.find('>', pos);
         if (end == std::string::npos) break;
         const std::string tag = xml.substr(pos + 1, end - pos - 1);
@@ -314,20 +389,16 @@ extern "C" int mpcmp_model_from_urdf(const char *path, mpcmp_model *m) {
         if (tag.empty() || tag[0] == '?' || tag[0] == '!') continue;
         std::istringstream ts(tag); std::string name; ts >> name;
         if (!name.empty() && name.back() == '/') name.pop_back();
-        if (name == "link") { cur_link = attr(tag, "name"); links[cur_link]; in_link = tag.back() != '/'; }
+        if (name == "link") { cur_link = attr(tag, "name"); if (!links.count(cur_link)) link_order.push_back(cur_link); links[cur_link]; in_link = tag.back() != '/'; }
         else if (name == "/link") in_link = false;
         else if (name == "joint" && tag.find("type=") != std::string::npos) {
-            cur_joint = UrdfJoint(); cur_joint.type = attr(tag, "type"); in_joint = true;
+            cur_joint = UrdfJoint(); cur_joint.type = attr(tag, "type"); cur_joint.name = attr(tag, "name"); in_joint = true;
         } else if (name == "/joint") { if (in_joint) joints.push_back(cur_joint); in_joint = false; }
         else if (name == "inertial") in_inertial = true;
         else if (name == "/inertial") in_inertial = false;
         else if (name == "origin") {
             if (in_joint) { parse3(attr(tag, "xyz"), cur_joint.xyz); parse3(attr(tag, "rpy"), cur_joint.rpy); }
-            else if (in_link && in_inertial) {
-                parse3(attr(tag, "xyz"), links[cur_link].com);
-                double rpy[3] = {0, 0, 0}; parse3(attr(tag, "rpy"), rpy);
-                if (rpy[0] != 0 || rpy[1] != 0 || rpy[2] != 0) { g_err = "rotated inertial frames are not supported"; return MPCMP_EINVAL; }
-            }
+            else if (in_link && in_inertial) { parse3(attr(tag, "xyz"), links[cur_link].com); parse3(attr(tag, "rpy"), links[cur_link].irpy); }
         } else if (name == "mass" && in_link && in_inertial) { links[cur_link].mass = atof(attr(tag, "value").c_str()); links[cur_link].has_inertial = true; }
         else if (name == "inertia" && in_link && in_inertial) {
             UrdfLink &L = links[cur_link];
@@ -339,40 +410,101 @@ extern "C" int mpcmp_model_from_urdf(const char *path, mpcmp_model *m) {
         else if (name == "child" && in_joint) cur_joint.child = attr(tag, "link");
         else if (name == "axis" && in_joint) parse3(attr(tag, "xyz"), cur_joint.axis);
     }
-    std::vector<UrdfJoint> rev, fixed;
-    for (auto &j : joints) (j.type == "revolute" || j.type == "continuous" ? rev : fixed).push_back(j);
-    if (rev.size() != 7) { g_err = "URDF must contain exactly 7 revolute joints"; return MPCMP_EINVAL; }
-    std::memset(m, 0, sizeof *m);
-    for (int i = 0; i < 7; i++) {
-        const UrdfJoint &j = rev[i];
-        if (i > 0 && j.parent != rev[i - 1].child) { g_err = "revolute joints do not form a serial chain"; return MPCMP_EINVAL; }
-        if (!(j.axis[0] == 0 && j.axis[1] == 0 && j.axis[2] == 1)) { g_err = "only +z joint axes are supported"; return MPCMP_EINVAL; }
-        rpy_to_R(j.rpy, m->R0[i]);
-        std::memcpy(m->p[i], j.xyz, sizeof j.xyz);
-        const UrdfLink &L = links[j.child];
-        m->mass[i] = L.mass; std::memcpy(m->com[i], L.com, sizeof L.com); std::memcpy(m->I[i], L.I, sizeof L.I);
+    if (links.empty()) { g_err = "URDF holds no links"; return MPCMP_EINVAL; }
+    // the kinematic tree
+    std::map<std::string, std::vector<const UrdfJoint *>> kids;
+    std::map<std::string, int> is_child;
+    for (auto &j : joints) {
+        if (!links.count(j.parent) || !links.count(j.child)) { g_err = "joint " + j.name + " names an unknown link"; return MPCMP_EINVAL; }
+        kids[j.parent].push_back(&j);
+        if (is_child[j.child]++) { g_err = "link " + j.child + " has two parent joints"; return MPCMP_EINVAL; }
     }
-    // fixed chain after the last revolute joint: link7 -> link8 -> panda_tool (panda_arm.urdf:134-153)
-    double mk[3] = {m->mass[6], 0, 0}, ck[3][3] = {{m->com[6][0], m->com[6][1], m->com[6][2]}, {0, 0, 0}, {0, 0, 0}}, Ik[3][9];
-    std::memcpy(Ik[0], m->I[6], sizeof Ik[0]); std::memset(Ik[1], 0, sizeof Ik[1]); std::memset(Ik[2], 0, sizeof Ik[2]);
-    std::string parent = rev[6].child; double off[3] = {0, 0, 0}; int nfix = 0;
-    for (int guard = 0; guard < 2; guard++) {
-        const UrdfJoint *fj = nullptr;
-        for (auto &j : fixed) if (j.parent == parent) fj = &j;
-        if (!fj) break;
-        if (fj->rpy[0] != 0 || fj->rpy[1] != 0 || fj->rpy[2] != 0) { g_err = "rotated fixed joints are not supported"; return MPCMP_EINVAL; }
-        for (int d = 0; d < 3; d++) off[d] += fj->xyz[d];
-        const UrdfLink &L = links[fj->child];
-        nfix++;
-        mk[nfix] = L.mass;
-        for (int d = 0; d < 3; d++) ck[nfix][d] = off[d] + L.com[d];
-        std::memcpy(Ik[nfix], L.I, sizeof L.I);
-        if (nfix == 1) std::memcpy(m->link8, off, sizeof off);
-        std::memcpy(m->tool, off, sizeof off);
-        parent = fj->child;
+    std::string root;
+    for (auto &ln : link_order) if (!is_child.count(ln)) { if (!root.empty()) { g_err = "URDF has more than one root link"; return MPCMP_EINVAL; } root = ln; }
+    if (root.empty()) { g_err = "URDF has no root link (cycle)"; return MPCMP_EINVAL; }
+    std::vector<ChainAcc> chains;
+    std::string err;
+    // depth first in file order; C: link frame in the current model frame (the world before a chain starts, then the joint frame)
+    std::function<bool(const std::string &, const Xf &, int, int)> visit = [&](const std::string &ln, const Xf &C, int ci, int ji) -> bool {
+        const UrdfLink &L = links[ln];
+        if (ci >= 0) {
+            ChainAcc &ch = chains[ci];
+            if (L.has_inertial) {
+                double Rin[9], Il[9], If[9];
+                rpy_to_R(L.irpy, Rin);
+                rotate_inertia(Rin, L.I, Il);          // inertial frame -> link axes
+                rotate_inertia(C.R, Il, If);           // link axes -> joint frame axes
+                Xf com; std::memcpy(com.t, L.com, sizeof L.com);
+                const Xf cj = compose(C, com);
+                ch.bodies[ji].m.push_back(L.mass);
+                ch.bodies[ji].c.push_back({cj.t[0], cj.t[1], cj.t[2]});
+                std::array<double, 9> Ia; std::memcpy(Ia.data(), If, sizeof If);
+                ch.bodies[ji].I.push_back(Ia);
+            }
+        }
+        int revolute_kids = 0;
+        for (const UrdfJoint *j : kids[ln]) {
+            Xf T; rpy_to_R(j->rpy, T.R); std::memcpy(T.t, j->xyz, sizeof j->xyz);
+            if (j->type == "fixed") {
+                const Xf Cc = compose(C, T);
+                if (ci >= 0) chains[ci].frames[ji].push_back({Cc.t[0], Cc.t[1], Cc.t[2]});
+                if (!visit(j->child, Cc, ci, ji)) return false;
+            } else if (j->type == "revolute" || j->type == "continuous") {
+                if (ci >= 0 && ++revolute_kids > 1) { err = "link " + ln + " carries two revolute joints: not a serial chain"; return false; }
+                Xf Ra;
+                if (!axis_rotation(j->axis, Ra.R)) { err = "joint " + j->name + " has a zero axis"; return false; }
+                int c2 = ci;
+                if (c2 < 0) { chains.emplace_back(); c2 = (int)chains.size() - 1; chains[c2].first_joint = j->name; }
+                else if (ji != (int)chains[c2].placement.size() - 1) { err = "joint " + j->name + " branches off the chain starting at " + chains[c2].first_joint; return false; }
+                ChainAcc &ch = chains[c2];
+                ch.placement.push_back(compose(compose(C, T), Ra));
+                ch.bodies.emplace_back(); ch.frames.emplace_back();
+                Xf Cn;                                  // child link frame in the new joint frame: the inverse of the axis rotation
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Cn.R[3 * r + c] = Ra.R[3 * c + r];
+                if (!visit(j->child, Cn, c2, (int)ch.placement.size() - 1)) return false;
+            } else { err = "joint " + j->name + ": type '" + j->type + "' is not supported (fixed, revolute, continuous)"; return false; }
+        }
+        return true;
+    };
+    // (a chain must run through consecutive joint frames: the recursion above passes the frame index down, so a revolute joint
+    //  found below joint frame ji of chain ci extends that chain only if ji is its last frame)
+    if (!visit(root, Xf(), -1, -1)) { g_err = err; return MPCMP_EINVAL; }
+    if (chains.empty()) { g_err = "URDF holds no revolute joint"; return MPCMP_EINVAL; }
+    if ((int)chains.size() > max_chains) { g_err = "URDF holds more chains than the caller has room for"; return MPCMP_ETOOBIG; }
+    for (size_t ci = 0; ci < chains.size(); ci++) {
+        const ChainAcc &ch = chains[ci];
+        if (ch.placement.size() != 7) {
+            g_err = "the chain starting at joint " + ch.first_joint + " has " + std::to_string(ch.placement.size()) + " revolute joints; the kernels are built for 7";
+            return MPCMP_EINVAL;
+        }
+        mpcmp_model *m = models + ci;
+        std::memset(m, 0, sizeof *m);
+        for (int i = 0; i < 7; i++) {
+            std::memcpy(m->R0[i], ch.placement[i].R, sizeof m->R0[i]);
+            std::memcpy(m->p[i], ch.placement[i].t, sizeof m->p[i]);
+            const BodyAcc &b = ch.bodies[i];
+            if (b.m.empty()) continue;                                   // (a massless joint frame)
+            if (b.m.size() == 1) { m->mass[i] = b.m[0]; std::memcpy(m->com[i], b.c[0].data(), sizeof m->com[i]); std::memcpy(m->I[i], b.I[0].data(), sizeof m->I[i]); }
+            else lump(b, m->mass[i], m->com[i], m->I[i]);
+        }
+        // the two named frames of the reference behind the last joint (panda_link8, panda_tool: panda_arm.urdf:134-153): the first
+        // and the last fixed descendant of joint frame 7
+        const auto &fr = ch.frames[6];
+        if (!fr.empty()) { std::memcpy(m->link8, fr.front().data(), sizeof m->link8); std::memcpy(m->tool, fr.back().data(), sizeof m->tool); }
+        m->gravity[2] = -9.81;
     }
-    lump_last_body(m, mk, ck, Ik);
-    m->gravity[2] = -9.81;
+    *n_chains = (int)chains.size();
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_model_from_urdf(const char *path, mpcmp_model *m) {
+    if (!path || !m) return MPCMP_EINVAL;
+    mpcmp_model tmp[8];
+    int n = 0;
+    const int rc = mpcmp_models_from_urdf(path, 8, tmp, &n);
+    if (rc != MPCMP_OK) return rc;
+    if (n != 1) { g_err = "URDF holds " + std::to_string(n) + " chains: use mpcmp_models_from_urdf / mpcmp_create_multi"; return MPCMP_EINVAL; }
+    *m = tmp[0];
     return MPCMP_OK;
 }
 
@@ -463,7 +595,24 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
     if (cfg->num_seg >= 6) {        // k_qp3: per-arm tables with T bordered out (structure3.hpp)
         Tables3 t3;
         if (!build_tables3(cfg->num_seg, t3)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
-        tab.nseg = t3.nseg; tab.ext_of_int = t3.ext_of_int; tab.entry_ptr = t3.entry_ptr; tab.terms = t3.terms;
+        tab.nseg = t3.nseg; tab.ext_of_int = t3.ext_of_int;
+        // term lists in ELL form [term index][entry] (entry stride padded to 64): consecutive threads assemble consecutive entries,
+        // so every load of a term word is one coalesced 256-byte request per wave (the per-entry lists of the CSR form cost a
+        // cache line per 4-byte word, and every workgroup of the launch reads the same table: 0.47 M cycles per factorisation)
+        {
+            const int E = (int)t3.entry_ptr.size() - 1, EP = (E + 63) / 64 * 64;
+            // (kappa, the (T, T) entry, has one term per row of A: the kernel sums it by a workgroup reduction instead)
+            const int e_kap = cfg->num_seg == 6 ? Dim3<6>::eKap : Dim3<8>::eKap;
+            int tmax = 0;
+            for (int e = 0; e < E; e++) if (e != e_kap) tmax = std::max(tmax, t3.entry_ptr[e + 1] - t3.entry_ptr[e]);
+            tab.entry_ptr.assign(EP, 0);
+            tab.terms.assign((size_t)tmax * EP, 0xFFFFFFFFu);
+            for (int e = 0; e < E; e++) {
+                const int c = e == e_kap ? 0 : t3.entry_ptr[e + 1] - t3.entry_ptr[e];
+                tab.entry_ptr[e] = c;
+                for (int t = 0; t < c; t++) tab.terms[(size_t)t * EP + e] = t3.terms[t3.entry_ptr[e] + t];
+            }
+        }
         TRY(dalloc(ctx, &ctx->d_fac, (size_t)max_batch * narm * (cfg->num_seg == 6 ? Qp3<6>::FAC : Qp3<8>::FAC)));
         TRY(dalloc(ctx, &ctx->d_pat, 1));
         HIPTRY(hipMemcpy(ctx->d_pat, &t3.pat, sizeof(Qp3Pat), hipMemcpyHostToDevice));

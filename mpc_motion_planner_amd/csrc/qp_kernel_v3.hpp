@@ -133,7 +133,7 @@ struct Qp3 {
     static constexpr int FAC = oFS + 4 * SC * 512;
     // misc slots
     static constexpr int M_xT = 0, M_zbT = 1, M_ybT = 2, M_baseT = 3, M_delta = 4, M_hdT = 5, M_rbT = 6, M_lbT = 7, M_ubT = 8,
-                         M_xtT = 9, M_sumha = 10, M_dl = 12, M_done = 13, M_s0 = 14, M_s1 = 15, M_c0 = 16 /* 16..31: check exchange */;
+                         M_xtT = 9, M_sumha = 10, M_mtsT = 11 /* -ts T */, M_dl = 12, M_done = 13, M_s0 = 14, M_s1 = 15, M_c0 = 16 /* 16..31: check exchange */;
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -257,7 +257,7 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
     auto coef_T = [&](int r) -> double { const int k = r / 14, rr = r % 14; return -ts * zg_[(rr < 7) ? 14 * k + 7 + rr : 14 * N + 7 * k + rr - 7]; }; \
     if (FILL_CT_) for (int r = tid; r < meq; r += NT) lds[L::oCT + r] = coef_T(r); \
     if (tid < 32) cD[tid] = tid < 16 ? c_D[tid] : 0.0; \
-    if (tid < 32) misc[tid] = 0.0; \
+    if (tid < 32) misc[tid] = tid == L::M_mtsT ? -tsT : 0.0; \
     double *cfl = lds + L::oCfg; \
     if (tid < 14) { cfl[tid] = cfg.lbx[tid]; cfl[14 + tid] = cfg.ubx[tid]; } \
     else if (tid < 21) { cfl[28 + tid - 14] = cfg.lbu[tid - 14]; cfl[35 + tid - 14] = cfg.ubu[tid - 14]; } \
@@ -270,21 +270,18 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
     } \
     __syncthreads(); \
     const double *c_lbx = cfl, *c_ubx = cfl + 14, *c_lbu = cfl + 28, *c_ubu = cfl + 35, *c_lbg = cfl + 42, *c_ubg = cfl + 50; \
+    /* one term rho_r A[r][a] A[r][b] of an entry of A^T rho A.  Both factors are read from LDS through ONE computed address each \
+       (a select between an LDS load and a register value makes the compiler select between POINTERS, one of them into scratch, \
+       and load through a generic pointer: 0.8 M cycles per factorisation went into those flat loads) */ \
     auto term_val = [&](uint32_t t) -> double { \
         const int r = t >> 16, a = (t >> 8) & 255, c = t & 255; \
-        double va, vb, rho; \
-        if (r < meq) { \
-            const int i = (r / 14) % 3; \
-            const double cT = lds[L::oCT + r]; \
-            va = a < 4 ? cD[4 * i + a] : (a == 4 ? -tsT : cT); \
-            vb = c < 4 ? cD[4 * i + c] : (c == 4 ? -tsT : cT); \
-            rho = rho_eq; \
-        } else { \
-            const double *row = gkl + (r - meq) * GS; \
-            va = row[a]; vb = row[c]; \
-            const int q = (r - meq) & 7; \
-            rho = (c_ubg[q] - c_lbg[q] < 1e-4) ? rho_eq : rho_in; \
-        } \
+        const bool dyn = r < meq; \
+        const int i4 = 4 * ((r / 14) % 3), gro = L::oGk + (r - meq) * GS; \
+        const int ia = dyn ? (a < 4 ? L::oCD + i4 + a : (a == 4 ? L::oMisc + L::M_mtsT : L::oCT + r)) : gro + a; \
+        const int ic = dyn ? (c < 4 ? L::oCD + i4 + c : (c == 4 ? L::oMisc + L::M_mtsT : L::oCT + r)) : gro + c; \
+        const int iq = L::oCfg + 42 + (dyn ? 0 : ((r - meq) & 7)); \
+        const double va = lds[ia], vb = lds[ic], lbq = lds[iq], ubq = lds[iq + 8]; \
+        const double rho = (dyn || ubq - lbq < 1e-4) ? rho_eq : rho_in; \
         return rho * va * vb; \
     }; \
     auto dst_of = [&](int e) -> double * { \
@@ -296,13 +293,27 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
         if (e < D::EA) return lds + L::oKT + (e - D::eKT); \
         return lds + L::fKJJ + (e - D::eS); \
     }; \
-    auto assemble = [&](int e0, int e1) { \
-        for (int e = e0 + tid; e < e1; e += NT) { \
-            double acc = 0.0; \
-            const int t1 = ws.entry_ptr[e + 1]; \
-            for (int t = ws.entry_ptr[e]; t < t1; t++) acc += term_val(ws.terms[t]); \
-            *dst_of(e) = acc; \
+    /* Assembly of the entries [e0, e1) of K_0.  Term lists in ELL form: ws.entry_ptr[e] = number of terms, ws.terms[t * EP + e] \
+       (0xFFFFFFFF beyond an entry's list).  A thread owns up to NE entries and walks their lists together: per step the NE term \
+       words are loaded by independent, coalesced requests (one round trip to L2 per step, ~20 per call; entry after entry it \
+       was ~90 dependent round trips of 2 - 4 k cycles each while every workgroup of the launch reads the same table). */ \
+    auto assemble = [&](int e0, int e1, auto ne_tag) { \
+        constexpr int NE = decltype(ne_tag)::value; \
+        constexpr int EP = (D::E + 63) / 64 * 64; \
+        int cnt[NE], mymax = 0; \
+        double acc[NE]; \
+        _Pragma("unroll") for (int i = 0; i < NE; i++) { \
+            const int e = e0 + tid + i * NT; \
+            cnt[i] = e < e1 ? ws.entry_ptr[e] : 0; \
+            acc[i] = 0.0; \
         } \
+        _Pragma("unroll") for (int i = 0; i < NE; i++) mymax = cnt[i] > mymax ? cnt[i] : mymax; \
+        for (int t = 0; t < mymax; t++) { \
+            uint32_t w[NE]; \
+            _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; w[i] = ws.terms[t * EP + (e < e1 ? e : e0)]; } \
+            _Pragma("unroll") for (int i = 0; i < NE; i++) if (t < cnt[i]) acc[i] += term_val(w[i]); \
+        } \
+        _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; if (e < e1) *dst_of(e) = acc[i]; } \
     }; \
     auto var_h = [&](int v, double &ha, double &rb, double &lo, double &hi) { \
         ha = 0.0; \
@@ -328,13 +339,27 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
 template <int NSEG, int NARM>
 __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, double *__restrict__ fac) {
     QP3_PROLOGUE(1024, true)
-    assemble(0, D::EA);
-    {   // sum |ha| of this arm (Gershgorin row of T, polympc_redef.hpp:57-70)
-        double s = 0.0;
+#ifdef MPCMP_STAMPS
+    unsigned long long fst_t = clock64();
+#define FST(k) do { if (tid == 0 && arm == 0) { const unsigned long long n_ = clock64(); ws.dbg[(size_t)b * MPCMP_DBG_WORDS + 128 + (k)] = n_ - fst_t; fst_t = n_; } } while (0)
+#else
+#define FST(k) do { } while (0)
+#endif
+    FST(0);
+    assemble(0, D::EA, std::integral_constant<int, (D::EA + 1023) / 1024>());
+    {   // sum |ha| of this arm (Gershgorin row of T, polympc_redef.hpp:57-70); kappa_a = sum_r rho_r A[r][T]^2 (one term per row:
+        // a reduction, not an entry of the term table: walked by one thread its 400+ terms took 0.7 M cycles)
+        double s = 0.0, kq = 0.0;
         for (int v = tid; v < na; v += NT) { double ha, rb, lo, hi; var_h(v, ha, rb, lo, hi); s += fabs(ha); }
-        double sv[1] = {s};
-        block_reduce<16, 1, false>(sv, redp, tid);        // (its barriers also publish the assembled entries)
-        if (tid == 0) misc[L::M_sumha] = sv[0];
+        for (int r = tid; r < ma; r += NT) {
+            const double cf = r < meq ? lds[L::oCT + r] : gkl[(r - meq) * GS + 21];
+            const int q = (r - meq) & 7;
+            const double rho = (r < meq || c_ubg[q] - c_lbg[q] < 1e-4) ? rho_eq : rho_in;
+            kq += rho * cf * cf;
+        }
+        double sv[2] = {s, kq};
+        block_reduce<16, 2, false>(sv, redp, tid);        // (its barriers also publish the assembled entries)
+        if (tid == 0) { misc[L::M_sumha] = sv[0]; lds[L::oKT + na] = sv[1]; }
     }
     // diagonal H + sigma I + rho_box of the interior and U blocks; Hessian arrow into the T column
     for (int v = tid; v < na; v += NT) {
@@ -348,6 +373,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     }
     __syncthreads();
 
+    FST(1);
     // ---------------- factorisation ----------------
     auto tri_decode = [](int e, int &i, int &j) {
         i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
@@ -470,6 +496,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
               if (blk < NSEG) lds[L::fKJJ + blk * D::JP + packed(i, j)] = val;
               else if (i < 7) lds[L::fKUU + packed(i, j)] = val;
           });
+    FST(2);
     // factor registers: a G lane keeps its whole row of G_s, an S lane (later) its quarter row of S^-1
     const bool isG = wave < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 56 && lane < 63;
     double m[49];
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     if (tid < 28) lds[L::oGu + tid] = lds[L::fKUU + tid];           // -(K_UU^-1), for the Schur complement
     __syncthreads();
     // interface block K_II + its diagonal
-    assemble(D::eS, D::E);
+    assemble(D::eS, D::E, std::integral_constant<int, (D::SP + 1023) / 1024>());
     __syncthreads();
     for (int v = tid; v < na; v += NT) {
         const int ip = int3_of_ext(NSEG, v);
@@ -497,6 +524,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
         }
     }
     __syncthreads();
+    FST(3);
     // Schur complement S = K_II - sum_s K_CJ G_s K_JC - K_XU G_u K_UX: one column of K_JC at a time through the G rows in
     // registers; even and odd segments in turn (neighbours share the diagonal block of their common interface node)
     double *S = lds + L::fKJJ;
@@ -551,11 +579,25 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
         S[packed(14 * NSEG + a, 14 * NSEG + c)] += acc;             // gu holds -(K_UU^-1)
     }
     __syncthreads();
+    FST(4);
+    // The G rows leave for the factor workspace NOW: the sweep of S below keeps 64 registers of tiles per thread, and with the 98
+    // of a row still live next to them the compiler spilled inside the sweep's 100+ steps (2.4 M cycles per factorisation).
+    double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
+    if (wave < 8) {
+        // row `lane` of G_s (or of G_u: lanes 56..62 of the last segment's wave), scattered into the block layout of g_blk
+        double *fg = fa + L::oFG + (size_t)(wave * 52) * 64 + (lane & ~3);
+        const int rpos = lane & 3;
+#pragma unroll
+        for (int c = 0; c < 52; c++) {
+            const int mcol = c / 13, e = ((rpos ^ mcol) * 13 + c % 13);
+            fg[e * 64 + mcol] = c < 49 ? m[c] : 0.0;
+        }
+    }
     sweep(nI, 1, L::CB,
           [&](int, int i, int j) -> double { return S[packed(i, j)]; },
           [&](int, int i, int j, double val) { S[packed(i, j)] = val; });        // S <- -(S^-1)
+    FST(5);
     // ---------------- derived copies of the coupling blocks in the access order of the loop kernel ----------------
-    double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
     for (int i = tid; i < NSEG * 224; i += NT) {
         const int sg = i / 224, c = (i % 224) >> 3, d = i & 7, r = c % 14 + 7 * (d - 1);
         double val = 0.0;
@@ -583,22 +625,15 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     for (int i = tid; i < L::KJN; i += NT) fa[i] = lds[L::oKJC + i];                // sparse K_JC + zero row
     for (int i = tid; i < L::NAP; i += NT) fa[L::oFT + i] = lds[L::oKT + i];        // T column, kappa
     if (tid == 0) fa[L::oFH] = misc[L::M_sumha];
-    if (wave < 8) {
-        // row `lane` of G_s (or of G_u: lanes 56..62 of the last segment's wave), scattered into the block layout of g_blk
-        double *fg = fa + L::oFG + (size_t)(wave * 52) * 64 + (lane & ~3);
-        const int rpos = lane & 3;
-#pragma unroll
-        for (int c = 0; c < 52; c++) {
-            const int mcol = c / 13, e = ((rpos ^ mcol) * 13 + c % 13);
-            fg[e * 64 + mcol] = c < 49 ? m[c] : 0.0;
-        }
-    } else {
+    if (wave >= 8) {
         const int si = tid - 512, row0 = 4 * (si >> 4), mpos = si & 3, col0 = SC * (si & 15);
         for (int e = 0; e < 4 * SC; e++) {
             const int row = row0 + (mpos ^ (e / SC)), col = col0 + e % SC;
             fa[L::oFS + e * 512 + si] = (row < nI && col < nI) ? -S[packed(row, col)] : 0.0;
         }
     }
+    __syncthreads();
+    FST(6);
 }
 
 // ADMM half of the QP (see the header comment): 512 threads = 8 waves, two per SIMD, so every lane may hold 256 registers — its

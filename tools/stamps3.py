@@ -49,3 +49,7 @@ busy = st[:, 16:144].reshape(B, 16, 8)
 print("per-wave busy cycles / iteration in phases A, P1, P3, P4, E (waves 0-7: G role, 8-15: S role)")
 for w in range(16):
     print("  wave %2d  " % w + "  ".join("%8.1f" % (busy[:, w, ph] / its).mean() for ph in range(5)) + "   | P3 parts: r_I build %7.1f  S^-1 block %7.1f" % ((busy[:, w, 5] / its).mean(), (busy[:, w, 6] / its).mean()))
+
+fs = st[:, 128:135]
+print("k_qp3f (factorisation), cycles per QP: prologue %.0f | assembly (all but K_II) %.0f | diagonal, sweep of the interior blocks %.0f | G rows %.0f | K_II assembly + Schur complement %.0f | G scatter + sweep of S %.0f | derived copies + hand-over %.0f | total %.0f"
+      % (*fs.mean(axis=0), fs.sum(axis=1).mean()))
