@@ -51,8 +51,8 @@ template <int NSEG>
 struct Qp3 {
     using D = Dim3<NSEG>;
     static constexpr int NT = 1024;
-    static constexpr int GS = 22;                                   // row stride of the path Jacobians in LDS (2 x odd: lane = row reads of 8 or 16 bytes are conflict free)
-    static constexpr int NS = 22;                                   // node stride of x~, w (border), w = rho z - y in the loop kernel: [x_k (14) | u_k (7) | x~_T] resp. [dynamics rows (14) | path rows (8)]
+    static constexpr int GS = 23;                                   // row stride of the path Jacobians in LDS: odd, so that the 32 lanes of an 8-byte read group (lane = row) hit 32 different bank pairs (22 gave a two-way conflict on every coefficient read)
+    static constexpr int NS = GS;                                   // node stride of x~, w (border), w = rho z - y in the loop kernel: [x_k (14) | u_k (7) | x~_T] resp. [dynamics rows (14) | path rows (8)]
     static constexpr int NX = NS * D::N, NXP = (NX + 2 + 1) / 2 * 2; // (slot NX: pad for lanes without a job)
     static constexpr int JS = 52;                                   // stride of one segment's part of rhs (49 + zero pad: 4 x 13 column groups)
     static constexpr int SC = (D::nI + 15) / 16;                    // columns of S^-1 per lane (16 lanes per group of four rows)
@@ -92,7 +92,7 @@ struct Qp3 {
     // ---- loop kernel ----
     static constexpr int lKJC = oPE;                                // [KJN] sparse K_JC, row form
     static constexpr int lKT = lKJC + KJN;                          // [na] T column k (internal order), [na] kappa_a
-    static constexpr int oKCJ = lKT + NAP;                          // [NSEG][28][8] column form of the sparse K_JC: C-column c, rows c % 14 + 7 d, d = -1..5
+    static constexpr int oKCJ = lKT + NAP;                          // [NSEG][8][28] column form of the sparse K_JC: entry d of C-column c sits in row c % 14 + 7 (d - 1); d-major, so that lanes = columns read neighbouring words
     static constexpr int oKUXT = oKCJ + NSEG * 224;                 // [NSEG + 1][14][8] dense blocks transposed (column c: 7 entries + pad), last: u_{N-1} x x_{N-1}
     static constexpr int oKUXP = oKUXT + (NSEG + 1) * 112;          // [NSEG + 1][7][16] dense blocks, rows padded to 16
     static constexpr int oZR = oKUXP + (NSEG + 1) * 112;            // [16] zeros
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     FST(5);
     // ---------------- derived copies of the coupling blocks in the access order of the loop kernel ----------------
     for (int i = tid; i < NSEG * 224; i += NT) {
-        const int sg = i / 224, c = (i % 224) >> 3, d = i & 7, r = c % 14 + 7 * (d - 1);
+        const int sg = i / 224, d = (i % 224) / 28, c = i % 28, r = c % 14 + 7 * (d - 1);
         double val = 0.0;
         if (d < 7 && r >= 0 && r < 49) {
             const uint32_t w = pat->jc[r];
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         c.tslot = g_row ? tJ + ln : (gu_row ? L::oTU + ln - 56 : tJ + 56);
         c.op1 = (gu_quad ? L::oRhsU : L::oRhsJ + JS * wg_) + 13 * (ln & 3);
         const int cl = ln < 28 ? ln : 27;
-        c.kcj = L::oKCJ + (wg_ * 28 + cl) * 8;
+        c.kcj = L::oKCJ + wg_ * 224 + cl;
         c.tcc = tJ + (cl < 14 ? cl : cl - 14);
         c.partd = ln < 14 ? L::oPA + 14 * wg_ + ln : (ln < 28 ? L::oPB + 14 * wg_ + ln : L::oPD);      // (others: pad slot)
         const int c2 = ln >> 1, j = ln & 1;
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             const double *kc = lds + c.kcj, *tc = lds + c.tcc;
             double kq[7], tv[7], dk[4], dt[4];
 #pragma unroll
-            for (int d = 0; d < 7; d++) { kq[d] = ldv(kc + d); tv[d] = ldv(tc + 7 * (d - 1)); }      // rows c % 14 + 7 (d - 1) of the segment
+            for (int d = 0; d < 7; d++) { kq[d] = ldv(kc + 28 * d); tv[d] = ldv(tc + 7 * (d - 1)); }      // rows c % 14 + 7 (d - 1) of the segment
 #pragma unroll
             for (int d = 0; d < 4; d++) { dk[d] = ldv(lds + c.p1k + d); dt[d] = ldv(lds + c.p1t + d); }
             const double acc = ((kq[0] * tv[0] + kq[1] * tv[1]) + (kq[2] * tv[2] + kq[3] * tv[3])) + ((kq[4] * tv[4] + kq[5] * tv[5]) + kq[6] * tv[6]);

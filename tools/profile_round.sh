@@ -20,5 +20,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
     rocprofv3 --kernel-trace --pmc $grp -d "$OUT/pmc_$name" -o r -- python3 "$ROOT/bench.py" $BENCH_ARGS --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$name.log" 2>&1
 done
 python3 "$ROOT/tools/prof_summary.py" $(find "$OUT" -name '*_results.db' | sort) > "$ROOT/gpurun_out/${TAG}_summary.txt" 2>&1
+# the raw rocprofv3 databases are tens of MB each; gpurun merges at most 64 MiB back: keep the summary, the bench line and the logs
+find "$OUT" -name '*_results.db' -delete
+find "$OUT" -type d -empty -delete
 tail -3 "$OUT/bench.json"
 head -8 "$ROOT/gpurun_out/${TAG}_summary.txt"
