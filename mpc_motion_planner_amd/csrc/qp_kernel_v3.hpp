@@ -97,10 +97,11 @@ struct Qp3 {
     static constexpr int oKUXP = oKUXT + (NSEG + 1) * 112;          // [NSEG + 1][7][16] dense blocks, rows padded to 16
     static constexpr int oZR = oKUXP + (NSEG + 1) * 112;            // [16] zeros
     static constexpr int DER = NSEG * 224 + 2 * (NSEG + 1) * 112 + 16;   // (doubles of the derived copies)
-    static constexpr int oLb = oKCJ + DER, oUb = oLb + NAP, oRb = oUb + NAP, oWv = oRb + NAP;     // variable constants; w of the T border (node order)
-    static constexpr int oLg = oWv + NXP, oUg = oLg + MAP, oRr = oUg + MAP, oCf = oRr + MAP;   // row constants
+    static constexpr int oLb = oKCJ + DER, oUb = oLb + NAP, oWv = oUb + NAP;     // variable constants (rho: a flag in the lane's descriptor word); w of the T border (node order)
+    static constexpr int oLg = oWv + NXP, oUg = oLg + MAP, oCf = oUg + MAP;   // row constants
     static constexpr int oRpos = oCf + MAP;                         // [na] ints: LDS slot of the variable's rhs entry
-    static constexpr int oRhsJ = oRpos + e2((D::na + 1) / 2);       // [NSEG][JS]
+    static constexpr int oRhsJ = oRpos + e2((D::na + 1) / 2);       // [NSEG][JS]; at the termination tests [oRhsJ, oRhsJ + NX): the duals of the rows in node order
+    static_assert(NSEG * JS + JS + RIW >= NX, "dual vector of the termination test must fit over the rhs vectors");
     static constexpr int oRhsU = oRhsJ + NSEG * JS;                 // [JS] (7 used, rest zero)
     static constexpr int oRhsI = oRhsU + JS;                        // [RIW] (zero beyond nI)
     static constexpr int TS = 64;                                   // wave-private vector of a G wave: [0..51] operand / result, [56] dummy
@@ -112,8 +113,8 @@ struct Qp3 {
     static constexpr int oPB = oPA + RIW;                           // [RIW] sparse part from the segment the node closes (x_3s+3)
     static constexpr int oDP = oPB + RIW;                           // [RIW] dense part (columns x_3s)
     static constexpr int oPD = oDP + RIW;                           // [2] pad slot for lanes without an entry
-    static constexpr int oRIw = oPD + 2;                            // [8][RIW] wave-private r_I; y (duals) at checks
-    static constexpr int oYI = oRIw + cmax(8 * RIW, NXP);           // [nI] + pad slot
+    static constexpr int oRIw = oPD + 2;                            // [RIW] r_I: ONE copy that every wave writes in full (identical values: no hand-off between waves)
+    static constexpr int oYI = oRIw + RIW;                          // [nI] + pad slot
     static constexpr int oXt = oYI + e2(D::nI + 2);                 // [NXP] x~ in node order
     static constexpr int oWg = oXt + NXP;                           // [NXP] w = rho z - y in node order
     static constexpr int oRedB = oWg + NXP;                         // [8] per-wave partial sums of w^T rhs
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             double ha, rb, lo, hi;
             var_h(v, ha, rb, lo, hi);
             const double zv = zg_[v];
-            lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv; lds[L::oRb + v] = rb;
+            lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv;
             rpos[v] = rhs_slot(int3_of_ext(NSEG, v));
         }
         for (int r = tid; r < ma; r += NT) {
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 rr = (ug - lg < 1e-4) ? rho_eq : rho_in;
                 cf = gkl[(r - meq) * GS + 21];
             }
-            lds[L::oLg + r] = lg; lds[L::oUg + r] = ug; lds[L::oRr + r] = rr; lds[L::oCf + r] = cf;
+            lds[L::oLg + r] = lg; lds[L::oUg + r] = ug; lds[L::oCf + r] = cf;
         }
         if (tid == 0) {
             misc[L::M_lbT] = cfg.lbT - T; misc[L::M_ubT] = cfg.ubT - T;
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         asm volatile("" : "+v"(t));
         LaneC3 c;
         const int srow = 4 * (t >> 4) + (t & 3);
-        c.rop = L::oRIw + wave * L::RIW + SC * (t & 15);
+        c.rop = L::oRIw + SC * (t & 15);
         c.ysl = L::oYI + (((t & 15) < 4 && srow < nI) ? srow : nI + 1);      // (lanes without an output row: pad slot)
         return c;
     };
@@ -936,7 +937,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         double yi;
         {
             QM0();
-            double *rIw = lds + L::oRIw + wv * L::RIW;
+            double *rIw = lds + L::oRIw;                                       // (every wave writes all of it, with identical values)
             {
                 int l8 = lane;
                 asm volatile("" : "+v"(l8));
@@ -1021,6 +1022,10 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         unsigned d = 0;
         if (r < meq) { const int k = r / 14, rr = r % 14; d = (unsigned)(NS * 3 * (k / 3) + rr) | ((unsigned)(k % 3) << 16); }
         else if (r < ma) d = (unsigned)(NS * ((r - meq) >> 3));
+        // bit 20: rho of the lane's variable is rho_eq (x_0, or any box narrower than 1e-4); bit 21: rho of the lane's row is rho_eq
+        const int v = tid + 512 * h;
+        if (v < na) { double ha, rb, lo, hi; var_h(v, ha, rb, lo, hi); if (rb == rho_eq) d |= 1u << 20; }
+        if (r < ma && (r < meq || lds[L::oUg + r] - lds[L::oLg + r] < 1e-4)) d |= 1u << 21;
         dr[h] = d;
     }
     // (A^T w)[v] without the T row; w in node order
@@ -1084,7 +1089,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         return r < meq ? (int)(d & 0xFFFF) + NS * (int)((d >> 16) & 3) : (int)(d & 0xFFFF) + 14 + ((r - meq) & 7);
     };
     const double inv_eq = 1.0 / rho_eq, inv_in = 1.0 / rho_in;     // (the two values 1 / rho takes; the oracle divides, both round the same way)
-    double *ys = lds + L::oRIw;                                     // duals of the rows at the termination tests (node order)
+    double *ys = lds + L::oRhsJ;                                    // duals of the rows at the termination tests (node order), over the rhs vectors
     load_rows();
     solve(false, 0, tid, pk_x, pk_y, lane_c1(tid));   // K_0 w = k (the T border)
     finish_border();
@@ -1115,7 +1120,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     const int v = sio + 512 * h;
                     if (v < na) {
                         const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : zb0, yy = h ? s1y[sio] : yb0;
-                        const double rbv = ldv(lds + L::oRb + v), wv_ = ldv(wvv + (dvo[h] & 0xFFFF));     // (issued with the gather's reads)
+                        const double rbv = (dro[h < NR ? h : 0] >> 20) & 1u ? rho_eq : rho_in, wv_ = ldv(wvv + (dvo[h] & 0xFFFF));     // (issued with the gather's reads)
                         const double r = (sigma * xx + (rbv * zz - yy)) + col_gather(wg, dvo[h]);
                         lds[h ? rpos[v] : (int)((unsigned)pky >> 16)] = r;
                         bp += wv_ * r;
@@ -1133,8 +1138,8 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 {   // first row and first variable of the lane: every constant it needs is read up front (lanes without one read
                     // valid neighbouring words)
                     const int r = sio < ma ? row_of(sio) : 0;
-                    const double rr = ldv(lds + L::oRr + r), lg = ldv(lds + L::oLg + r), ug = ldv(lds + L::oUg + r), cf = ldv(lds + L::oCf + r);
-                    const double xtv = ldv(xt + (dvo[0] & 0xFFFF)), rb = ldv(lds + L::oRb + sio), lb = ldv(lds + L::oLb + sio), ub = ldv(lds + L::oUb + sio);
+                    const double rr = (dro[0] >> 21) & 1u ? rho_eq : rho_in, lg = ldv(lds + L::oLg + r), ug = ldv(lds + L::oUg + r), cf = ldv(lds + L::oCf + r);
+                    const double xtv = ldv(xt + (dvo[0] & 0xFFFF)), rb = (dro[0] >> 20) & 1u ? rho_eq : rho_in, lb = ldv(lds + L::oLb + sio), ub = ldv(lds + L::oUb + sio);
                     if (sio < ma) {
                         const double zt = row_dot(xt, dro[0], r, cf);
                         const double zr = alpha * zt + (1.0 - alpha) * zg0;
@@ -1156,7 +1161,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 if (NR == 2 && sio + 512 < ma) {              // second row (N = 25: 24 lanes), state in LDS
                     const int r = row_of(sio + 512);
                     double zg = s1zg[sio], yg = s1yg[sio];
-                    const double rr = lds[L::oRr + r], cf = lds[L::oCf + r];
+                    const double rr = (dro[NR - 1] >> 21) & 1u ? rho_eq : rho_in, cf = lds[L::oCf + r];
                     const double zt = row_dot(xt, dro[NR - 1], r, cf);
                     const double zr = alpha * zt + (1.0 - alpha) * zg;
                     const double zn = clip(zr + yg * (rr == rho_eq ? inv_eq : inv_in), lds[L::oLg + r], lds[L::oUg + r]);
@@ -1170,7 +1175,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 if (NV == 2 && sio + 512 < na) {              // second variable (N = 25: 13 lanes)
                     const int v = sio + 512;
                     double xx = s1x[sio], zz = s1z[sio], yy = s1y[sio];
-                    const double xtv = xt[dvo[NV - 1] & 0xFFFF], rb = lds[L::oRb + v];
+                    const double xtv = xt[dvo[NV - 1] & 0xFFFF], rb = (dro[NR - 1] >> 20) & 1u ? rho_eq : rho_in;
                     xx = alpha * xtv + (1.0 - alpha) * xx;
                     const double zr = alpha * xtv + (1.0 - alpha) * zz;
                     const double zn = clip(zr + yy * (rb == rho_eq ? inv_eq : inv_in), lds[L::oLb + v], lds[L::oUb + v]);
@@ -1244,6 +1249,8 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 }
             }
             done = check_tail(sums, mx, nchk++);
+            for (int i = sio; i < NX; i += 512) ys[i] = 0.0;          // (the rhs vectors under the dual vector: their pads must read zero)
+            __syncthreads();
             QS(5);
         }
     }
