@@ -71,8 +71,7 @@ struct Qp3 {
     static constexpr int oRedP = oCD + 32;                          // [160] workgroup reductions
     static constexpr int oCfg = oRedP + 160;                        // [64] bound tables of the configuration: lbx 0, ubx 14, lbu 28, ubu 35, lbg 42, ubg 50
     static constexpr int oPat = oCfg + 64;                          // [49 + 28 + 28] ints: sparse K_JC pattern words (jc | cjl | cjh)
-    static constexpr int oXdG = oPat + 54;                          // [8][64] ints: where the G lanes' x~ entries go (loop kernel)
-    static constexpr int oPE = oXdG + 256;                          // end of the common part
+    static constexpr int oPE = oPat + 54;                           // end of the common part
     static constexpr int KJN = NSEG * 196 + 4;                      // sparse K_JC [NSEG][49][4] (canonical slots, structure3.hpp) + a zero row
     // ---- factorisation kernel ----
     static constexpr int oKJC = oPE;                                // [KJN]
@@ -120,10 +119,13 @@ struct Qp3 {
     static constexpr int oRedB = oWg + NXP;                         // [8] per-wave partial sums of w^T rhs
     static constexpr int oRedT = oRedB + 8;                         // [8] per-wave partial sums of the T column of A^T w
     static constexpr int oS1 = oRedT + 8;                           // [5][32] ADMM state of the second variable / row of the lanes that own two (N = 25)
-    static constexpr bool LCT = NSEG < 8;                           // lane-constant table (N = 25 has no LDS left for it)
+    static constexpr bool LCT = NSEG < 8;                           // lane-constant table (N = 25: measured slower with it — the register allocator answers with copies and spills)
     static constexpr int NLC = 21;                                  // fields of LaneC1 + LaneC3 + LaneC4
     static constexpr int oLCT = oS1 + 160;                          // [NLC][512] 16-bit words
-    static constexpr int lEnd = oLCT + (LCT ? NLC * 128 : 0);
+    static constexpr int oXdG = oLCT;                               // [8][64] ints, set-up only (before the table is filled): where the G lanes' x~ entries go
+    static constexpr bool STL = false;                              // (option: z_b, y_b, z_g, y_g of the lane's first variable / row in LDS; measured: no gain at N = 25)
+    static constexpr int oSt = oLCT + (LCT ? NLC * 128 : 256);      // [4][512]
+    static constexpr int lEnd = oSt + (STL ? 4 * 512 : 0);
     static constexpr int sizeF = fEnd, sizeL = lEnd;
     static_assert(sizeF * 8 <= 160 * 1024 - 512 && sizeL * 8 <= 160 * 1024 - 512, "LDS budget");
     // factor workspace (doubles per arm): the sparse K_JC [KJN], the T column [NAP], sum|ha| [8], the derived copies [DER], then
@@ -681,7 +683,8 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         if (wv == NSEG - 1 && ln >= 56 && ln < 63) xd = node_slot(ws.ext_of_int[nJ + (ln - 56)]);
         xdgt[tid] = xd;
         // loop-resident constants and the rhs of K_0 w = k
-        for (int i = tid; i < L::oLCT - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;              // vectors, pads, partial sums, second-pass state
+        for (int i = tid; i < L::oLCT - L::oRpos; i += NT) lds[L::oRpos + i] = 0.0;
+        if (L::STL) for (int i = tid; i < 4 * 512; i += NT) lds[L::oSt + i] = 0.0;              // vectors, pads, partial sums, second-pass state
         for (int i = tid; i < L::NXP; i += NT) lds[L::oWv + i] = 0.0;
         __syncthreads();
         for (int v = tid; v < na; v += NT) {
@@ -999,7 +1002,8 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // second row (N = 25: 24 of them) get a cheap one.  The state of a lane's second variable / row lives in LDS (the 10 registers
     // it would take in EVERY lane are needed elsewhere).
     auto row_of = [&](int q) -> int { return q < 8 * N ? meq + q : q - 8 * N; };
-    double xv0 = 0, zb0 = 0, yb0 = 0, zg0 = 0, yg0 = 0;
+    double xv0 = 0, zb0 = 0, yb0 = 0, zg0 = 0, yg0 = 0;             // (z_b .. y_g: registers unless L::STL)
+    double *stz = lds + L::oSt, *sty = stz + 512, *stg = stz + 1024, *sth = stz + 1536;
     double *s1x = lds + L::oS1, *s1z = s1x + 32, *s1y = s1x + 64, *s1zg = s1x + 96, *s1yg = s1x + 128;
     static_assert(na - 512 <= 32 && ma - 512 <= 32, "second-pass state");
     unsigned dv[NV], dr[NR];
@@ -1119,7 +1123,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 for (int h = 0; h < NV; h++) {
                     const int v = sio + 512 * h;
                     if (v < na) {
-                        const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : zb0, yy = h ? s1y[sio] : yb0;
+                        const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : (L::STL ? ldv(stz + sio) : zb0), yy = h ? s1y[sio] : (L::STL ? ldv(sty + sio) : yb0);
                         const double rbv = (dro[h < NR ? h : 0] >> 20) & 1u ? rho_eq : rho_in, wv_ = ldv(wvv + (dvo[h] & 0xFFFF));     // (issued with the gather's reads)
                         const double r = (sigma * xx + (rbv * zz - yy)) + col_gather(wg, dvo[h]);
                         lds[h ? rpos[v] : (int)((unsigned)pky >> 16)] = r;
@@ -1140,22 +1144,26 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     const int r = sio < ma ? row_of(sio) : 0;
                     const double rr = (dro[0] >> 21) & 1u ? rho_eq : rho_in, lg = ldv(lds + L::oLg + r), ug = ldv(lds + L::oUg + r), cf = ldv(lds + L::oCf + r);
                     const double xtv = ldv(xt + (dvo[0] & 0xFFFF)), rb = (dro[0] >> 20) & 1u ? rho_eq : rho_in, lb = ldv(lds + L::oLb + sio), ub = ldv(lds + L::oUb + sio);
+                    double zgv = zg0, ygv = yg0, zbv = zb0, ybv = yb0;
+                    if (L::STL) { zgv = ldv(stg + sio); ygv = ldv(sth + sio); zbv = ldv(stz + sio); ybv = ldv(sty + sio); }
                     if (sio < ma) {
                         const double zt = row_dot(xt, dro[0], r, cf);
-                        const double zr = alpha * zt + (1.0 - alpha) * zg0;
-                        const double zn = clip(zr + yg0 * (rr == rho_eq ? inv_eq : inv_in), lg, ug);
-                        yg0 += rr * (zr - zn);
-                        zg0 = zn;
-                        const double w = rr * zg0 - yg0;
+                        const double zr = alpha * zt + (1.0 - alpha) * zgv;
+                        const double zn = clip(zr + ygv * (rr == rho_eq ? inv_eq : inv_in), lg, ug);
+                        ygv += rr * (zr - zn);
+                        zgv = zn;
+                        if (L::STL) { stg[sio] = zgv; sth[sio] = ygv; } else { zg0 = zgv; yg0 = ygv; }
+                        const double w = rr * zgv - ygv;
                         wg[w_slot(dro[0], r)] = w;
                         tp += cf * w;
                     }
                     if (sio < na) {
                         xv0 = alpha * xtv + (1.0 - alpha) * xv0;
-                        const double zr = alpha * xtv + (1.0 - alpha) * zb0;
-                        const double zn = clip(zr + yb0 * (rb == rho_eq ? inv_eq : inv_in), lb, ub);
-                        yb0 += rb * (zr - zn);
-                        zb0 = zn;
+                        const double zr = alpha * xtv + (1.0 - alpha) * zbv;
+                        const double zn = clip(zr + ybv * (rb == rho_eq ? inv_eq : inv_in), lb, ub);
+                        ybv += rb * (zr - zn);
+                        zbv = zn;
+                        if (L::STL) { stz[sio] = zbv; sty[sio] = ybv; } else { zb0 = zbv; yb0 = ybv; }
                     }
                 }
                 if (NR == 2 && sio + 512 < ma) {              // second row (N = 25: 24 lanes), state in LDS
@@ -1211,7 +1219,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             for (int h = 0; h < NR; h++) {
                 if (sio + 512 * h < ma) {
                     const int r = row_of(sio + 512 * h);
-                    const double yg = h ? s1yg[sio] : yg0; ys[w_slot(dr[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg;
+                    const double yg = h ? s1yg[sio] : (L::STL ? sth[sio] : yg0); ys[w_slot(dr[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg;
                 }
             }
 #pragma unroll
@@ -1232,7 +1240,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             for (int h = 0; h < NR; h++) {
                 if (sio + 512 * h < ma) {
                     const int r = row_of(sio + 512 * h);
-                    const double zg = h ? s1zg[sio] : zg0, ax = row_dot(xt, dr[h], r, lds[L::oCf + r]);
+                    const double zg = h ? s1zg[sio] : (L::STL ? stg[sio] : zg0), ax = row_dot(xt, dr[h], r, lds[L::oCf + r]);
                     mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
                 }
             }
@@ -1240,7 +1248,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             for (int h = 0; h < NV; h++) {
                 const int v = sio + 512 * h;
                 if (v < na) {
-                    const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : zb0, yy = h ? s1y[sio] : yb0;
+                    const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : (L::STL ? stz[sio] : zb0), yy = h ? s1y[sio] : (L::STL ? sty[sio] : yb0);
                     double ha, rb, lo, hi;
                     var_h(v, ha, rb, lo, hi);
                     const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, dv[h]) + yy;
@@ -1260,12 +1268,12 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         const int v = tid + 512 * h;
         if (v < na) {
             ws.p[(size_t)b * n_tot + arm * na + v] = h ? s1x[tid] : xv0;
-            ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? s1y[tid] : yb0;
+            ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? s1y[tid] : (L::STL ? sty[tid] : yb0);
         }
     }
 #pragma unroll
     for (int h = 0; h < NR; h++) {
-        if (tid + 512 * h < ma) ws.y[(size_t)b * mn_tot + arm * ma + row_of(tid + 512 * h)] = h ? s1yg[tid] : yg0;
+        if (tid + 512 * h < ma) ws.y[(size_t)b * mn_tot + arm * ma + row_of(tid + 512 * h)] = h ? s1yg[tid] : (L::STL ? sth[tid] : yg0);
     }
     if (tid == 511 && arm == 0) {
         ws.p[(size_t)b * n_tot + NARM * na] = misc[L::M_xT];
