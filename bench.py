@@ -38,7 +38,11 @@ WORKLOADS = {
 }
 # FP64 FMAs the dominant kernel EXECUTES (tools/isa_mix.py on the ISA of the ADMM loop / the sweeps), per ADMM iteration and
 # per factorisation; None where it has not been counted
-EXECUTED_FMA = {4: (34.0e3, 0.85e6)}
+# FMAs the kernels execute on useful data: (per ADMM iteration, per factorisation) of one arm.  N = 13: counted in k_qp2's ISA
+# (round 1).  N = 19 / 25 (k_qp3f + k_qp3): products of the algorithm — two G products (NSEG x 49^2 each), S^-1 (n_I^2), the sparse
+# and dense K_JC parts, A x~ and A^T w (22 per path row, 6 per dynamics row), the updates; factorisation: Gauss-Jordan sweeps of
+# the NSEG + 1 interior blocks (49^3 each), the Schur complement (28 columns x (49^2 + 200) per segment), the sweep of S (n_I^3).
+EXECUTED_FMA = {4: (34.0e3, 0.85e6), 6: (55.0e3, 2.2e6), 8: (66.0e3, 3.6e6)}
 
 
 def canonical_flops(N, sqp_iters, admm_iters_total, narm=1):

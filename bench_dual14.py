@@ -106,7 +106,9 @@ def run(args, rank, world, local, dist):
                    "batch": batch, "problems_total": total, "problems_rank0": B, "rccl_world_size": world, "seed": scenarios.SEED,
                    "margins": list(margins), "n_variables": 42 * N + 1},
         "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": Bn.FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / Bn.FP64_PEAK_TFLOPS, "peak_measured": peak_meas,
+                     "frac": achieved / Bn.FP64_PEAK_TFLOPS,
+                     "executed_frac": per_gpu * 2.0 * narm * (admm_mean * Bn.EXECUTED_FMA[nseg][0] + sqp * Bn.EXECUTED_FMA[nseg][1]) / 1e12 / Bn.FP64_PEAK_TFLOPS,
+                     "peak_measured": peak_meas,
                      "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None, "traffic": None, "mfma_busy": 0.0,
                      "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts,
                      "problems_per_launch": B / parts, "workgroups_per_problem": 2,
