@@ -894,8 +894,11 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // after it is kept in VGPRs by the register allocator.
     double mm[52], sm[4 * SC];
     auto load_rows = [&]() {
-        const double *fo = fa + L::oFG + (size_t)(wave * 52) * 64 + lane, *so = fa + L::oFS + tid;
-        asm volatile("" : "+v"(fo), "+v"(so));
+        const double *fo_ = fa + L::oFG + (size_t)(wave * 52) * 64 + lane, *so_ = fa + L::oFS + tid;
+        asm volatile("" : "+v"(fo_), "+v"(so_));
+        // (the opaque copies are generic pointers to the compiler: name the address space again, or the 80 loads become flat loads)
+        typedef const __attribute__((address_space(1))) double *gptr_t;
+        gptr_t fo = (gptr_t)fo_, so = (gptr_t)so_;
 #pragma unroll
         for (int j = 0; j < 52; j++) mm[j] = fo[j * 64];
 #pragma unroll
@@ -1107,7 +1110,9 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     int it = 0, done = 0, nchk = 0;
     while (it < cfg.qp_iters && !done) {
         const int cnt = cfg.qp_iters - it < cfg.check_every ? cfg.qp_iters - it : cfg.check_every;
+#ifndef MPCMP_QP3_NO_RELOAD
         load_rows();
+#endif
         for (int k = 0; k < cnt; k++) {
             // opaque copies of the lane index and of the packed words: what is derived from them stays inside the iteration
             int sio = tid, pkx = pk_x, pky = pk_y;
