@@ -1,21 +1,21 @@
-// qp_kernel_v3.hpp — k_qp3<NSEG, NARM>: the QP kernel for the larger discretisations (N = 19, the reference as shipped,
-// robot_ocp.hpp:31-32; N = 25) and for multi-arm robots (BASELINE.json configs[3]: 14-DoF dual Panda, N = 25).
+// qp_kernel_v3.hpp — k_qp3f<NSEG, NARM> + k_qp3<NSEG, NARM>: the QP of the larger discretisations (N = 19, the reference as
+// shipped, robot_ocp.hpp:31-32; N = 25) and of multi-arm robots (BASELINE.json configs[3]: 14-DoF dual Panda, N = 25).
 //
-// One workgroup of 1024 threads (= one CU: 16 waves, 128 VGPRs each) per (OCP, arm).  Same arithmetic as k_qp / k_qp2 — OSQP-form ADMM on [A; I] with the
-// reduced KKT system solved by nested dissection and explicit block inverses — with two structural changes that make the
-// factor of an N = 25 arm fit one CU's registers (structure3.hpp):
+// One workgroup per (OCP, arm).  Same arithmetic as k_qp / k_qp2 — OSQP-form ADMM on [A; I] with the reduced KKT system solved
+// by nested dissection and explicit block inverses — with two structural changes that make the factor of an N = 25 arm fit one
+// CU's registers (structure3.hpp):
 //   * the final time T, the only variable the arms share, is bordered out: every arm factorises its own K_0 and the arms of one
 //     OCP exchange ONE scalar per ADMM iteration (k_a^T K_0a^-1 b_a) through global memory (NARM = 2; nothing for NARM = 1);
 //   * E_s = G_s K_JC is never formed: the interior solve applies G_s twice around the sparse K_JC / K_CJ products, so the only
-//     dense factors are G_s (49 x 49 per segment, one ROW per lane of wave s: every lane of a wave reads the same operand, i.e.
-//     LDS broadcast reads) and S^-1 (nI x nI, four lanes per row, DPP quad reduction).
-// Waves 0..7 are the G role: wave s holds G_s, one ROW per lane (98 of the lane's 128 VGPRs; lanes 49..55 of the last G wave hold
-// the 7 x 7 block of u_{N-1}).  Waves 8..15 are the S role: a quarter row of S^-1 per lane and the ADMM state of up to two
-// variables and two rows.  The roles run separate code (own register arrays) with the same barrier sequence, five workgroup
-// barriers per iteration:
-//     A  rhs = sigma x - q + rho z - y + A^T w         (S)       | P1  t = G b_J,  part = K_CJ t               (G)
-//     P3 r_I = b_I - part,  y_I = S^-1 r_I             (S)       | P4  x_J = G (b_J - K_JC y_I) - w x_T        (G)
-//     E  z~ = A x~, relaxation, projection, dual update (S)
+//     dense factors are G_s (49 x 49 per segment) and S^-1 (nI x nI).
+// k_qp3f (1024 threads) assembles and factorises K_0 and leaves the factor in a per-problem workspace, in the lane layout of
+// k_qp3 (512 threads = 8 waves, two per SIMD, 256 registers per lane), which runs the ADMM loop: a lane keeps a 4 x 13 block of
+// G_s (wave s = segment s; the four lanes of a quad share four rows, lanes 56..62 of the last segment's wave hold the 7 x 7 block
+// of u_{N-1}), a 4 x SC block of S^-1 (sixteen lanes share four rows) and the ADMM state of one variable and one row in
+// registers.  Every wave takes part in every phase; five workgroup barriers per iteration:
+//     A  rhs = sigma x - q + rho z - y + A^T w    P1  t = G b_J,  K_CJ t    P3  y_I = S^-1 (b_I - K_CJ t)
+//     P4 x_J = G (b_J - K_JC y_I) - w x_T         E   z~ = A x~, relaxation, projection, dual update
+// DESIGN.md (section 4) has the measurements behind every choice made here.
 #pragma once
 #include "qp_kernel_v2.hpp"
 #include "structure3.hpp"
