@@ -933,11 +933,12 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             const double sa = ssum - bsum;
             misc[L::M_s0 + arm] = sa;
             if (NARM == 2) xch_post(xown + 8 + it, sa);
+            else misc[L::M_xtT] = (misc[L::M_baseT] + sa) / misc[L::M_delta];      // one arm: x~_T right here (read in P4)
         }
         const LaneC3 c3 = lane_c3(tl);
         QB(1); __syncthreads(); QS(1);
         // ---- P3: r_I = b_I - part (every wave its own copy), y_I = S^-1 r_I ----
-        if (use_xT && wv == 7) {                                               // x~_T of the bordered solve, once per workgroup
+        if (NARM == 2 && use_xT && wv == 7) {                                  // x~_T of the bordered solve, once per workgroup (needs the partner's share)
             const double xT7 = border_xT(it, lane);
             if (lane == 63) misc[L::M_xtT] = xT7;
         }
