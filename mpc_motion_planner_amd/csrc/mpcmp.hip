@@ -662,6 +662,9 @@ extern "C" int mpcmp_set_config(mpcmp_ctx *ctx, const mpcmp_config *cfg) {
     if (!ctx || !cfg) return MPCMP_EINVAL;
     if (cfg->num_seg != ctx->nseg) { ctx->err = "num_seg cannot change after mpcmp_create"; return MPCMP_EINVAL; }
     if (int rc = validate(cfg, ctx->err)) return rc;
+    if (ctx->narm == 2 && 8 + cfg->qp_iters + 1 + 8 * (cfg->qp_iters / cfg->check_every + 1) > MPCMP_XCH_STRIDE) {
+        ctx->err = "multi-arm OCPs: qp_iters too large for the exchange slots"; return MPCMP_EINVAL;
+    }
     ctx->cfg = *cfg;
     // a captured receding-horizon step holds the configuration by value as a kernel argument: re-capture on the next rh_run
     if (ctx->rh_exec) { (void)hipGraphExecDestroy(ctx->rh_exec); ctx->rh_exec = nullptr; }

@@ -110,3 +110,17 @@ def test_config4_full_size_properties(M):
         xg, ug, Tg = o.warm_start_jerk_multi(8, *_limits(), x0[b], xf[b])
         xs, us, T, oi = o.solve_multi(models, ocfg, x0[b], xf[b], xg, ug, Tg)
         assert abs(sT[b] - T) <= 1e-6 * T and np.abs(sx[b] - xs).max() <= 1e-6 and info["qp_iters_total"][b] == oi.qp_iters_total
+
+
+def test_set_config_rejects_iteration_caps_beyond_the_exchange_slots(M):
+    """the two arm workgroups of an OCP exchange through a fixed number of slots per QP: a cap that needs more is refused, by
+    mpcmp_create_multi and by mpcmp_set_config alike (it would otherwise overrun the slots of the next problem)"""
+    cfg = M.default_config(6, 1)
+    s = M.Solver(cfg, 1, models=M.arm_models(M.DUAL_BASES))
+    bad = M.default_config(6, 1); bad.qp_iters = 2000
+    with pytest.raises(M.MpcmpError):
+        s.set_config(bad)
+    with pytest.raises(M.MpcmpError):
+        M.Solver(bad, 1, models=M.arm_models(M.DUAL_BASES))
+    ok = M.default_config(6, 1); ok.qp_iters = 100
+    s.set_config(ok)
