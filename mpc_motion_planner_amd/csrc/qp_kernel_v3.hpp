@@ -164,6 +164,34 @@ __device__ __forceinline__ double g_dot(const double (&m)[49], const double *op)
     return a0 + a1;
 }
 
+// workgroup reduction (sum or max) of K values per thread by DPP inside the waves (no LDS permutes: 24 ds_bpermute per value in the
+// generic block_reduce) and one LDS exchange between them; the result is valid in every thread.  Two barriers.
+template <int NW, int K, bool MAX>
+__device__ __forceinline__ void block_reduce_dpp(double (&v)[K], double *red, int tid) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double x = v[k];
+        if (MAX) {
+            x = fmax(x, dpp_mov<0xB1>(x)); x = fmax(x, dpp_mov<0x4E>(x)); x = fmax(x, dpp_mov<0x141>(x)); x = fmax(x, dpp_mov<0x140>(x));
+            x = fmax(fmax(x, read_lane(x, 16)), fmax(read_lane(x, 32), read_lane(x, 48)));
+        } else x = wave_sum(x);
+        v[k] = x;                                   // valid in lanes 0..15
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[(tid >> 6) * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double x = red[k];
+#pragma unroll
+        for (int w = 1; w < NW; w++) x = MAX ? fmax(x, red[w * K + k]) : x + red[w * K + k];
+        v[k] = x;
+    }
+    __syncthreads();
+}
+
 // diagnostic builds (-DMPCMP_STAMPS, tools/stamps3.py): cycles per phase of the ADMM loop (QS: after a barrier) and the busy part of
 // each phase per wave (QB: in front of the barrier)
 #ifdef MPCMP_STAMPS
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // termination test, common tail: combine the arms, add the row / column of T, decide
     const unsigned chk_base = 8 + cfg.qp_iters + 1;
     auto check_tail = [&](double (&sums)[2], double (&mx)[6], int nchk) -> int {
-        block_reduce<8, 6, true>(mx, redp, tid);
+        block_reduce_dpp<8, 6, true>(mx, redp, tid);
         double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
         s1[arm] = sums[0]; s2[arm] = sums[1];
         if (NARM == 2) {
@@ -1216,8 +1244,15 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         }
         it += cnt;
         if (cnt == cfg.check_every) {
+            // (opaque copies here as well: addresses derived from the plain descriptors would be hoisted out of the OUTER loop,
+            // spilled across the hot loop and re-read from scratch one by one in every test)
             int sio = tid;
+            unsigned dvc[NV], drc[NR];
             asm volatile("" : "+v"(sio));
+#pragma unroll
+            for (int h = 0; h < NV; h++) { dvc[h] = dv[h]; asm volatile("" : "+v"(dvc[h])); }
+#pragma unroll
+            for (int h = 0; h < NR; h++) { drc[h] = dr[h]; asm volatile("" : "+v"(drc[h])); }
             // ---- termination test: r_prim = ||[A;I]x - z||inf, r_dual = ||Hx + q + [A;I]^T y||inf (oracle/ocp.c admm) ----
             double sums[2] = {0.0, 0.0};              // T row: sum coefT_r y_r, sum ha_i x_i of this arm
             for (int i = sio; i < NX; i += 512) ys[i] = 0.0;          // (the unused slots of the node-ordered dual vector)
@@ -1226,7 +1261,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             for (int h = 0; h < NR; h++) {
                 if (sio + 512 * h < ma) {
                     const int r = row_of(sio + 512 * h);
-                    const double yg = h ? s1yg[sio] : (L::STL ? sth[sio] : yg0); ys[w_slot(dr[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg;
+                    const double yg = h ? s1yg[sio] : (L::STL ? sth[sio] : yg0); ys[w_slot(drc[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg;
                 }
             }
 #pragma unroll
@@ -1235,18 +1270,18 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 if (v < na) {
                     const double xx = h ? s1x[sio] : xv0;
                     const double ha = lds[L::oHa + v];
-                    xt[dv[h] & 0xFFFF] = xx; sums[1] += ha * xx;
+                    xt[dvc[h] & 0xFFFF] = xx; sums[1] += ha * xx;
                 }
             }
             if (sio < N) xt[NS * sio + 21] = misc[L::M_xT];
-            block_reduce<8, 2, false>(sums, redp, tid);          // (its barriers publish xt / ys)
+            block_reduce_dpp<8, 2, false>(sums, redp, tid);      // (its barriers publish xt / ys)
             double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
             const double xTc = xt[21];
 #pragma unroll
             for (int h = 0; h < NR; h++) {
                 if (sio + 512 * h < ma) {
                     const int r = row_of(sio + 512 * h);
-                    const double zg = h ? s1zg[sio] : (L::STL ? stg[sio] : zg0), ax = row_dot(xt, dr[h], r, lds[L::oCf + r]);
+                    const double zg = h ? s1zg[sio] : (L::STL ? stg[sio] : zg0), ax = row_dot(xt, drc[h], r, lds[L::oCf + r]);
                     mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
                 }
             }
@@ -1256,7 +1291,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 if (v < na) {
                     const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : (L::STL ? stz[sio] : zb0), yy = h ? s1y[sio] : (L::STL ? sty[sio] : yb0);
                     const double ha = lds[L::oHa + v];
-                    const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, dv[h]) + yy;
+                    const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, dvc[h]) + yy;
                     mx[0] = fmax(mx[0], fabs(xx - zz)); mx[1] = fmax(mx[1], fabs(xx)); mx[2] = fmax(mx[2], fabs(zz));
                     mx[3] = fmax(mx[3], fabs(hx + aty)); mx[4] = fmax(mx[4], fabs(hx)); mx[5] = fmax(mx[5], fabs(aty));
                 }
