@@ -123,10 +123,11 @@ struct Qp3 {
     static constexpr int NLC = 21;                                  // fields of LaneC1 + LaneC3 + LaneC4
     static constexpr int oLCT = oS1 + 160;                          // [NLC][512] 16-bit words
     static constexpr int oXdG = oLCT;                               // [8][64] ints, set-up only (before the table is filled): where the G lanes' x~ entries go
-    static constexpr bool STL = false;                              // (option: z_b, y_b, z_g, y_g of the lane's first variable / row in LDS; measured: no gain at N = 25)
+    static constexpr bool STL = false;                                    // (option: z_b, y_b, z_g, y_g of the lane's first variable / row in LDS; measured: no gain at N = 25)
     static constexpr int oSt = oLCT + (LCT ? NLC * 128 : 256);      // [4][512]
     static constexpr int oHa = oSt + (STL ? 4 * 512 : 0);           // [na] Hessian arrow entries h_a (termination test)
-    static constexpr int lEnd = oHa + NAP;
+    static constexpr bool HAL = !STL;                               // (with the state in LDS there is no room for it: h_a is then re-derived at the tests)
+    static constexpr int lEnd = oHa + (HAL ? NAP : 0);
     static constexpr int sizeF = fEnd, sizeL = lEnd;
     static_assert(sizeF * 8 <= 160 * 1024 - 512 && sizeL * 8 <= 160 * 1024 - 512, "LDS budget");
     // factor workspace (doubles per arm): the sparse K_JC [KJN], the T column [NAP], sum|ha| [8], the derived copies [DER], then
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             double ha, rb, lo, hi;
             var_h(v, ha, rb, lo, hi);
             const double zv = zg_[v];
-            lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv; lds[L::oHa + v] = ha;
+            lds[L::oLb + v] = lo - zv; lds[L::oUb + v] = hi - zv; if (L::HAL) lds[L::oHa + v] = ha;
             rpos[v] = rhs_slot(int3_of_ext(NSEG, v));
         }
         for (int r = tid; r < ma; r += NT) {
@@ -1269,7 +1270,8 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 const int v = sio + 512 * h;
                 if (v < na) {
                     const double xx = h ? s1x[sio] : xv0;
-                    const double ha = lds[L::oHa + v];
+                    double ha, rb_, lo_, hi_;
+                    if (L::HAL) ha = lds[L::oHa + v]; else var_h(v, ha, rb_, lo_, hi_);
                     xt[dvc[h] & 0xFFFF] = xx; sums[1] += ha * xx;
                 }
             }
@@ -1290,7 +1292,8 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 const int v = sio + 512 * h;
                 if (v < na) {
                     const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : (L::STL ? stz[sio] : zb0), yy = h ? s1y[sio] : (L::STL ? sty[sio] : yb0);
-                    const double ha = lds[L::oHa + v];
+                    double ha, rb_, lo_, hi_;
+                    if (L::HAL) ha = lds[L::oHa + v]; else var_h(v, ha, rb_, lo_, hi_);
                     const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, dvc[h]) + yy;
                     mx[0] = fmax(mx[0], fabs(xx - zz)); mx[1] = fmax(mx[1], fabs(xx)); mx[2] = fmax(mx[2], fabs(zz));
                     mx[3] = fmax(mx[3], fabs(hx + aty)); mx[4] = fmax(mx[4], fabs(hx)); mx[5] = fmax(mx[5], fabs(aty));
