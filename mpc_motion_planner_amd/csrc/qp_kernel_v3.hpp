@@ -116,9 +116,10 @@ struct Qp3 {
     static constexpr int oYI = oRIw + RIW;                          // [nI] + pad slot
     static constexpr int oXt = oYI + e2(D::nI + 2);                 // [NXP] x~ in node order
     static constexpr int oWg = oXt + NXP;                           // [NXP] w = rho z - y in node order
-    static constexpr int oRedB = oWg + NXP;                         // [8] per-wave partial sums of w^T rhs
-    static constexpr int oRedT = oRedB + 8;                         // [8] per-wave partial sums of the T column of A^T w
-    static constexpr int oS1 = oRedT + 8;                           // [5][32] ADMM state of the second variable / row of the lanes that own two (N = 25)
+    static constexpr bool P8 = NSEG < 8;                            // N = 19: partial sums per 8 lanes (half the DPP chain in A and E); wave 7, idle in P1, adds them up
+    static constexpr int oRedB = oWg + NXP;                         // [64] partial sums of w^T rhs (per wave, or per 8 lanes)
+    static constexpr int oRedT = oRedB + 64;                        // [64] partial sums of the T column of A^T w
+    static constexpr int oS1 = oRedT + 64;                          // [5][32] ADMM state of the second variable / row of the lanes that own two (N = 25)
     static constexpr bool LCT = NSEG < 8;                           // lane-constant table (N = 25: measured slower with it — the register allocator answers with copies and spills)
     static constexpr int NLC = 21;                                  // fields of LaneC1 + LaneC3 + LaneC4
     static constexpr int oLCT = oS1 + 160;                          // [NLC][512] 16-bit words
@@ -955,7 +956,16 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             const double ad = (dk[0] * dt[0] + dk[1] * dt[1]) + (dk[2] * dt[2] + dk[3] * dt[3]);
             lds[c.p1d] = ad + dpp_mov<0xB1>(ad);                                   // (odd lanes, lanes without a column: pad slot)
         }
-        if (use_xT && tid == 511) {
+        if (L::P8) {
+            if (use_xT && wv == 7) {                                           // (wave 7 holds no segment at N = 19)
+                const double sa = wave_sum(ldv(redT + lane) - ldv(redB + lane));
+                if (lane == 0) {
+                    misc[L::M_s0 + arm] = sa;
+                    if (NARM == 2) xch_post(xown + 8 + it, sa);
+                    else misc[L::M_xtT] = (misc[L::M_baseT] + sa) / misc[L::M_delta];      // one arm: x~_T right here (read in P4)
+                }
+            }
+        } else if (use_xT && tid == 511) {
             double ssum = 0.0, bsum = 0.0;
 #pragma unroll
             for (int w8 = 0; w8 < 8; w8++) { ssum += redT[w8]; bsum += redB[w8]; }
@@ -1166,8 +1176,8 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                         bp += wv_ * r;
                     }
                 }
-                bp = wave_sum(bp);                             // (valid in lanes 0..15)
-                if (lane == 0) redB[wave] = bp;
+                if (L::P8) { bp = sum8(bp); if ((lane & 7) == 0) redB[8 * wave + (lane >> 3)] = bp; }
+                else { bp = wave_sum(bp); if (lane == 0) redB[wave] = bp; }      // (valid in lanes 0..15)
             }
             const LaneC1 c1 = lane_c1(sio);
             QB(0); __syncthreads(); QS(0);
@@ -1227,8 +1237,8 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     zz = zn;
                     s1x[sio] = xx; s1z[sio] = zz; s1y[sio] = yy;
                 }
-                tp = wave_sum(tp);
-                if (lane == 0) redT[wave] = tp;               // (read by the next iteration's P1: two barriers away)
+                if (L::P8) { tp = sum8(tp); if ((lane & 7) == 0) redT[8 * wave + (lane >> 3)] = tp; }
+                else { tp = wave_sum(tp); if (lane == 0) redT[wave] = tp; }      // (read by the next iteration's P1: two barriers away)
                 if (sio == 511) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
                     const double xtv = xt[21], rb = misc[L::M_rbT];
                     double xx = misc[L::M_xT], zz = misc[L::M_zbT], yy = misc[L::M_ybT];
