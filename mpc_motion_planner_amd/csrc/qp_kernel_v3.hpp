@@ -87,7 +87,7 @@ struct Qp3 {
     static constexpr int fRdv = fCol + 2 * CB;                      // [2][16]
     static constexpr int fEnd = fRdv + 32;
     static constexpr int fSW = fKJJ + e2(D::SP);                    // Schur phase scratch behind S: [8][64] column, [8][64] product
-    static_assert(fSW + 1024 <= fKUU, "Schur scratch must fit between S and the K_UU block");
+    static_assert(fSW + 512 + 2 * 416 <= fKUU, "Schur scratch must fit between S and the K_UU block");
     // ---- loop kernel ----
     static constexpr int lKJC = oPE;                                // [KJN] sparse K_JC, row form
     static constexpr int lKT = lKJC + KJN;                          // [na] T column k (internal order), [na] kappa_a
@@ -151,18 +151,13 @@ __device__ __forceinline__ void wave_sync() {
 
 // row . operand for a G lane: broadcast LDS reads of the operand in chunks of three 16-byte pairs, so that the scheduler cannot
 // hoist all 25 reads in front of the FMAs (the row itself already takes 98 of the 128 VGPRs)
-__device__ __forceinline__ double g_dot(const double (&m)[49], const double *op) {
+__device__ __forceinline__ double g_dot_half(const double (&m)[27], const double *op) {      // 26 entries (the 27th is scatter padding)
     double a0 = 0.0, a1 = 0.0;
+    D2 v4[13];
 #pragma unroll
-    for (int j0 = 0; j0 < 24; j0 += 3) {
-        D2 v4[3];
+    for (int q = 0; q < 13; q++) v4[q] = lds2(op + 2 * q);
 #pragma unroll
-        for (int q = 0; q < 3; q++) v4[q] = lds2(op + 2 * (j0 + q));
-#pragma unroll
-        for (int q = 0; q < 3; q++) { a0 += m[2 * (j0 + q)] * v4[q].x; a1 += m[2 * (j0 + q) + 1] * v4[q].y; }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    a0 += m[48] * op[48];
+    for (int q = 0; q < 13; q++) { a0 += m[2 * q] * v4[q].x; a1 += m[2 * q + 1] * v4[q].y; }
     return a0 + a1;
 }
 
@@ -422,13 +417,14 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
         constexpr int CB = L::CB;
         double *rdv = lds + L::fRdv;
         const int nt4 = (nb + 3) >> 2, ntile = nt4 * (nt4 + 1) / 2;
-        // up to two tiles per thread (tile ids tid and tid + NT)
-        bool live[2], diag[2];
-        int blk[2], Ib[2], Jb[2];
-        double *cb0[2];
-        double v[2][4][4];
+        // one tile per thread (every sweep of this kernel has at most NT tiles: checked at the call sites)
+        constexpr int NH = 1;
+        bool live[NH], diag[NH];
+        int blk[NH], Ib[NH], Jb[NH];
+        double *cb0[NH];
+        double v[NH][4][4];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < NH; h++) {
             const int t = tid + h * NT;
             live[h] = t < ntile * nblk;
             blk[h] = 0; Ib[h] = 0; Jb[h] = 0;
@@ -444,13 +440,14 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
                 }
             }
         }
+        if (tid == 0) rdv[15] = 0.0;                  // "a pivot was not positive" (a flag in LDS: `status` as a register live across the steps was spilled and re-read in every one of them)
         __syncthreads();                              // (every tile is in registers before the first column is published)
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < NH; h++) {
             if (live[h] && Jb[h] == 0) {
 #pragma unroll
                 for (int a = 0; a < 4; a++) cb0[h][4 * Ib[h] + a] = v[h][a][0];
-                if (Ib[h] == 0) { if (!(v[h][0][0] > 0.0)) status |= 2; rdv[blk[h]] = pivot_rcp(v[h][0][0]); }
+                if (Ib[h] == 0) { if (!(v[h][0][0] > 0.0)) rdv[15] = 1.0; rdv[blk[h]] = pivot_rcp(v[h][0][0]); }
             }
         }
         __syncthreads();
@@ -462,7 +459,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
                 if (k < npad) {
                     const int k1a = (ka + 1) & 3, k1b = kb + (ka == 3 ? 1 : 0);
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
+                    for (int h = 0; h < NH; h++) {
                         if (live[h]) {
                             const double *cur = cb0[h] + (k & 1) * CB;
                             double *nxt = cb0[h] + ((k + 1) & 1) * CB;
@@ -491,7 +488,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
                                     for (int a = 0; a < 4; a++) nxt[4 * Ib[h] + a] = (diag[h] && a < k1a) ? v[h][k1a][a] : v[h][a][k1a];
                                     if (diag[h]) {
                                         const double pv = v[h][k1a][k1a];
-                                        if (!(pv > 0.0)) status |= 2;
+                                        if (!(pv > 0.0)) rdv[15] = 1.0;
                                         rdv[((k + 1) & 1) * 16 + blk[h]] = pivot_rcp(pv);
                                     }
                                 } else if (Ib[h] == k1b) {
@@ -506,7 +503,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
             }
         }
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < NH; h++) {
             if (live[h]) {
 #pragma unroll
                 for (int a = 0; a < 4; a++) {
@@ -518,9 +515,11 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
                 }
             }
         }
+        if (tid == 0 && rdv[15] != 0.0) status |= 2;
         __syncthreads();
     };
     // interior blocks K_JJ,s (49 x 49) and K_UU (7 x 7, padded with an identity to 49 x 49), all at once
+    static_assert(91 * (NSEG + 1) <= NT && ((nI + 3) / 4) * ((nI + 3) / 4 + 1) / 2 <= NT, "one 4 x 4 tile per thread in both sweeps");
     sweep(49, NSEG + 1, 52,
           [&](int blk, int i, int j) -> double {
               if (blk < NSEG) return lds[L::fKJJ + blk * D::JP + packed(i, j)];
@@ -531,13 +530,16 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
               else if (i < 7) lds[L::fKUU + packed(i, j)] = val;
           });
     FST(2);
-    // factor registers: a G lane keeps its whole row of G_s, an S lane (later) its quarter row of S^-1
-    const bool isG = wave < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 56 && lane < 63;
-    double m[49];
+    // factor registers: TWO waves per segment (sw and sw + 8) keep one half of each row of G_s: columns 0..24 and 25..48 (a whole row,
+    // 98 registers of the 128 a 1024-thread kernel has, was spilled and re-read in every step of the Schur phase)
+    const int sw = wave & 7, hf = wave >> 3;
+    const bool isG = sw < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 56 && lane < 63;
+    double m[27];
 #pragma unroll
-    for (int j = 0; j < 49; j++) {
+    for (int j = 0; j < 27; j++) {
+        const int c = 25 * hf + j;
         double val = 0.0;
-        if (isG) val = -lds[L::fKJJ + wave * D::JP + packed(lane, j)];
+        if (isG && c < 49 && (hf == 1 || j < 25)) val = -lds[L::fKJJ + sw * D::JP + packed(lane, c)];
         if (isGu && j < 7) val = -lds[L::fKUU + packed(lane - 56, j)];
         m[j] = val;
         if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);          // one-time loads: keep the address temporaries few
@@ -562,44 +564,46 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     // Schur complement S = K_II - sum_s K_CJ G_s K_JC - K_XU G_u K_UX: one column of K_JC at a time through the G rows in
     // registers; even and odd segments in turn (neighbours share the diagonal block of their common interface node)
     double *S = lds + L::fKJJ;
-    const uint32_t jcw = lane < 49 ? pat->jc[lane] : 0xFFFFFFFFu;
+    // a lane builds the K_JC entry of row 25 hf + lane (lane < 26) of the current column for its wave's half of the dot products
+    const int krow = 25 * hf + lane;
+    const bool kact = lane < 26 && krow < 49 && (hf == 1 || lane < 25);
+    const uint32_t jcw = kact ? pat->jc[krow] : 0xFFFFFFFFu;
     const uint32_t cjl = lane < 28 ? pat->cjl[lane] : 0xFFFFFFFFu, cjh = lane < 28 ? pat->cjh[lane] : 0xFFFFFFFFu;
-    // Per-iteration opaque copies of the lane-dependent constants: everything derived from them (LDS addresses of the sparse K_JC
-    // entries, of the operands, ...) is loop invariant, and hoisted out of the ADMM loop it takes > 150 VGPRs and evicts the
-    // factor rows to scratch.  The copies are re-made by an empty asm at the top of every iteration.
-    const double *kjc = lds + L::oKJC + (wave < NSEG ? wave : 0) * 196, *kux = lds + L::oKUX + (wave < NSEG ? wave : 0) * 98;
-    auto kjc_entry = [&](int r, int c) -> double {          // K_JC[r][c] of this wave's segment (r = own lane)
+    const double *kjc = lds + L::oKJC + (sw < NSEG ? sw : 0) * 196, *kux = lds + L::oKUX + (sw < NSEG ? sw : 0) * 98;
+    auto kjc_entry = [&](int r, int c) -> double {          // K_JC[r][c] of this wave's segment
         if (r < 7 && c < 14) return kux[r * 14 + c];
         double val = 0.0;
 #pragma unroll
         for (int q = 0; q < 4; q++) if ((int)((jcw >> (8 * q)) & 255u) == c) val = kjc[r * 4 + q];
         return val;
     };
-    auto kcj_dot = [&](int c, const double *vec) -> double {  // (K_CJ vec)[c] of this wave's segment (c = own lane < 28)
+    auto kcj_dot = [&](int c, const double *va, const double *vb) -> double {  // (K_CJ (va + vb))[c] of this wave's segment (c = own lane < 28)
         double acc = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t ref = ((q < 4 ? cjl : cjh) >> (8 * (q & 3))) & 255u;
-            if (ref != 255u) acc += kjc[(ref >> 2) * 4 + (ref & 3u)] * vec[ref >> 2];
+            if (ref != 255u) acc += kjc[(ref >> 2) * 4 + (ref & 3u)] * (va[ref >> 2] + vb[ref >> 2]);
         }
         if (c < 14) {
 #pragma unroll
-            for (int r = 0; r < 7; r++) acc += kux[r * 14 + c] * vec[r];
+            for (int r = 0; r < 7; r++) acc += kux[r * 14 + c] * (va[r] + vb[r]);
         }
         return acc;
     };
+    // Scratch behind S: [16][32] column halves, then [2][8][52] half products (double buffered over the columns: one barrier each).
     for (int ph = 0; ph < 2; ph++) {
-        if (wave < NSEG && (wave & 1) == ph) {
-            double *colb = lds + L::fSW + wave * 64, *eb = lds + L::fSW + 512 + wave * 64;
-            for (int c = 0; c < 28; c++) {
-                colb[lane] = lane < 49 ? kjc_entry(lane, c) : 0.0;
+        const bool mine = sw < NSEG && (sw & 1) == ph;
+        double *colb = lds + L::fSW + wave * 32;
+        for (int c = 0; c < 28; c++) {
+            double *eb = lds + L::fSW + 512 + (c & 1) * 416 + (sw >> 1) * 104;
+            if (mine) {
+                if (lane < 32) colb[lane] = kact ? kjc_entry(krow, c) : 0.0;
                 wave_sync();
-                const double ev = g_dot(m, colb);
-                eb[lane] = lane < 49 ? ev : 0.0;
-                wave_sync();
-                if (lane < 28 && lane >= c) S[packed(14 * wave + lane, 14 * wave + c)] -= kcj_dot(lane, eb);
-                wave_sync();
+                const double ev = g_dot_half(m, colb);
+                if (lane < 52) eb[hf * 52 + lane] = lane < 49 ? ev : 0.0;
             }
+            __syncthreads();
+            if (mine && hf == 0 && lane < 28 && lane >= c) S[packed(14 * sw + lane, 14 * sw + c)] -= kcj_dot(lane, eb, eb + 52);
         }
         __syncthreads();
     }
@@ -617,14 +621,17 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     // The G rows leave for the factor workspace NOW: the sweep of S below keeps 64 registers of tiles per thread, and with the 98
     // of a row still live next to them the compiler spilled inside the sweep's 100+ steps (2.4 M cycles per factorisation).
     double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
-    if (wave < 8) {
-        // row `lane` of G_s (or of G_u: lanes 56..62 of the last segment's wave), scattered into the block layout of g_blk
-        double *fg = fa + L::oFG + (size_t)(wave * 52) * 64 + (lane & ~3);
+    {
+        // row `lane` of G_s (or of G_u: lanes 56..62 of the last segment's wave), scattered into the block layout of g_blk: each of the
+        // segment's two waves writes its half of the columns
+        double *fg = fa + L::oFG + (size_t)(sw * 52) * 64 + (lane & ~3);
         const int rpos = lane & 3;
+        if (hf == 0) {
 #pragma unroll
-        for (int c = 0; c < 52; c++) {
-            const int mcol = c / 13, e = ((rpos ^ mcol) * 13 + c % 13);
-            fg[e * 64 + mcol] = c < 49 ? m[c] : 0.0;
+            for (int j = 0; j < 25; j++) { const int mcol = j / 13, e = ((rpos ^ mcol) * 13 + j % 13); fg[e * 64 + mcol] = m[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 27; j++) { const int c = 25 + j, mcol = c / 13, e = ((rpos ^ mcol) * 13 + c % 13); fg[e * 64 + mcol] = m[j]; }
         }
     }
     sweep(nI, 1, L::CB,
