@@ -153,11 +153,21 @@ __device__ __forceinline__ void wave_sync() {
 // hoist all 25 reads in front of the FMAs (the row itself already takes 98 of the 128 VGPRs)
 __device__ __forceinline__ double g_dot_half(const double (&m)[27], const double *op) {      // 26 entries (the 27th is scatter padding)
     double a0 = 0.0, a1 = 0.0;
-    D2 v4[13];
+    {
+        D2 v4[7];
 #pragma unroll
-    for (int q = 0; q < 13; q++) v4[q] = lds2(op + 2 * q);
+        for (int q = 0; q < 7; q++) v4[q] = lds2(op + 2 * q);
 #pragma unroll
-    for (int q = 0; q < 13; q++) { a0 += m[2 * q] * v4[q].x; a1 += m[2 * q + 1] * v4[q].y; }
+        for (int q = 0; q < 7; q++) { a0 += m[2 * q] * v4[q].x; a1 += m[2 * q + 1] * v4[q].y; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        D2 v4[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) v4[q] = lds2(op + 14 + 2 * q);
+#pragma unroll
+        for (int q = 0; q < 6; q++) { a0 += m[14 + 2 * q] * v4[q].x; a1 += m[15 + 2 * q] * v4[q].y; }
+    }
     return a0 + a1;
 }
 
@@ -570,27 +580,52 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     const uint32_t jcw = kact ? pat->jc[krow] : 0xFFFFFFFFu;
     const uint32_t cjl = lane < 28 ? pat->cjl[lane] : 0xFFFFFFFFu, cjh = lane < 28 ? pat->cjh[lane] : 0xFFFFFFFFu;
     const double *kjc = lds + L::oKJC + (sw < NSEG ? sw : 0) * 196, *kux = lds + L::oKUX + (sw < NSEG ? sw : 0) * 98;
-    auto kjc_entry = [&](int r, int c) -> double {          // K_JC[r][c] of this wave's segment
-        if (r < 7 && c < 14) return kux[r * 14 + c];
+    // (every load below is unconditional, with a safe index and a select afterwards: a load under a lane condition is not
+    //  speculated, and eight of them in a row were eight serial LDS round trips per column)
+    auto kjc_entry = [&](int r, int c) -> double {          // K_JC[r][c] of this wave's segment (r = the lane's row krow)
+        const int rs = kact ? r : 0;
+        double kq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) kq[q] = kjc[rs * 4 + q];
+        const double dv = kux[(rs < 7 ? rs : 0) * 14 + (c < 14 ? c : 0)];
         double val = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) if ((int)((jcw >> (8 * q)) & 255u) == c) val = kjc[r * 4 + q];
+        for (int q = 0; q < 4; q++) if ((int)((jcw >> (8 * q)) & 255u) == c) val = kq[q];
+        if (rs < 7 && c < 14) val = dv;
         return val;
     };
-    auto kcj_dot = [&](int c, const double *va, const double *vb) -> double {  // (K_CJ (va + vb))[c] of this wave's segment (c = own lane < 28)
+    auto kcj_dot = [&](int c, const double *eb) -> double {  // (K_CJ e)[c] of this wave's segment (c = own lane < 28); eb [49][2]: the two half products of e
         double acc = 0.0;
+        {
+            double kq[8];
+            D2 ab[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const uint32_t ref = ((q < 4 ? cjl : cjh) >> (8 * (q & 3))) & 255u;
-            if (ref != 255u) acc += kjc[(ref >> 2) * 4 + (ref & 3u)] * (va[ref >> 2] + vb[ref >> 2]);
+            for (int q = 0; q < 8; q++) {
+                const uint32_t ref = ((q < 4 ? cjl : cjh) >> (8 * (q & 3))) & 255u;
+                const int rr = ref != 255u ? (int)ref : 0;
+                kq[q] = kjc[rr]; ab[q] = lds2(eb + 2 * (rr >> 2));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t ref = ((q < 4 ? cjl : cjh) >> (8 * (q & 3))) & 255u;
+                if (ref != 255u) acc += kq[q] * (ab[q].x + ab[q].y);
+            }
         }
-        if (c < 14) {
+        __builtin_amdgcn_sched_barrier(0);                   // (two batches of loads: 98 registers of temporaries at once spilled the G rows)
+        {
+            double ku[7];
+            D2 ab[7];
+            const int cs = c < 14 ? c : 0;
 #pragma unroll
-            for (int r = 0; r < 7; r++) acc += kux[r * 14 + c] * (va[r] + vb[r]);
+            for (int r = 0; r < 7; r++) { ku[r] = kux[r * 14 + cs]; ab[r] = lds2(eb + 2 * r); }
+            if (c < 14) {
+#pragma unroll
+                for (int r = 0; r < 7; r++) acc += ku[r] * (ab[r].x + ab[r].y);
+            }
         }
         return acc;
     };
-    // Scratch behind S: [16][32] column halves, then [2][8][52] half products (double buffered over the columns: one barrier each).
+    // Scratch behind S: [16][32] column halves, then [2][4][52][2] half products (double buffered over the columns: one barrier each).
     for (int ph = 0; ph < 2; ph++) {
         const bool mine = sw < NSEG && (sw & 1) == ph;
         double *colb = lds + L::fSW + wave * 32;
@@ -600,10 +635,10 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
                 if (lane < 32) colb[lane] = kact ? kjc_entry(krow, c) : 0.0;
                 wave_sync();
                 const double ev = g_dot_half(m, colb);
-                if (lane < 52) eb[hf * 52 + lane] = lane < 49 ? ev : 0.0;
+                if (lane < 52) eb[2 * lane + hf] = lane < 49 ? ev : 0.0;
             }
             __syncthreads();
-            if (mine && hf == 0 && lane < 28 && lane >= c) S[packed(14 * sw + lane, 14 * sw + c)] -= kcj_dot(lane, eb, eb + 52);
+            if (mine && hf == 0 && lane < 28 && lane >= c) S[packed(14 * sw + lane, 14 * sw + c)] -= kcj_dot(lane, eb);
         }
         __syncthreads();
     }
