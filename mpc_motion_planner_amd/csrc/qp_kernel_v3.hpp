@@ -151,26 +151,6 @@ __device__ __forceinline__ void wave_sync() {
 
 // row . operand for a G lane: broadcast LDS reads of the operand in chunks of three 16-byte pairs, so that the scheduler cannot
 // hoist all 25 reads in front of the FMAs (the row itself already takes 98 of the 128 VGPRs)
-__device__ __forceinline__ double g_dot_half(const double (&m)[27], const double *op) {      // 26 entries (the 27th is scatter padding)
-    double a0 = 0.0, a1 = 0.0;
-    {
-        D2 v4[7];
-#pragma unroll
-        for (int q = 0; q < 7; q++) v4[q] = lds2(op + 2 * q);
-#pragma unroll
-        for (int q = 0; q < 7; q++) { a0 += m[2 * q] * v4[q].x; a1 += m[2 * q + 1] * v4[q].y; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        D2 v4[6];
-#pragma unroll
-        for (int q = 0; q < 6; q++) v4[q] = lds2(op + 14 + 2 * q);
-#pragma unroll
-        for (int q = 0; q < 6; q++) { a0 += m[14 + 2 * q] * v4[q].x; a1 += m[15 + 2 * q] * v4[q].y; }
-    }
-    return a0 + a1;
-}
-
 // workgroup reduction (sum or max) of K values per thread by DPP inside the waves (no LDS permutes: 24 ds_bpermute per value in the
 // generic block_reduce) and one LDS exchange between them; the result is valid in every thread.  Two barriers.
 template <int NW, int K, bool MAX>
@@ -540,21 +520,89 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
               else if (i < 7) lds[L::fKUU + packed(i, j)] = val;
           });
     FST(2);
-    // factor registers: TWO waves per segment (sw and sw + 8) keep one half of each row of G_s: columns 0..24 and 25..48 (a whole row,
-    // 98 registers of the 128 a 1024-thread kernel has, was spilled and re-read in every step of the Schur phase)
+    // ---------------- Schur complement S = K_II - sum_s K_CJ G_s K_JC - K_XU G_u K_UX ----------------
+    // The segment products E_s = G_s K_JC,s (49 x 49 by 49 x 28) and K_CJ,s E_s (28 x 49 by 49 x 28) are the block GEMMs of the QP
+    // and run on the matrix cores (v_mfma_f64_16x16x4_f64; lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15], and row
+    // (l >> 4) + 4 r, column l & 15 of the result in register r).  Two waves per segment (sw and sw + 8), one 16-column tile of E_s
+    // each.  Register r of row tile mt of E_s IS the B operand of k-step 4 mt + r of the second product (same lane map), and a
+    // fragment of K_JC serves as B operand of the first product and as A operand (K_CJ = K_JC^T) of the second: no data movement.
+    // G_s is read where the sweep left it; the products are taken BEFORE K_II is assembled over it, and subtracted afterwards.
+    using V4 = __attribute__((ext_vector_type(4))) double;
     const int sw = wave & 7, hf = wave >> 3;
-    const bool isG = sw < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 56 && lane < 63;
-    double m[27];
-#pragma unroll
-    for (int j = 0; j < 27; j++) {
-        const int c = 25 * hf + j;
-        double val = 0.0;
-        if (isG && c < 49 && (hf == 1 || j < 25)) val = -lds[L::fKJJ + sw * D::JP + packed(lane, c)];
-        if (isGu && j < 7) val = -lds[L::fKUU + packed(lane - 56, j)];
-        m[j] = val;
-        if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);          // one-time loads: keep the address temporaries few
+    double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
+    {
+        // G_s leaves for the factor workspace in the block layout of g_blk: row `lane` of G_s (or of G_u: lanes 56..62 of the last
+        // segment's wave), each of the segment's two waves writes one half of the columns
+        const bool isG = sw < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 56 && lane < 63;
+        const double *Gs = lds + L::fKJJ + (sw < NSEG ? sw : 0) * D::JP, *Gu = lds + L::fKUU;
+        double *fg = fa + L::oFG + (size_t)(sw * 52) * 64 + (lane & ~3);
+        const int rpos = lane & 3, rowG = isG ? lane : 0, rowU = isGu ? lane - 56 : 0;
+        const int c0 = hf == 0 ? 0 : 25, c1 = hf == 0 ? 25 : 52;
+#pragma unroll 1
+        for (int c = c0; c < c1; c++) {                        // (a rolled loop: unrolled, its 27 independent loads and index chains were all hoisted and spilled)
+            const int cs = c < 49 ? c : 0, cu = c < 7 ? c : 0;
+            const double g = -Gs[packed(rowG, cs)], u = -Gu[packed(rowU, cu)];
+            const double val = (isG && c < 49) ? g : ((isGu && c < 7) ? u : 0.0);
+            const int mcol = c / 13, e = ((rpos ^ mcol) * 13 + c % 13);
+            fg[e * 64 + mcol] = val;
+        }
     }
-
+    V4 sacc[2];
+    sacc[0] = V4{0.0, 0.0, 0.0, 0.0}; sacc[1] = V4{0.0, 0.0, 0.0, 0.0};
+    if (sw < NSEG) {
+        const double *Gs = lds + L::fKJJ + sw * D::JP;
+        const double *kjc = lds + L::oKJC + sw * 196, *kux = lds + L::oKUX + sw * 98;
+        const int li = lane & 15, lk = lane >> 4;
+        // K_JC fragment (ks, t) = K_JC[4 ks + lk][16 t + li] (rows >= 49, columns >= 28: zero), recomputed where it is used (a table of the
+        // 26 fragments was spilled while it was built): loads with safe indices, then selects
+        uint32_t jw[13];
+#pragma unroll
+        for (int ks = 0; ks < 13; ks++) { const int row = 4 * ks + lk; jw[ks] = pat->jc[row < 49 ? row : 0]; }
+        auto frag = [&](int ks, int t, int lkk, int lii) -> double {
+            const int row = 4 * ks + lkk, rs = row < 49 ? row : 0, col = 16 * t + lii;
+            double kq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) kq[q] = kjc[rs * 4 + q];
+            const double dv = kux[(rs < 7 ? rs : 0) * 14 + (lii < 14 ? lii : 0)];
+            double val = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) if ((int)((jw[ks] >> (8 * q)) & 255u) == col) val = kq[q];
+            if (t == 0 && rs < 7 && lii < 14) val = dv;
+            return (row < 49 && col < 28) ? val : 0.0;
+        };
+        auto products = [&](auto NTc) {
+            constexpr int nt = decltype(NTc)::value;
+            V4 e[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) e[mt] = V4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 13; ks++) {
+                int lkk = lk, lii = li;
+                asm volatile("" : "+v"(lkk), "+v"(lii) :: "memory");     // (opaque copies: the operand addresses are not computed ahead of their k-step, where they spilled)
+                const int k = 4 * ks + lkk;
+                double av[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const int i = 16 * mt + lii;
+                    const double g = -Gs[packed(i < 49 ? i : 0, k < 49 ? k : 0)];
+                    av[mt] = (i < 49 && k < 49) ? g : 0.0;
+                }
+                const double bf = frag(ks, nt, lkk, lii);
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) e[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mt], bf, e[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 13; ks++) {
+                int lkk = lk, lii = li;
+                asm volatile("" : "+v"(lkk), "+v"(lii) :: "memory");
+#pragma unroll
+                for (int mt2 = nt; mt2 < 2; mt2++)
+                    sacc[mt2] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag(ks, mt2, lkk, lii), e[ks >> 2][ks & 3], sacc[mt2], 0, 0, 0);
+            }
+        };
+        if (hf == 0) products(std::integral_constant<int, 0>());
+        else products(std::integral_constant<int, 1>());
+    }
     if (tid < 28) lds[L::oGu + tid] = lds[L::fKUU + tid];           // -(K_UU^-1), for the Schur complement
     __syncthreads();
     // interface block K_II + its diagonal
@@ -571,74 +619,21 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     }
     __syncthreads();
     FST(3);
-    // Schur complement S = K_II - sum_s K_CJ G_s K_JC - K_XU G_u K_UX: one column of K_JC at a time through the G rows in
-    // registers; even and odd segments in turn (neighbours share the diagonal block of their common interface node)
+    // the segment products leave the accumulators: tile (mt2, nt = hf) of the segment's 28 x 28 block, lower triangle; even and odd
+    // segments in turn (neighbours share the diagonal block of their common interface node)
     double *S = lds + L::fKJJ;
-    // a lane builds the K_JC entry of row 25 hf + lane (lane < 26) of the current column for its wave's half of the dot products
-    const int krow = 25 * hf + lane;
-    const bool kact = lane < 26 && krow < 49 && (hf == 1 || lane < 25);
-    const uint32_t jcw = kact ? pat->jc[krow] : 0xFFFFFFFFu;
-    const uint32_t cjl = lane < 28 ? pat->cjl[lane] : 0xFFFFFFFFu, cjh = lane < 28 ? pat->cjh[lane] : 0xFFFFFFFFu;
-    const double *kjc = lds + L::oKJC + (sw < NSEG ? sw : 0) * 196, *kux = lds + L::oKUX + (sw < NSEG ? sw : 0) * 98;
-    // (every load below is unconditional, with a safe index and a select afterwards: a load under a lane condition is not
-    //  speculated, and eight of them in a row were eight serial LDS round trips per column)
-    auto kjc_entry = [&](int r, int c) -> double {          // K_JC[r][c] of this wave's segment (r = the lane's row krow)
-        const int rs = kact ? r : 0;
-        double kq[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) kq[q] = kjc[rs * 4 + q];
-        const double dv = kux[(rs < 7 ? rs : 0) * 14 + (c < 14 ? c : 0)];
-        double val = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) if ((int)((jcw >> (8 * q)) & 255u) == c) val = kq[q];
-        if (rs < 7 && c < 14) val = dv;
-        return val;
-    };
-    auto kcj_dot = [&](int c, const double *eb) -> double {  // (K_CJ e)[c] of this wave's segment (c = own lane < 28); eb [49][2]: the two half products of e
-        double acc = 0.0;
-        {
-            double kq[8];
-            D2 ab[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t ref = ((q < 4 ? cjl : cjh) >> (8 * (q & 3))) & 255u;
-                const int rr = ref != 255u ? (int)ref : 0;
-                kq[q] = kjc[rr]; ab[q] = lds2(eb + 2 * (rr >> 2));
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t ref = ((q < 4 ? cjl : cjh) >> (8 * (q & 3))) & 255u;
-                if (ref != 255u) acc += kq[q] * (ab[q].x + ab[q].y);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);                   // (two batches of loads: 98 registers of temporaries at once spilled the G rows)
-        {
-            double ku[7];
-            D2 ab[7];
-            const int cs = c < 14 ? c : 0;
-#pragma unroll
-            for (int r = 0; r < 7; r++) { ku[r] = kux[r * 14 + cs]; ab[r] = lds2(eb + 2 * r); }
-            if (c < 14) {
-#pragma unroll
-                for (int r = 0; r < 7; r++) acc += ku[r] * (ab[r].x + ab[r].y);
-            }
-        }
-        return acc;
-    };
-    // Scratch behind S: [16][32] column halves, then [2][4][52][2] half products (double buffered over the columns: one barrier each).
     for (int ph = 0; ph < 2; ph++) {
-        const bool mine = sw < NSEG && (sw & 1) == ph;
-        double *colb = lds + L::fSW + wave * 32;
-        for (int c = 0; c < 28; c++) {
-            double *eb = lds + L::fSW + 512 + (c & 1) * 416 + (sw >> 1) * 104;
-            if (mine) {
-                if (lane < 32) colb[lane] = kact ? kjc_entry(krow, c) : 0.0;
-                wave_sync();
-                const double ev = g_dot_half(m, colb);
-                if (lane < 52) eb[2 * lane + hf] = lane < 49 ? ev : 0.0;
+        if (sw < NSEG && (sw & 1) == ph) {
+#pragma unroll
+            for (int mt2 = 0; mt2 < 2; mt2++) {
+                if (mt2 >= hf) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int R = 16 * mt2 + (lane >> 4) + 4 * r, C = 16 * hf + (lane & 15);
+                        if (R < 28 && C < 28 && R >= C) S[packed(14 * sw + R, 14 * sw + C)] -= sacc[mt2][r];
+                    }
+                }
             }
-            __syncthreads();
-            if (mine && hf == 0 && lane < 28 && lane >= c) S[packed(14 * sw + lane, 14 * sw + c)] -= kcj_dot(lane, eb);
         }
         __syncthreads();
     }
@@ -653,22 +648,6 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     }
     __syncthreads();
     FST(4);
-    // The G rows leave for the factor workspace NOW: the sweep of S below keeps 64 registers of tiles per thread, and with the 98
-    // of a row still live next to them the compiler spilled inside the sweep's 100+ steps (2.4 M cycles per factorisation).
-    double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
-    {
-        // row `lane` of G_s (or of G_u: lanes 56..62 of the last segment's wave), scattered into the block layout of g_blk: each of the
-        // segment's two waves writes its half of the columns
-        double *fg = fa + L::oFG + (size_t)(sw * 52) * 64 + (lane & ~3);
-        const int rpos = lane & 3;
-        if (hf == 0) {
-#pragma unroll
-            for (int j = 0; j < 25; j++) { const int mcol = j / 13, e = ((rpos ^ mcol) * 13 + j % 13); fg[e * 64 + mcol] = m[j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 27; j++) { const int c = 25 + j, mcol = c / 13, e = ((rpos ^ mcol) * 13 + c % 13); fg[e * 64 + mcol] = m[j]; }
-        }
-    }
     sweep(nI, 1, L::CB,
           [&](int, int i, int j) -> double { return S[packed(i, j)]; },
           [&](int, int i, int j, double val) { S[packed(i, j)] = val; });        // S <- -(S^-1)
