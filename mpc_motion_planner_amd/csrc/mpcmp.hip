@@ -607,10 +607,22 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
             for (int e = 0; e < E; e++) if (e != e_kap) tmax = std::max(tmax, t3.entry_ptr[e + 1] - t3.entry_ptr[e]);
             tab.entry_ptr.assign(EP, 0);
             tab.terms.assign((size_t)tmax * EP, 0xFFFFFFFFu);
-            for (int e = 0; e < E; e++) {
-                const int c = e == e_kap ? 0 : t3.entry_ptr[e + 1] - t3.entry_ptr[e];
-                tab.entry_ptr[e] = c;
-                for (int t = 0; t < c; t++) tab.terms[(size_t)t * EP + e] = t3.terms[t3.entry_ptr[e] + t];
+            // Slots instead of entries: inside each of the two assembly calls' ranges ([0, EA): everything but K_II; [EA, E): K_II) the
+            // entries are sorted by the length of their term lists, longest first, so that the 64 lanes of a wave (consecutive slots)
+            // walk lists of (nearly) equal length.  In entry order a wave executed every step of its longest list for all of its 10 - 13
+            // entries per lane: 140 term evaluations per lane for 32 terms.  tab.entry_ptr[slot] = count | entry << 8.
+            const int EA = e_kap + 1;
+            auto count_of = [&](int e) { return e == e_kap ? 0 : t3.entry_ptr[e + 1] - t3.entry_ptr[e]; };
+            for (int part = 0; part < 2; part++) {
+                const int lo = part ? EA : 0, hi = part ? E : EA;
+                std::vector<int> order(hi - lo);
+                for (int e = lo; e < hi; e++) order[e - lo] = e;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return count_of(a) > count_of(b); });
+                for (int k = 0; k < hi - lo; k++) {
+                    const int slot = lo + k, e = order[k], c = count_of(e);
+                    tab.entry_ptr[slot] = c | (e << 8);
+                    for (int t = 0; t < c; t++) tab.terms[(size_t)t * EP + slot] = t3.terms[t3.entry_ptr[e] + t];
+                }
             }
         }
         TRY(dalloc(ctx, &ctx->d_fac, (size_t)max_batch * narm * (cfg->num_seg == 6 ? Qp3<6>::FAC : Qp3<8>::FAC)));

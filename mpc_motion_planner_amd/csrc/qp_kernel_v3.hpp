@@ -312,10 +312,11 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
         if (e < D::EA) return lds + L::oKT + (e - D::eKT); \
         return lds + L::fKJJ + (e - D::eS); \
     }; \
-    /* Assembly of the entries [e0, e1) of K_0.  Term lists in ELL form: ws.entry_ptr[e] = number of terms, ws.terms[t * EP + e] \
-       (0xFFFFFFFF beyond an entry's list).  A thread owns up to NE entries and walks their lists together: per step the NE term \
-       words are loaded by independent, coalesced requests (one round trip to L2 per step, ~20 per call; entry after entry it \
-       was ~90 dependent round trips of 2 - 4 k cycles each while every workgroup of the launch reads the same table). */ \
+    /* Assembly of the entries of K_0 in the slots [e0, e1).  Term lists in ELL form over SLOTS (the entries of the range sorted by list \
+       length, longest first: mpcmp.hip): ws.entry_ptr[s] = number of terms | entry << 8, ws.terms[t * EP + s] (0xFFFFFFFF beyond a \
+       list).  A thread owns up to NE slots and walks their lists together: per step the NE term words are loaded by independent, \
+       coalesced requests (one round trip to L2 per step; entry after entry it was ~90 dependent round trips of 2 - 4 k cycles each \
+       while every workgroup of the launch reads the same table), and the lanes of a wave hold lists of equal length. */ \
     auto assemble = [&](int e0, int e1, auto ne_tag) { \
         constexpr int NE = decltype(ne_tag)::value; \
         constexpr int EP = (D::E + 63) / 64 * 64; \
@@ -323,7 +324,7 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
         double acc[NE]; \
         _Pragma("unroll") for (int i = 0; i < NE; i++) { \
             const int e = e0 + tid + i * NT; \
-            cnt[i] = e < e1 ? ws.entry_ptr[e] : 0; \
+            cnt[i] = e < e1 ? (ws.entry_ptr[e] & 255) : 0; \
             acc[i] = 0.0; \
         } \
         _Pragma("unroll") for (int i = 0; i < NE; i++) mymax = cnt[i] > mymax ? cnt[i] : mymax; \
@@ -332,7 +333,7 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
             _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; w[i] = ws.terms[t * EP + (e < e1 ? e : e0)]; } \
             _Pragma("unroll") for (int i = 0; i < NE; i++) if (t < cnt[i]) acc[i] += term_val(w[i]); \
         } \
-        _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; if (e < e1) *dst_of(e) = acc[i]; } \
+        _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; if (e < e1) *dst_of(ws.entry_ptr[e] >> 8) = acc[i]; } \
     }; \
     auto var_h = [&](int v, double &ha, double &rb, double &lo, double &hi) { \
         ha = 0.0; \
@@ -531,20 +532,19 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     const int sw = wave & 7, hf = wave >> 3;
     double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
     {
-        // G_s leaves for the factor workspace in the block layout of g_blk: row `lane` of G_s (or of G_u: lanes 56..62 of the last
-        // segment's wave), each of the segment's two waves writes one half of the columns
-        const bool isG = sw < NSEG && lane < 49, isGu = wave == NSEG - 1 && lane >= 56 && lane < 63;
+        // G_s leaves for the factor workspace in the block layout of g_blk ([segment][52 entries][64 lanes]: lane L keeps row L, entry
+        // ((L & 3) ^ mcol) * 13 + c % 13 of the lane (L & ~3) + mcol holds G[L][c], mcol = c / 13; lanes 56..62 of the last segment: G_u).
+        // Written entry by entry, 64 consecutive doubles per store (by row, a store touched 64 different cache lines: 90 k cycles);
+        // each of the segment's two waves writes one half of the entries.
         const double *Gs = lds + L::fKJJ + (sw < NSEG ? sw : 0) * D::JP, *Gu = lds + L::fKUU;
-        double *fg = fa + L::oFG + (size_t)(sw * 52) * 64 + (lane & ~3);
-        const int rpos = lane & 3, rowG = isG ? lane : 0, rowU = isGu ? lane - 56 : 0;
-        const int c0 = hf == 0 ? 0 : 25, c1 = hf == 0 ? 25 : 52;
+        double *fg = fa + L::oFG + (size_t)(sw * 52) * 64 + lane;
+        const int mcol = lane & 3, qb = lane & ~3;
 #pragma unroll 1
-        for (int c = c0; c < c1; c++) {                        // (a rolled loop: unrolled, its 27 independent loads and index chains were all hoisted and spilled)
-            const int cs = c < 49 ? c : 0, cu = c < 7 ? c : 0;
-            const double g = -Gs[packed(rowG, cs)], u = -Gu[packed(rowU, cu)];
-            const double val = (isG && c < 49) ? g : ((isGu && c < 7) ? u : 0.0);
-            const int mcol = c / 13, e = ((rpos ^ mcol) * 13 + c % 13);
-            fg[e * 64 + mcol] = val;
+        for (int e = 26 * hf; e < 26 * hf + 26; e++) {       // (a rolled loop: unrolled, its independent loads and index chains were all hoisted and spilled)
+            const int eq = e / 13, row = qb + (eq ^ mcol), c = mcol * 13 + e % 13;
+            const bool inG = sw < NSEG && row < 49 && c < 49, inU = sw == NSEG - 1 && row >= 56 && row < 63 && c < 7;
+            const double g = -Gs[packed(inG ? row : 0, inG ? c : 0)], u = -Gu[packed(inU ? row - 56 : 0, inU ? c : 0)];
+            fg[e * 64] = inG ? g : (inU ? u : 0.0);
         }
     }
     V4 sacc[2];
