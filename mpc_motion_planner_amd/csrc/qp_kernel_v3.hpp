@@ -328,9 +328,13 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
             acc[i] = 0.0; \
         } \
         _Pragma("unroll") for (int i = 0; i < NE; i++) mymax = cnt[i] > mymax ? cnt[i] : mymax; \
+        uint32_t wn[NE];                /* the words of step t + 1 are in flight while step t is evaluated (one L2 round trip per step otherwise) */ \
+        _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; wn[i] = ws.terms[e < e1 ? e : e0]; } \
         for (int t = 0; t < mymax; t++) { \
             uint32_t w[NE]; \
-            _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; w[i] = ws.terms[t * EP + (e < e1 ? e : e0)]; } \
+            _Pragma("unroll") for (int i = 0; i < NE; i++) w[i] = wn[i]; \
+            const int tn = t + 1 < mymax ? t + 1 : t; \
+            _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; wn[i] = ws.terms[tn * EP + (e < e1 ? e : e0)]; } \
             _Pragma("unroll") for (int i = 0; i < NE; i++) if (t < cnt[i]) acc[i] += term_val(w[i]); \
         } \
         _Pragma("unroll") for (int i = 0; i < NE; i++) { const int e = e0 + tid + i * NT; if (e < e1) *dst_of(ws.entry_ptr[e] >> 8) = acc[i]; } \
