@@ -446,12 +446,11 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
             }
         }
         __syncthreads();
-        const int npad = 4 * nt4;
-        for (int kb = 0; 4 * kb < npad; kb++) {
+        for (int kb = 0; 4 * kb < nb; kb++) {          // (pivots nb .. 4 nt4 - 1 are the identity padding: nothing to sweep)
 #pragma unroll
             for (int ka = 0; ka < 4; ka++) {
                 const int k = 4 * kb + ka;
-                if (k < npad) {
+                if (k < nb) {
                     const int k1a = (ka + 1) & 3, k1b = kb + (ka == 3 ? 1 : 0);
 #pragma unroll
                     for (int h = 0; h < NH; h++) {
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
                                 for (int a = 0; a < 4; a++) v[h][a][ka] = cI[a] * rd;
                                 if (Ib[h] == kb) v[h][ka][ka] = -rd;
                             }
-                            if (k + 1 < npad) {
+                            if (k + 1 < nb) {
                                 if (Jb[h] == k1b) {
 #pragma unroll
                                     for (int a = 0; a < 4; a++) nxt[4 * Ib[h] + a] = (diag[h] && a < k1a) ? v[h][k1a][a] : v[h][a][k1a];
