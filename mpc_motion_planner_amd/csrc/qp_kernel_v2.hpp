@@ -211,6 +211,9 @@ struct Qp2Ctx {
     double ts, tsT, rho_in, rho_eq, sigma, alpha;
 };
 
+#ifndef MPCMP_WPERM
+#define MPCMP_WPERM 0xFEDCBA9876543210ull
+#endif
 // what-if profiling (tools/ablate.py): -DMPCMP_ABL=n removes one role's work in one phase (results are then wrong); the
 // change in run time at a fixed iteration count is that piece's share of the critical path.  0 = product build.
 #ifndef MPCMP_ABL
@@ -839,7 +842,10 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, Qp2Stream
     constexpr int N = D::N, n = D::n, meq = D::meq, nJ = D::nJ, nI = D::nI, NT = L::NT;
     constexpr int GS = L::GS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, b = ws.perm[blockIdx.x];      // launch order: solver_kernels.hpp k_order
+    // logical wave of hardware wave w = nibble w of MPCMP_WPERM (hardware wave w runs on SIMD w % 4; the roles are wave ranges of
+    // the LOGICAL thread index, so the permutation decides which roles share a SIMD's issue slots)
+    const int tid = (int)((MPCMP_WPERM >> (4 * (threadIdx.x >> 6))) & 15ull) * 64 + (int)(threadIdx.x & 63);
+    const int b = ws.perm[blockIdx.x];      // launch order: solver_kernels.hpp k_order
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
     Qp2Ctx<NSEG> c;
     c.cfg = &cfg; c.ws = ws; c.lds = lds; c.tid = tid; c.b = b;

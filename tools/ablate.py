@@ -7,7 +7,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = {0: "product build", 1: "B: E (rows+vars)", 2: "A2: E (path rows)", 3: "B: A (rhs gather)", 4: "A1 wave0: T column sum",
-         5: "A2: P1 (r_I)", 6: "A1: P1 part of G b", 7: "B: P2 (S^-1 r)", 8: "A1: P3 (x_J)", 9: "A1: P2 part of G b", 11: "candidate build"}
+         5: "A2: P1 (r_I)", 6: "A1: P1 part of G b", 7: "B: P2 (S^-1 r)", 8: "A1: P3 (x_J)", 9: "A1: P2 part of G b", 11: "candidate build",
+         20: "wave order: identity", 21: "wave order: light B pair + light A1 share a SIMD", 22: "wave order: three heavy B on one SIMD (control)",
+         23: "wave order: candidate 3", 24: "wave order: candidate 4", 25: "wave order: candidate 5"}
+WPERM = {20: "0xFEDCBA9876543210ull", 21: "0xFDCBEA9875436210ull", 22: "0x76FEDA98C543B210ull",
+         23: os.environ.get("WPERM23", "0xFEDCBA9876543210ull"), 24: os.environ.get("WPERM24", "0xFEDCBA9876543210ull"), 25: os.environ.get("WPERM25", "0xFEDCBA9876543210ull")}
 which = [int(a) for a in sys.argv[1:]] or sorted(NAMES)
 B = 1024
 import mpc_motion_planner_amd.capi as capi
@@ -16,7 +20,7 @@ from mpc_motion_planner_amd import scenarios
 for n in which:
     so = os.path.join(ROOT, "tools", "micro", "libabl%d.bin" % n)
     if not os.path.exists(so):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMPCMP_ABL=%d" % n,
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *(["-DMPCMP_WPERM=" + WPERM[n]] if n in WPERM else ["-DMPCMP_ABL=%d" % n]),
                                "-o", so, os.path.join(ROOT, "mpc_motion_planner_amd", "csrc", "mpcmp.hip")])
 if "--build-only" in os.environ.get("ABLATE_MODE", ""):
     sys.exit(0)
