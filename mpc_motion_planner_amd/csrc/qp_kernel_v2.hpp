@@ -844,7 +844,8 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, Qp2Stream
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // logical wave of hardware wave w = nibble w of MPCMP_WPERM (hardware wave w runs on SIMD w % 4; the roles are wave ranges of
     // the LOGICAL thread index, so the permutation decides which roles share a SIMD's issue slots)
-    const int tid = (int)((MPCMP_WPERM >> (4 * (threadIdx.x >> 6))) & 15ull) * 64 + (int)(threadIdx.x & 63);
+    const int tid = (MPCMP_WPERM == 0xFEDCBA9876543210ull) ? (int)threadIdx.x
+                                                            : (int)((MPCMP_WPERM >> (4 * (threadIdx.x >> 6))) & 15ull) * 64 + (int)(threadIdx.x & 63);
     const int b = ws.perm[blockIdx.x];      // launch order: solver_kernels.hpp k_order
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
     Qp2Ctx<NSEG> c;

@@ -6,9 +6,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 TMP=$(mktemp -d)
 git show HEAD:mpc_motion_planner_amd/csrc/qp_kernel_v2.hpp > "$TMP/qp_kernel_v2.hpp"
-cp mpc_motion_planner_amd/csrc/{mpcmp.hip,solver_kernels.hpp,rbd_device.hpp,structure.hpp,kinematics_host.hpp} "$TMP/"
+for f in mpc_motion_planner_amd/csrc/*.hpp mpc_motion_planner_amd/csrc/mpcmp.hip; do [ "$(basename $f)" = qp_kernel_v2.hpp ] || cp "$f" "$TMP/"; done
 mkdir -p "$TMP/../include_ab" && true
-( cd "$TMP" && sed -i 's|"../../include/mpcmp.h"|"'"$ROOT"'/include/mpcmp.h"|' mpcmp.hip rbd_device.hpp kinematics_host.hpp && \
+( cd "$TMP" && sed -i 's|"../../include/mpcmp.h"|"'"$ROOT"'/include/mpcmp.h"|' mpcmp.hip *.hpp && \
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o "$ROOT/tools/micro/libabl0.bin" mpcmp.hip ) &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o tools/micro/libabl11.bin mpc_motion_planner_amd/csrc/mpcmp.hip &
 wait
