@@ -73,6 +73,20 @@ def committed_traffic(kname, problems_per_launch):
     return None, None
 
 
+def committed_mfma(workload):
+    """MFMA counters of the factorisation kernel k_qp3f (its Schur complement products run on the matrix cores) from the committed
+    rocprofv3 PMC pass (profiles/r02_mfma.json); None for the N = 13 path, whose kernel k_qp2 issues no MFMA"""
+    try:
+        mj = json.load(open(os.path.join(ROOT, "profiles", "r02_mfma.json")))
+        e = mj.get(workload)
+        if e is None:
+            return None
+        return {"kernel": mj["kernel"], "insts_mfma_per_launch": e["SQ_INSTS_MFMA"], "mfma_busy_cycles_per_launch": e["SQ_VALU_MFMA_BUSY_CYCLES"],
+                "busy_frac_of_simd_time": e.get("mfma_busy_frac_of_simd_time"), "source": "profiles/r02_mfma.json"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(nseg, sqp, x0, xf, warm, n_multi, n_single):
     """Time the CPU oracle (same algorithm, same warm start; oracle/liboracle.so, C -O3) on a bounded sample of the same
     workload: (i) one thread = the reference's execution model (examples/benchmark.cpp:16), (ii) a pthread pool over
@@ -302,6 +316,7 @@ def main():
                          "executed_frac": (executed / FP64_PEAK_TFLOPS) if executed is not None else None,
                          "peak_measured": peak_meas, "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None,
                          "traffic": traffic, "mfma_busy": 0.0 if mfma_busy is None else mfma_busy,
+                         "mfma_factor_kernel": committed_mfma(args.workload),
                          "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts, "problems_per_launch": problems_per_launch,
                          "canonical_gflop_per_launch": flops_launch / 1e9,
                          "per_launch_tflops": flops_launch / k_avg_s / 1e12 if k_avg_s > 0 else None,
@@ -310,7 +325,8 @@ def main():
                                  "peak_gbs": HBM_PEAK_GBS, "frac": alg_bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS if k_avg_s > 0 else None},
                          "note": "achieved = canonical dense-equivalent FP64 flops (SURVEY.md 8d) of the QP kernel per GPU over the wall clock of the "
                                  "timed region; `launches_in_flight` launches overlap, so avg_launch_ms is not exclusive GPU time; executed_frac counts "
-                                 "the FMAs the ISA executes; mfma_busy is 0 because the kernel issues no MFMA (one right-hand side per problem)"},
+                                 "the FMAs the ISA executes; mfma_busy is that of the dominant kernel (the ADMM loop has one right-hand side per problem and issues no MFMA); "
+                                 "for N >= 19 the factorisation kernel k_qp3f runs the QP's block GEMMs (Schur complement products) on the matrix cores: mfma_factor_kernel"},
             "quality": {"status_ok_frac": float((inf["status"] == 0).mean()), "feasible_frac": float(feasible.mean()),
                         "T_mean": float(inf["T"].mean()),
                         "defect_inf_median": float(np.median(inf["defect_inf"])),

@@ -110,6 +110,7 @@ def run(args, rank, world, local, dist):
                      "executed_frac": per_gpu * 2.0 * narm * (admm_mean * Bn.EXECUTED_FMA[nseg][0] + sqp * Bn.EXECUTED_FMA[nseg][1]) / 1e12 / Bn.FP64_PEAK_TFLOPS,
                      "peak_measured": peak_meas,
                      "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None, "traffic": None, "mfma_busy": 0.0,
+                     "mfma_factor_kernel": Bn.committed_mfma("dual14"),
                      "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts,
                      "problems_per_launch": B / parts, "workgroups_per_problem": 2,
                      "canonical_gflop_per_traj": flops_traj / 1e9, "admm_iters_per_traj": admm_mean,
