@@ -321,6 +321,36 @@ def test_headline_configuration_full_size(M):
         assert info["qp_iters_total"][b] == oi.qp_iters_total
 
 
+def test_reference_as_shipped_configuration_full_size(M):
+    """BASELINE.json configs[0] depth at batch size (1024 problems, N = 19, 2 SQP iterations: robot_ocp.hpp:32, motionPlanner.cpp:15) from
+    the jerk-limited warm start, through k_qp3f (Schur products on the matrix cores) + k_qp3: every problem reported ok, bitwise
+    reproducible, independent of the batch a problem travels in, and oracle parity on a sample."""
+    cfg, ocfg = _cfgs(M, 6, 2)
+    from mpc_motion_planner_amd import scenarios
+    lim = M.default_limits()
+    margins = (0.9, 0.9, 0.5, 0.9)
+    vmax, amax, jmax = margins[1] * lim["vmax"], margins[2] * lim["amax"], 0.1 * lim["jmax"]
+    B = 1024
+    x0, xf = scenarios.make_batch(B)
+    s = M.Solver(cfg, B)
+    warm = s.warm_start_jerk(x0, xf, jmax)
+    sx, su, sT, info = s.solve(x0, xf, warm)
+    assert np.all(info["status"] == 0) and np.all(np.isfinite(sx)) and np.all(np.isfinite(su)) and np.all(np.isfinite(sT))
+    assert np.all(info["sqp_iters"] == 2) and np.all(info["qp_iters_total"] <= 2 * 700) and np.all(info["qp_iters_total"] >= 2 * 25)
+    assert (sT > 0).mean() >= 0.99
+    sx2, su2, sT2, info2 = s.solve(x0, xf, warm)
+    assert np.array_equal(sx, sx2) and np.array_equal(su, su2) and np.array_equal(sT, sT2)
+    assert np.array_equal(info["qp_iters_total"], info2["qp_iters_total"])
+    sub = np.arange(700, 764)                                     # the same problems as a small batch of their own
+    sxs, _, sTs, _ = s.solve(x0[sub], xf[sub], tuple(w[sub] for w in warm))
+    assert np.array_equal(sTs, sT[sub]) and np.array_equal(sxs, sx[sub])
+    for b in (0, 511, 512, 1023):
+        xg, ug, Tg = o.warm_start_jerk(6, vmax, amax, jmax, x0[b], xf[b])
+        xs, us, T, oi = o.solve(ocfg, x0[b], xf[b], xg, ug, Tg)
+        assert abs(sT[b] - T) <= 1e-6 * abs(T) and np.abs(sx[b] - xs).max() <= 1e-6 and np.abs(su[b] - us).max() <= 1e-5
+        assert info["qp_iters_total"][b] == oi.qp_iters_total
+
+
 def test_jerk_limited_warm_start_vs_oracle_and_stored_ruckig(M, golden_dir):
     """the generator that stands in for Ruckig (motionPlanner.cpp:146-175): HIP kernel vs the oracle's restatement on random
     state pairs, vs the reference's stored Ruckig trajectory, and as the warm start of a solve"""
