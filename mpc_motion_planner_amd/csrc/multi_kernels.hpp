@@ -45,7 +45,7 @@ __device__ __forceinline__ void arm_box(const mpcmp_config &c, const double *x0a
 // Linearisation of one arm's nodes: zl = the arm's block of the iterate (LDS), T the final time.  Writes g [8N], Gk [N][8][22],
 // ceq [14(N-1)] (global).  scr: N*14 + N*147 doubles of LDS.
 template <int NSEG, int NT>
-__device__ __forceinline__ void linearise_arm(const mpcmp_config &cfg, const mpcmp_model *__restrict__ mdl, const double *zl, double T,
+__device__ __forceinline__ void linearise_arm(const mpcmp_config &cfg, const mpcmp_model *__restrict__ mdl_, const double *zl, double T,
                                               double *scr, double *g_out, double *Gk_out, double *ceq_out, int tid) {
     constexpr int N = 3 * NSEG + 1;
     double *sc = scr, *raw = scr + N * 14;
@@ -57,6 +57,10 @@ __device__ __forceinline__ void linearise_arm(const mpcmp_config &cfg, const mpc
     __syncthreads();
 #pragma nounroll
     for (int t = tid; t < N * 22; t += NT) {
+        // (an opaque copy of the model pointer per pass: the ~180 model constants of the recursion are otherwise hoisted out of the loop
+        //  as invariants and spilled - 1.7 KB of scratch per lane; with it they are scalar loads inside the pass)
+        const mpcmp_model *mdl = mdl_;
+        asm volatile("" : "+s"(mdl));
         const int k = t / 22, d = t % 22;
         const double *q_sc = sc + 14 * k;
         const double *v = zl + 14 * k + 7, *a = zl + 14 * N + 7 * k;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(512) void k_step_m(mpcmp_config cfg, const mpcmp_mo
 #pragma nounroll
     for (int a = 0; a < NARM; a++) {
         const double *za = zl + a * na, *pa = pl + a * na;
-        const mpcmp_model *mdl = models + a;
+        const mpcmp_model *mdl_a = models + a;
         for (int t = tid; t < ntr * N * 7; t += NT) {
             const int tr = t / (N * 7), kj = t % (N * 7), k = kj / 7, j = kj % 7;
             double al = 1.0;
@@ -267,6 +271,8 @@ __global__ __launch_bounds__(512) void k_step_m(mpcmp_config cfg, const mpcmp_mo
         __syncthreads();
 #pragma nounroll
         for (int t = tid; t < ntr * N; t += NT) {
+            const mpcmp_model *mdl = mdl_a;                 // (opaque per pass: see linearise_arm)
+            asm volatile("" : "+s"(mdl));
             const int tr = t / N, k = t % N;
             double al = 1.0;
             for (int q = 0; q < tr; q++) al *= cfg.ls_tau;
