@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 so = os.path.join(ROOT, "gpurun_out", "libmpcmp_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMPCMP_STAMPS", *os.environ.get("MPCMP_EXTRA_DEFS", "").split(),
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-DMPCMP_STAMPS", *os.environ.get("MPCMP_EXTRA_DEFS", "").split(),
                        "-o", so, os.path.join(ROOT, "mpc_motion_planner_amd", "csrc", "mpcmp.hip")])
 import mpc_motion_planner_amd.capi as capi
 capi._SO = so
