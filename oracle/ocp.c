@@ -367,6 +367,9 @@ static int admm(const orc_config *c, work *w, double *x, double *y, int *status)
     memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * mn);
     const double sigma = c->sigma, alpha = c->alpha;
     int it = 0;
+    double rho_cur = c->rho;
+    const char *adapt_env = getenv("ORC_ADAPT");
+    const double adapt_tol = adapt_env ? atof(adapt_env) : 0.0;
     *status = 0;
     if (factor(c, w)) { *status = 2; goto done; }
     for (it = 1; it <= c->qp_iters; it++) {
@@ -401,6 +404,22 @@ static int admm(const orc_config *c, work *w, double *x, double *y, int *status)
             double mx = nHx > nAty ? nHx : nAty; if (mx < 1.0) mx = 1.0;   /* ||q||_inf = 1 */
             double ed = c->eps_abs + c->eps_rel * mx;
             if (rp <= ep && rd <= ed) break;
+            if (adapt_tol > 0.0) {
+                /* HYPOTHESIS PROBE (tools/polympc_adaptive_rho_probe.py; off unless ORC_ADAPT=<tolerance> is set): OSQP's adaptive rho,
+                   rho <- rho sqrt((r_p / max(|Ax|,|z|)) / (r_d / max(|Hx|,|A^T y|,|q|))), applied with a refactorisation when it
+                   changes by more than the tolerance.  polympc is absent, so whether its boxADMM adapts rho cannot be read; against
+                   the reference's stored solve the probe is 3x - 50x worse than a fixed rho: not adopted. */
+                double pn = rp / ((nAx > nz ? nAx : nz) + 1e-10), dn = rd / (mx + 1e-10);
+                double est = rho_cur * sqrt(pn / (dn + 1e-10));
+                if (est < 1e-6) est = 1e-6;
+                if (est > 1e6) est = 1e6;
+                if (est > rho_cur * adapt_tol || est < rho_cur / adapt_tol) {
+                    const double f = est / rho_cur;
+                    for (int i = 0; i < mn; i++) w->rho[i] *= f;
+                    rho_cur = est;
+                    if (factor(c, w)) { *status = 2; break; }
+                }
+            }
         }
     }
     if (it > c->qp_iters) it = c->qp_iters;
