@@ -23,6 +23,16 @@
 #include "kinematics_host.hpp"
 #include "jerk_device.hpp"
 
+#ifdef MPCMP_SPLIT_N25
+// the N = 25 kernels live in qp3_n25.hip (built with another scheduler strategy: see there)
+namespace mpcmp {
+extern template __global__ void k_qp3f<8, 1>(mpcmp_config, WS, const Qp3Pat *, Xch, int, double *);
+extern template __global__ void k_qp3f<8, 2>(mpcmp_config, WS, const Qp3Pat *, Xch, int, double *);
+extern template __global__ void k_qp3<8, 1>(mpcmp_config, WS, const Qp3Pat *, Xch, int, const double *);
+extern template __global__ void k_qp3<8, 2>(mpcmp_config, WS, const Qp3Pat *, Xch, int, const double *);
+}  // namespace mpcmp
+#endif
+
 using namespace mpcmp;
 
 struct mpcmp_ctx {

@@ -18,7 +18,7 @@
 namespace mpcmp {
 
 // cubic Chebyshev-Gauss-Lobatto differentiation matrix on ascending nodes {-1,-1/2,1/2,1}
-__device__ __constant__ double c_D[16] = {-19.0 / 6, 4.0, -4.0 / 3, 0.5,  -1.0, 1.0 / 3, 1.0, -1.0 / 3,
+static __device__ __constant__ double c_D[16] = {-19.0 / 6, 4.0, -4.0 / 3, 0.5,  -1.0, 1.0 / 3, 1.0, -1.0 / 3,
                                           1.0 / 3, -1.0, -1.0 / 3, 1.0,  -0.5, 4.0 / 3, -4.0, 19.0 / 6};
 
 struct WS {
@@ -900,6 +900,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
     }
 }
 
+#ifndef MPCMP_V3_TU     /* (the leaf kernels below are not templates: they belong to the main translation unit only) */
 // ------------------------------------------------------------------------------------------------
 // leaf kernels
 __global__ __launch_bounds__(64) void k_rnea_batch(const mpcmp_model *mdl, int n, const double *q, const double *v, const double *a,
@@ -1116,5 +1117,7 @@ __global__ __launch_bounds__(256) void k_traj_stats(const mpcmp_model *mdl, int 
     __syncthreads();
     if (tid < 4) o[70 + tid] = (double)fl[tid];
 }
+
+#endif  /* MPCMP_V3_TU */
 
 }  // namespace mpcmp
