@@ -173,8 +173,9 @@ struct Qp2 {
     static constexpr int oWg = oXx + D::N * XS;                // [m]          w = rho z - y   (general rows)
     static constexpr int oYs = oWg + D::m;                     // [m]          y (termination tests)
     static constexpr int oTp = oYs + D::m;                     // [m]          coefT_r * w_r
-    static constexpr int oMisc = oTp + D::m;                   // [8]  0: zero slot, 1: T base, 2: T column sum, 3: sum|ha|
-    static constexpr int oRed = oMisc + 8;                     // [NW*8]
+    static constexpr int oMisc = oTp + D::m;                   // [16] 0: zero slot, 1: T base, 2: T column sum, 3: sum|ha|, 6..7 and 8..13: write-only pad slots (unconditional stores of lanes without an output)
+    static constexpr int oRed = oMisc + 16;                    // [NW*8]
+    static_assert(oMisc % 2 == 0, "16-byte stores into the pad slots");
     // factor area (must match build_streams): S | KJJ[NSEG] | KJC[HS] | Eh[HS] | scratch[32] | rdv[8]
     static constexpr int oS = oRed + NW * 8;                   // packed S, then -(S^-1)
     static constexpr int oKJJ = oS + D::SP;                    // [NSEG][JP]
@@ -295,6 +296,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         const int v = c.ws.ext_of_int[49 * seg + 2 * lp + part];
         jdst = v < 14 * N ? (v / 14) * XS + v % 14 : ((v - 14 * N) / 7) * XS + 14 + (v - 14 * N) % 7;
     }
+    double *xw = jdst >= 0 ? xn + jdst : misc + 7;     // unconditional store of x_J (exec masking costs more than the store)
     const double *bj = rhsJ + 56 * seg + 14 * part;
     // 16-byte reads of x_C: pairs 0,1 at xa, xa+2; pair 2 at xc3; pair 3 at xb
     const double *xn0 = xn + 3 * seg * XS, *xn1 = xn0 + 3 * XS;
@@ -366,7 +368,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
                 a0 += e1[0][2 * j + 1] * xv[j].y; a1 += e1[1][2 * j + 1] * xv[j].y;
             }
             const double aq = quad_sum2(a0, a1);         // (E_s x_C)[own row]
-            if (jdst >= 0) xn[jdst] = tq - aq;
+            *xw = tq - aq;                                 // (lanes without a row: the write-only pad slot)
         }
         BUSY_SYNC(3);
         STAMP2(6);
@@ -447,6 +449,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     const int rdst = (lig < 2 && irow >= 0 && (lig == 0 || ec1 >= 0)) ? irow + lig : -1;
     const int xoff = (rdst == D::nI - 1) ? L::oMisc + 2 : L::oMisc;
     const int rsrc = rdst >= 0 ? rdst : 0;
+    double *rw = rdst >= 0 ? rI + rdst : lds + L::oMisc + 6;
     // path rows: the row constants live in LDS (lane-transposed), only the ADMM state (z, y) of the owned row stays in registers
     const bool isPath = et < 16 * N;                    // four lanes per pair of path rows (six columns each)
     const int pk = et >> 4, prp = (et & 15) >> 2, pq = et & 3;
@@ -473,6 +476,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     // z~ of the owned row (lanes 0,1 of the quad) and, from the same Jacobian operands, this node's path-row part of
     // A^T w: every lane forms its six columns of g_row0*w0 + g_row1*w1, the four row pairs of the node (lane bits 2,3 of
     // the DPP row) are summed with two row rotations, and the lanes of pair 0 publish the node's 24 padded columns.
+    double *padw = lds + L::oMisc + 8;                  // 48 bytes of write-only pad
     auto path_rows = [&](const D2 (&p0)[3], const D2 (&p1)[3], const double *xe, double *gdst, auto &&row_update) -> double {
         const double *xv = xe + xnoff;
         D2 x2[3];
@@ -492,7 +496,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             double cx = p0[j].x * w0 + p1[j].x * w1, cy = p0[j].y * w0 + p1[j].y * w1;
             cx += dpp_mov<0x128>(cx); cy += dpp_mov<0x128>(cy);             // row_ror:8
             cx += dpp_mov<0x124>(cx); cy += dpp_mov<0x124>(cy);             // row_ror:4
-            if (prp == 0) { D2 o; o.x = cx; o.y = cy; *reinterpret_cast<D2 *>(gdst + xnoff + 2 * j) = o; }
+            { D2 o; o.x = cx; o.y = cy; *reinterpret_cast<D2 *>((prp == 0 ? gdst + xnoff : padw) + 2 * j) = o; }   // (pairs 1..3 of a node: pad)
         }
         return ax;
     };
@@ -519,7 +523,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
             double sq = quad_sum2(a0, a1);                  // even lanes: row ec0, odd lanes: row ec1
             sq += f8 * dpp_xor4(sq);                        // 8-lane groups: the other segment's quad
             sq += f16 * dpp_mov<0x128>(sq);                 // the T group of 16: row_ror:8 = lane ^ 8
-            if (rdst >= 0) rI[rdst] = (bI0 + bI1) - sq;
+            *rw = (bI0 + bI1) - sq;                         // (other lanes: a write-only pad slot)
         }
         BUSY_SYNC(1);
         // ---- P2 (role B) ----
@@ -690,6 +694,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             }
         }
     }
+    double *xiw = (myIrow >= 0 && myIrow != nI - 1) ? xn + xdst : lds + L::oMisc + 7;
     // A^T w restricted to this variable's column: the path-row part is formed by role A2 (gp, node-major like x~), the
     // dynamics-row part is gathered here
     auto col_gather = [&](const double *w, const double *gp) -> double {
@@ -750,7 +755,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             }
             double xi = quad_sum2(a0, a1);                 // even lanes: row 2 rp2, odd lanes: row 2 rp2 + 1
             xi += dpp_xor4(xi);
-            if (myIrow >= 0 && myIrow != nI - 1) xn[xdst] = xi;
+            *xiw = xi;                                     // (lanes without an output row, and the T row: the write-only pad slot)
             if (rp2 == (nI - 1) / 2 && (part2 & 1) == ((nI - 1) & 1)) {
                 // x_T is replicated (slot 21 of every node row): the four lanes of its group that hold it share the writes
 #pragma unroll
