@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                         bp += wv_ * r;
                     }
                 }
-                if (L::P8) { bp = sum8(bp); if ((lane & 7) == 0) redB[8 * wave + (lane >> 3)] = bp; }
+                if (L::P8) { bp = sum8(bp); redB[8 * wave + (lane >> 3)] = bp; }      // (all eight lanes of a group hold the sum and store it: no exec mask at the end of the phase)
                 else { bp = wave_sum(bp); if (lane == 0) redB[wave] = bp; }      // (valid in lanes 0..15)
             }
             const LaneC1 c1 = lane_c1(sio);
@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     zz = zn;
                     s1x[sio] = xx; s1z[sio] = zz; s1y[sio] = yy;
                 }
-                if (L::P8) { tp = sum8(tp); if ((lane & 7) == 0) redT[8 * wave + (lane >> 3)] = tp; }
+                if (L::P8) { tp = sum8(tp); redT[8 * wave + (lane >> 3)] = tp; }
                 else { tp = wave_sum(tp); if (lane == 0) redT[wave] = tp; }      // (read by the next iteration's P1: two barriers away)
                 if (sio == 511) {       // the shared variable T: replicated in the arm workgroups of the OCP, identical arithmetic
                     const double xtv = xt[21], rb = misc[L::M_rbT];
