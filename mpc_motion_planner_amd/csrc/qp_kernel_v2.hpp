@@ -757,13 +757,15 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
             xi += dpp_xor4(xi);
             *xiw = xi;                                     // (lanes without an output row, and the T row: the write-only pad slot)
             if (rp2 == (nI - 1) / 2 && (part2 & 1) == ((nI - 1) & 1)) {
-                // x_T is replicated (slot 21 of every node row): the four lanes of its group that hold it share the writes
-#pragma unroll
-                for (int q = 0; q < (N + 3) / 4; q++) { if ((part2 >> 1) + 4 * q < N) xn[((part2 >> 1) + 4 * q) * XS + 21] = xi; }
+                // x_T is replicated (slot 21 of every node row).  Here, at the end of this role's critical chain, only the copies role
+                // A1 reads in P3 (nodes 3, 6, ..: one store per lane of the group); the other nodes' copies are made in P3, below
+                const int nd = 3 * (1 + (part2 >> 1));
+                if (nd < N) xn[nd * XS + 21] = xi;
             }
         }
         BUSY_SYNC(2);
-        // ---- P3: (group A); this role is idle: fetch the constant operands of the E phase ----
+        // ---- P3: (group A); this role is idle: the remaining copies of x_T, and the constant operands of the E phase ----
+        if (u < N && (u % 3 != 0 || u == 0)) xn[u * XS + 21] = xn[3 * XS + 21];
         const double rc[4] = {rcl[0], rcl[1], rcl[2], rcl[3]};
         const double vrbi = vcl[12 * L::NB], vlb = vcl[10 * L::NB], vub = vcl[11 * L::NB];
         BUSY_SYNC(3);
