@@ -19,6 +19,7 @@
 #include "solver_kernels.hpp"
 #include "qp_kernel_v2.hpp"
 #include "qp_kernel_v3.hpp"
+#include "qp_kernel_v4.hpp"
 #include "multi_kernels.hpp"
 #include "kinematics_host.hpp"
 #include "jerk_device.hpp"
@@ -61,6 +62,10 @@ struct mpcmp_ctx {
     Qp3Pat *d_pat = nullptr;       // sparse K_JC pattern of k_qp3 (num_seg 6, 8), device copy
     double *d_fac = nullptr;       // factor workspace of k_qp3f -> k_qp3: [max_batch][narm][Qp3::FAC]
     Xch xch{nullptr};              // arm-to-arm exchange slots (multi-arm contexts)
+    // num_seg 4: second set of structure tables (structure3.hpp order, T bordered out) for the E-free QP kernels (k_qp3f + k_qp4 / k_qp3)
+    int *d3_ext_of_int = nullptr, *d3_entry_ptr = nullptr;
+    uint32_t *d3_terms = nullptr;
+    int qp13 = 2;                  // QP kernel of num_seg 4: 2 = k_qp2, 3 = k_qp3f + k_qp3, 4 = k_qp3f + k_qp4 (env MPCMP_QP13)
     // timing of the dominant kernel (k_qp)
     struct EvPair { hipEvent_t e[2]; };
     std::vector<EvPair> ev;          // at most MAX_EV pairs are ever created; launches beyond that are not timed until the
@@ -602,42 +607,47 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
     HIPTRY(hipMemcpy(ctx->d_model, mdl, sizeof(mpcmp_model) * narm, hipMemcpyHostToDevice));
     ctx->model = mdl[0];
     StructureTables tab;
-    if (cfg->num_seg >= 6) {        // k_qp3: per-arm tables with T bordered out (structure3.hpp)
+    // k_qp3 / k_qp4: per-arm tables with T bordered out (structure3.hpp), in ELL form
+    auto build_v3 = [&](int nseg, StructureTables &tb, Qp3Pat &pat) -> bool {
         Tables3 t3;
-        if (!build_tables3(cfg->num_seg, t3)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
-        tab.nseg = t3.nseg; tab.ext_of_int = t3.ext_of_int;
+        if (!build_tables3(nseg, t3)) return false;
+        tb.nseg = t3.nseg; tb.ext_of_int = t3.ext_of_int; pat = t3.pat;
         // term lists in ELL form [term index][entry] (entry stride padded to 64): consecutive threads assemble consecutive entries,
         // so every load of a term word is one coalesced 256-byte request per wave (the per-entry lists of the CSR form cost a
         // cache line per 4-byte word, and every workgroup of the launch reads the same table: 0.47 M cycles per factorisation)
-        {
-            const int E = (int)t3.entry_ptr.size() - 1, EP = (E + 63) / 64 * 64;
-            // (kappa, the (T, T) entry, has one term per row of A: the kernel sums it by a workgroup reduction instead)
-            const int e_kap = cfg->num_seg == 6 ? Dim3<6>::eKap : Dim3<8>::eKap;
-            int tmax = 0;
-            for (int e = 0; e < E; e++) if (e != e_kap) tmax = std::max(tmax, t3.entry_ptr[e + 1] - t3.entry_ptr[e]);
-            tab.entry_ptr.assign(EP, 0);
-            tab.terms.assign((size_t)tmax * EP, 0xFFFFFFFFu);
-            // Slots instead of entries: inside each of the two assembly calls' ranges ([0, EA): everything but K_II; [EA, E): K_II) the
-            // entries are sorted by the length of their term lists, longest first, so that the 64 lanes of a wave (consecutive slots)
-            // walk lists of (nearly) equal length.  In entry order a wave executed every step of its longest list for all of its 10 - 13
-            // entries per lane: 140 term evaluations per lane for 32 terms.  tab.entry_ptr[slot] = count | entry << 8.
-            const int EA = e_kap + 1;
-            auto count_of = [&](int e) { return e == e_kap ? 0 : t3.entry_ptr[e + 1] - t3.entry_ptr[e]; };
-            for (int part = 0; part < 2; part++) {
-                const int lo = part ? EA : 0, hi = part ? E : EA;
-                std::vector<int> order(hi - lo);
-                for (int e = lo; e < hi; e++) order[e - lo] = e;
-                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return count_of(a) > count_of(b); });
-                for (int k = 0; k < hi - lo; k++) {
-                    const int slot = lo + k, e = order[k], c = count_of(e);
-                    tab.entry_ptr[slot] = c | (e << 8);
-                    for (int t = 0; t < c; t++) tab.terms[(size_t)t * EP + slot] = t3.terms[t3.entry_ptr[e] + t];
-                }
+        const int E = (int)t3.entry_ptr.size() - 1, EP = (E + 63) / 64 * 64;
+        // (kappa, the (T, T) entry, has one term per row of A: the kernel sums it by a workgroup reduction instead)
+        const int e_kap = nseg * 1225 + 28 + nseg * 196 + nseg * 98 + 98 + 21 * (3 * nseg + 1);      // Dim3<nseg>::eKap
+        int tmax = 0;
+        for (int e = 0; e < E; e++) if (e != e_kap) tmax = std::max(tmax, t3.entry_ptr[e + 1] - t3.entry_ptr[e]);
+        tb.entry_ptr.assign(EP, 0);
+        tb.terms.assign((size_t)tmax * EP, 0xFFFFFFFFu);
+        // Slots instead of entries: inside each of the two assembly calls' ranges ([0, EA): everything but K_II; [EA, E): K_II) the
+        // entries are sorted by the length of their term lists, longest first, so that the 64 lanes of a wave (consecutive slots)
+        // walk lists of (nearly) equal length.  In entry order a wave executed every step of its longest list for all of its 10 - 13
+        // entries per lane: 140 term evaluations per lane for 32 terms.  tb.entry_ptr[slot] = count | entry << 8.
+        const int EA = e_kap + 1;
+        auto count_of = [&](int e) { return e == e_kap ? 0 : t3.entry_ptr[e + 1] - t3.entry_ptr[e]; };
+        for (int part = 0; part < 2; part++) {
+            const int lo = part ? EA : 0, hi = part ? E : EA;
+            std::vector<int> order(hi - lo);
+            for (int e = lo; e < hi; e++) order[e - lo] = e;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return count_of(a) > count_of(b); });
+            for (int k = 0; k < hi - lo; k++) {
+                const int slot = lo + k, e = order[k], c = count_of(e);
+                tb.entry_ptr[slot] = c | (e << 8);
+                for (int t = 0; t < c; t++) tb.terms[(size_t)t * EP + slot] = t3.terms[t3.entry_ptr[e] + t];
             }
         }
-        TRY(dalloc(ctx, &ctx->d_fac, (size_t)max_batch * narm * (cfg->num_seg == 6 ? Qp3<6>::FAC : Qp3<8>::FAC)));
+        return true;
+    };
+    auto fac_doubles = [](int nseg) -> size_t { return nseg == 4 ? std::max<size_t>(Qp3<4>::FAC, Qp4Fac<4>::FAC) : (nseg == 6 ? Qp3<6>::FAC : Qp3<8>::FAC); };
+    if (cfg->num_seg >= 6) {
+        Qp3Pat pat;
+        if (!build_v3(cfg->num_seg, tab, pat)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
+        TRY(dalloc(ctx, &ctx->d_fac, (size_t)max_batch * narm * fac_doubles(cfg->num_seg)));
         TRY(dalloc(ctx, &ctx->d_pat, 1));
-        HIPTRY(hipMemcpy(ctx->d_pat, &t3.pat, sizeof(Qp3Pat), hipMemcpyHostToDevice));
+        HIPTRY(hipMemcpy(ctx->d_pat, &pat, sizeof(Qp3Pat), hipMemcpyHostToDevice));
     } else if (!build_tables(cfg->num_seg, tab)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
     TRY(dalloc(ctx, &ctx->d_ext_of_int, tab.ext_of_int.size()));
     TRY(dalloc(ctx, &ctx->d_entry_ptr, tab.entry_ptr.size()));
@@ -673,6 +683,23 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
         ctx->streams.words = ctx->d_stream; ctx->streams.npass = as.npass;
         for (int p = 0; p < 8; p++) { ctx->streams.off[p] = as.off[p]; ctx->streams.W[p] = as.W[p]; }
         ctx->streams.split_dst = as.split_dst; ctx->streams.split_scr = as.split_scr; ctx->streams.split_n = as.split_n;
+    }
+    if (cfg->num_seg == 4) {
+        if (const char *e = std::getenv("MPCMP_QP13")) ctx->qp13 = std::atoi(e);
+        if (ctx->qp13 != 2) {
+            StructureTables t4;
+            Qp3Pat pat;
+            if (!build_v3(4, t4, pat)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
+            TRY(dalloc(ctx, &ctx->d3_ext_of_int, t4.ext_of_int.size()));
+            TRY(dalloc(ctx, &ctx->d3_entry_ptr, t4.entry_ptr.size()));
+            TRY(dalloc(ctx, &ctx->d3_terms, t4.terms.size()));
+            HIPTRY(hipMemcpy(ctx->d3_ext_of_int, t4.ext_of_int.data(), t4.ext_of_int.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPTRY(hipMemcpy(ctx->d3_entry_ptr, t4.entry_ptr.data(), t4.entry_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPTRY(hipMemcpy(ctx->d3_terms, t4.terms.data(), t4.terms.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            TRY(dalloc(ctx, &ctx->d_fac, (size_t)max_batch * fac_doubles(4)));
+            TRY(dalloc(ctx, &ctx->d_pat, 1));
+            HIPTRY(hipMemcpy(ctx->d_pat, &pat, sizeof(Qp3Pat), hipMemcpyHostToDevice));
+        }
     }
 #undef TRY
 #undef HIPTRY
@@ -725,13 +752,17 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     if (int rc = set_lds(ctx, k_init<NSEG>, l_init)) return rc;
     static const bool force_v1 = std::getenv("MPCMP_FORCE_V1") != nullptr;   // diagnostics: generic kernel everywhere
     constexpr bool V2C = (NSEG == 2 || NSEG == 4);      // role-specialised 1024-thread QP kernel
-    constexpr bool V3C = (NSEG >= 6);                   // k_qp3: T bordered out, E-free interior solve (N = 19, 25)
-    const bool V2 = V2C && !force_v1;
-    const size_t l_qp3 = Qp3<V3C ? NSEG : 6>::sizeL * sizeof(double), l_qp3f = Qp3<V3C ? NSEG : 6>::sizeF * sizeof(double);
-    if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3C ? NSEG : 6, 1>, l_qp3)) return rc; if (int rc = set_lds(ctx, k_qp3f<V3C ? NSEG : 6, 1>, l_qp3f)) return rc; }
+    constexpr bool V3T = (NSEG >= 4);                   // k_qp3 instantiated (num_seg 4: diagnostics, MPCMP_QP13=3)
+    const bool V3C = NSEG >= 6 || (NSEG == 4 && ctx->qp13 == 3);      // k_qp3: T bordered out, E-free interior solve (N = 19, 25)
+    const bool V4 = NSEG == 4 && ctx->qp13 == 4;                       // k_qp3f<4, 1, 4> + k_qp4: two OCPs per CU
+    const bool V2 = V2C && !force_v1 && !V3C && !V4;
+    const size_t l_qp3 = Qp3<V3T ? NSEG : 6>::sizeL * sizeof(double), l_qp3f = Qp3<V3T ? NSEG : 6>::sizeF * sizeof(double);
+    if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3T ? NSEG : 6, 1>, l_qp3)) return rc; if (int rc = set_lds(ctx, k_qp3f<V3T ? NSEG : 6, 1>, l_qp3f)) return rc; }
+    const size_t l_qp4 = Qp4<4>::size * sizeof(double);
+    if (V4) { if (int rc = set_lds(ctx, k_qp4<4>, l_qp4)) return rc; if (int rc = set_lds(ctx, k_qp3f<4, 1, 4>, Qp3<4>::sizeF * sizeof(double))) return rc; }
     const size_t l_qp2 = Qp2<V2C ? NSEG : 4>::size * sizeof(double);
     if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
-    else if (!V3C) { if (int rc = set_lds(ctx, k_qp<V3C ? 1 : NSEG>, l_qp)) return rc; }
+    else if (!V3C && !V4) { if (int rc = set_lds(ctx, k_qp<(NSEG >= 6) ? 1 : NSEG>, l_qp)) return rc; }
     if (int rc = set_lds(ctx, k_step<NSEG>, l_step)) return rc;
     // A large batch is solved as two half-batches on two streams.  Every SQP iteration is a chain of dependent launches
     // (QP -> order -> step), and a QP launch ends in a tail in which most CUs are idle (its problems run 25..700 ADMM
@@ -768,13 +799,22 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         for (int h = 0; h < nhalf; h++) {
             hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
             if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
-            if (V3C) {
-                double *fh = ctx->d_fac + (size_t)boff[h] * Qp3<V3C ? NSEG : 6>::FAC;
-                hipLaunchKernelGGL((k_qp3f<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3f, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);
-                hipLaunchKernelGGL((k_qp3<V3C ? NSEG : 6, 1>), dim3(Bh[h]), dim3(512), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
+            if (V4) {
+                WS w3 = wh[h];
+                w3.ext_of_int = ctx->d3_ext_of_int; w3.entry_ptr = ctx->d3_entry_ptr; w3.terms = ctx->d3_terms;
+                double *fh = ctx->d_fac + (size_t)boff[h] * Qp4Fac<4>::FAC;
+                hipLaunchKernelGGL((k_qp3f<4, 1, 4>), dim3(Bh[h]), dim3(1024), Qp3<4>::sizeF * sizeof(double), sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
+                hipLaunchKernelGGL((k_qp4<4>), dim3(Bh[h]), dim3(384), l_qp4, sh[h], ctx->cfg, w3, ctx->d_pat, Bh[h], (const double *)fh);
+            }
+            else if (V3C) {
+                WS w3 = wh[h];
+                if (NSEG == 4) { w3.ext_of_int = ctx->d3_ext_of_int; w3.entry_ptr = ctx->d3_entry_ptr; w3.terms = ctx->d3_terms; }
+                double *fh = ctx->d_fac + (size_t)boff[h] * Qp3<V3T ? NSEG : 6>::FAC;
+                hipLaunchKernelGGL((k_qp3f<V3T ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3f, sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
+                hipLaunchKernelGGL((k_qp3<V3T ? NSEG : 6, 1>), dim3(Bh[h]), dim3(512), l_qp3, sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
             }
             else if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(Bh[h]), dim3(1024), l_qp2, sh[h], ctx->cfg, wh[h], ctx->streams);
-            else hipLaunchKernelGGL((k_qp<V3C ? 1 : NSEG>), dim3(Bh[h]), dim3(Dim<V3C ? 1 : NSEG>::NT), l_qp, sh[h], ctx->cfg, wh[h]);
+            else hipLaunchKernelGGL((k_qp<(NSEG >= 6) ? 1 : NSEG>), dim3(Bh[h]), dim3(Dim<(NSEG >= 6) ? 1 : NSEG>::NT), l_qp, sh[h], ctx->cfg, wh[h]);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;
             hipLaunchKernelGGL(k_step<NSEG>, dim3(Bh[h]), dim3(D::NT), l_step, sh[h], ctx->cfg, ctx->model, wh[h], it == iters - 1 ? 1 : 0, it,

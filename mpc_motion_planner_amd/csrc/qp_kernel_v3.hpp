@@ -142,6 +142,22 @@ struct Qp3 {
                          M_xtT = 9, M_sumha = 10, M_mtsT = 11 /* -ts T */, M_dl = 12, M_done = 13, M_s0 = 14, M_s1 = 15, M_c0 = 16 /* 16..31: check exchange */;
 };
 
+// factor workspace of k_qp3f<NSEG, 1, 4> -> k_qp4 (qp_kernel_v4.hpp), doubles per problem
+template <int NSEG>
+struct Qp4Fac {
+    using Q3 = Qp3<NSEG>;
+    static constexpr int SRS = 72;                                  // row stride of S^-1 (full, both triangles)
+    static constexpr int KX = 44;                                   // row stride of the column form of K_JC
+    static constexpr int fKJC = 0;                                  // [KJN] sparse K_JC, row form (canonical slots) + a zero row
+    static constexpr int fKT = Q3::oFT, fH = Q3::oFH;               // T column k (internal order) + kappa; sum |ha|
+    static constexpr int fKX = Q3::AUX;                             // [NSEG + 1][7][KX]
+    static constexpr int fGu = fKX + (NSEG + 1) * 7 * KX;           // [7][8]  K_UU^-1
+    static constexpr int fS = fGu + 56;                             // [nI][SRS]
+    static constexpr int fG48 = fS + Q3::D::nI * SRS;               // [NSEG][56] row 48 of every G_s
+    static constexpr int fG = fG48 + NSEG * 56;                     // [28][384]  2 x 14 blocks of rows 0..47, lane layout of k_qp4
+    static constexpr int FAC = fG + 28 * 384;
+};
+
 __device__ __forceinline__ void wave_sync() {
     // LDS traffic of one wave is executed in order; this only keeps the compiler from moving accesses across the hand-off
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -360,9 +376,11 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
 // the factor workspace `fac` [B][NARM][Qp3::FAC].  A kernel of its own so that the ADMM loop kernel's register allocation is
 // not entangled with the sweeps' (with both in one kernel the compiler kept the factor rows in scratch: 45 serialised scratch
 // reloads per matrix-vector product).
-template <int NSEG, int NARM>
+template <int NSEG, int NARM, int LAY = 3>
 __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, double *__restrict__ fac) {
     QP3_PROLOGUE(1024, true)
+    using L4 = Qp4Fac<NSEG>;                         // LAY == 4: hand-over in the layout of k_qp4 (qp_kernel_v4.hpp)
+    constexpr int FACSZ = LAY == 4 ? L4::FAC : L::FAC;
 #ifdef MPCMP_STAMPS
     unsigned long long fst_t = clock64();
 #define FST(k) do { if (tid == 0 && arm == 0) { const unsigned long long n_ = clock64(); ws.dbg[(size_t)b * MPCMP_DBG_WORDS + 128 + (k)] = n_ - fst_t; fst_t = n_; } } while (0)
@@ -533,8 +551,25 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     // G_s is read where the sweep left it; the products are taken BEFORE K_II is assembled over it, and subtracted afterwards.
     using V4 = __attribute__((ext_vector_type(4))) double;
     const int sw = wave & 7, hf = wave >> 3;
-    double *fa = fac + ((size_t)b * NARM + arm) * L::FAC;
-    {
+    double *fa = fac + ((size_t)b * NARM + arm) * FACSZ;
+    if (LAY == 4) {
+        // k_qp4 (384 lanes): lane Lq = 4 Q + part (Q = 24 seg + lp) keeps rows 2 lp, 2 lp + 1 (the row of its own parity first) x columns
+        // 14 part .. + 13 of G_seg, entry e = 14 a + j at [e][384 lanes]; row 48 of every segment goes out whole ([NSEG][56], zero padded).
+        for (int w = tid; w < 2 * 384; w += NT) {
+            const int Lq = w % 384, a = w / 384, Q = Lq >> 2, part = Lq & 3, seg = Q / 24, lp = Q % 24;
+            const double *Gs = lds + L::fKJJ + (seg < NSEG ? seg : 0) * D::JP;
+            const int row = 2 * lp + (a ^ (part & 1));
+#pragma unroll 1
+            for (int j = 0; j < 14; j++) {
+                const int col = 14 * part + j;
+                const bool in = seg < NSEG && col < 49;
+                const double g = -Gs[packed(row, in ? col : 0)];
+                fa[L4::fG + (14 * a + j) * 384 + Lq] = in ? g : 0.0;
+            }
+        }
+        for (int i = tid; i < NSEG * 56; i += NT) { const int sg = i / 56, c = i % 56; fa[L4::fG48 + i] = c < 49 ? -lds[L::fKJJ + sg * D::JP + packed(48, c)] : 0.0; }
+        if (tid < 56) { const int r = tid >> 3, c = tid & 7; fa[L4::fGu + tid] = (r < 7 && c < 7) ? -lds[L::fKUU + packed(r, c)] : 0.0; }
+    } else {
         // G_s leaves for the factor workspace in the block layout of g_blk ([segment][52 entries][64 lanes]: lane L keeps row L, entry
         // ((L & 3) ^ mcol) * 13 + c % 13 of the lane (L & ~3) + mcol holds G[L][c], mcol = c / 13; lanes 56..62 of the last segment: G_u).
         // Written entry by entry, 64 consecutive doubles per store (by row, a store touched 64 different cache lines: 90 k cycles);
@@ -656,6 +691,25 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
           [&](int, int i, int j, double val) { S[packed(i, j)] = val; });        // S <- -(S^-1)
     FST(5);
     // ---------------- derived copies of the coupling blocks in the access order of the loop kernel ----------------
+    if (LAY == 4) {
+        // column form [NSEG + 1][7 d][KX]: columns 0..27: entry of C-column c in row c % 14 + 7 (d - 1) of the segment (sparse part);
+        // columns 28..41: the dense block u_3s x x_3s, row d (block NSEG: u_{N-1} x x_{N-1}); columns 42, 43: zero
+        for (int i = tid; i < (NSEG + 1) * 7 * L4::KX; i += NT) {
+            const int sg = i / (7 * L4::KX), d = (i % (7 * L4::KX)) / L4::KX, col = i % L4::KX;
+            double val = 0.0;
+            if (col < 28) {
+                const int r = col % 14 + 7 * (d - 1);
+                if (sg < NSEG && r >= 0 && r < 49) {
+                    const uint32_t w = pat->jc[r];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if ((int)((w >> (8 * q)) & 255u) == col) val = lds[L::oKJC + sg * 196 + r * 4 + q];
+                }
+            } else if (col < 42) {
+                val = sg < NSEG ? lds[L::oKUX + sg * 98 + d * 14 + (col - 28)] : lds[L::oKuX + d * 14 + (col - 28)];
+            }
+            fa[L4::fKX + i] = val;
+        }
+    } else {
     for (int i = tid; i < NSEG * 224; i += NT) {
         const int sg = i / 224, d = (i % 224) / 28, c = i % 28, r = c % 14 + 7 * (d - 1);
         double val = 0.0;
@@ -673,6 +727,7 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
         { const int r = (i % 112) >> 4, c = i & 15; fa[L::oFD + (L::oKUXP - L::oKCJ) + i] = c < 14 ? src[r * 14 + c] : 0.0; }
     }
     if (tid < 16) fa[L::oFD + (L::oZR - L::oKCJ) + tid] = 0.0;
+    }
     if (tid < 4) lds[L::oKJC + NSEG * 196 + tid] = 0.0;
     __syncthreads();
     // ---------------- hand the factor to the loop kernel (once per QP: ~45k doubles per arm) ----------------
@@ -683,7 +738,9 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     for (int i = tid; i < L::KJN; i += NT) fa[i] = lds[L::oKJC + i];                // sparse K_JC + zero row
     for (int i = tid; i < L::NAP; i += NT) fa[L::oFT + i] = lds[L::oKT + i];        // T column, kappa
     if (tid == 0) fa[L::oFH] = misc[L::M_sumha];
-    if (wave >= 8) {
+    if (LAY == 4) {
+        for (int i = tid; i < nI * L4::SRS; i += NT) { const int r = i / L4::SRS, c = i % L4::SRS; fa[L4::fS + i] = c < nI ? -S[packed(r, c)] : 0.0; }
+    } else if (wave >= 8) {
         const int si = tid - 512, row0 = 4 * (si >> 4), mpos = si & 3, col0 = SC * (si & 15);
         for (int e = 0; e < 4 * SC; e++) {
             const int row = row0 + (mpos ^ (e / SC)), col = col0 + e % SC;
