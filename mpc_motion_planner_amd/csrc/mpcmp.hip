@@ -65,6 +65,7 @@ struct mpcmp_ctx {
     // num_seg 4: second set of structure tables (structure3.hpp order, T bordered out) for the E-free QP kernels (k_qp3f + k_qp4 / k_qp3)
     int *d3_ext_of_int = nullptr, *d3_entry_ptr = nullptr;
     uint32_t *d3_terms = nullptr;
+    uint32_t *d_lane4 = nullptr;   // lane-constant table of k_qp4 (qp4_build_lanes)
     int qp13 = 2;                  // QP kernel of num_seg 4: 2 = k_qp2, 3 = k_qp3f + k_qp3, 4 = k_qp3f + k_qp4 (env MPCMP_QP13)
     // timing of the dominant kernel (k_qp)
     struct EvPair { hipEvent_t e[2]; };
@@ -699,6 +700,10 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
             TRY(dalloc(ctx, &ctx->d_fac, (size_t)max_batch * fac_doubles(4)));
             TRY(dalloc(ctx, &ctx->d_pat, 1));
             HIPTRY(hipMemcpy(ctx->d_pat, &pat, sizeof(Qp3Pat), hipMemcpyHostToDevice));
+            std::vector<uint32_t> lane4((size_t)Qp4<4>::NF * Qp4<4>::NT);
+            qp4_build_lanes<4>(pat, t4.ext_of_int.data(), lane4.data());
+            TRY(dalloc(ctx, &ctx->d_lane4, lane4.size()));
+            HIPTRY(hipMemcpy(ctx->d_lane4, lane4.data(), lane4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }
 #undef TRY
@@ -759,7 +764,16 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     const size_t l_qp3 = Qp3<V3T ? NSEG : 6>::sizeL * sizeof(double), l_qp3f = Qp3<V3T ? NSEG : 6>::sizeF * sizeof(double);
     if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3T ? NSEG : 6, 1>, l_qp3)) return rc; if (int rc = set_lds(ctx, k_qp3f<V3T ? NSEG : 6, 1>, l_qp3f)) return rc; }
     const size_t l_qp4 = Qp4<4>::size * sizeof(double);
-    if (V4) { if (int rc = set_lds(ctx, k_qp4<4>, l_qp4)) return rc; if (int rc = set_lds(ctx, k_qp3f<4, 1, 4>, Qp3<4>::sizeF * sizeof(double))) return rc; }
+    if (V4) {
+        if (int rc = set_lds(ctx, k_qp4<4>, l_qp4)) return rc;
+        if (int rc = set_lds(ctx, k_qp3f<4, 1, 4>, Qp3<4>::sizeF * sizeof(double))) return rc;
+        static const bool dbg_occ = std::getenv("MPCMP_DEBUG_OCC") != nullptr;      // diagnostics: resident workgroups per CU
+        if (dbg_occ) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qp4<4>, 384, l_qp4);
+            std::fprintf(stderr, "k_qp4: %zu B of dynamic LDS, %d workgroups per CU\n", l_qp4, nb);
+        }
+    }
     const size_t l_qp2 = Qp2<V2C ? NSEG : 4>::size * sizeof(double);
     if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
     else if (!V3C && !V4) { if (int rc = set_lds(ctx, k_qp<(NSEG >= 6) ? 1 : NSEG>, l_qp)) return rc; }
@@ -804,7 +818,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
                 w3.ext_of_int = ctx->d3_ext_of_int; w3.entry_ptr = ctx->d3_entry_ptr; w3.terms = ctx->d3_terms;
                 double *fh = ctx->d_fac + (size_t)boff[h] * Qp4Fac<4>::FAC;
                 hipLaunchKernelGGL((k_qp3f<4, 1, 4>), dim3(Bh[h]), dim3(1024), Qp3<4>::sizeF * sizeof(double), sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
-                hipLaunchKernelGGL((k_qp4<4>), dim3(Bh[h]), dim3(384), l_qp4, sh[h], ctx->cfg, w3, ctx->d_pat, Bh[h], (const double *)fh);
+                hipLaunchKernelGGL((k_qp4<4>), dim3(Bh[h]), dim3(384), l_qp4, sh[h], ctx->cfg, w3, (const uint32_t *)ctx->d_lane4, Bh[h], (const double *)fh);
             }
             else if (V3C) {
                 WS w3 = wh[h];

@@ -146,7 +146,7 @@ struct Qp3 {
 template <int NSEG>
 struct Qp4Fac {
     using Q3 = Qp3<NSEG>;
-    static constexpr int SRS = 72;                                  // row stride of S^-1 (full, both triangles)
+    static constexpr int SRS = 70;                                  // row stride of S^-1 (full, both triangles)
     static constexpr int KX = 44;                                   // row stride of the column form of K_JC
     static constexpr int fKJC = 0;                                  // [KJN] sparse K_JC, row form (canonical slots) + a zero row
     static constexpr int fKT = Q3::oFT, fH = Q3::oFH;               // T column k (internal order) + kappa; sum |ha|
