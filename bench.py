@@ -13,7 +13,9 @@ no data-path collective, one RCCL gather of the solutions to rank 0 inside the t
   --scaling strong            --batch problems in the WHOLE job (slice [r*B/G, (r+1)*B/G))
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scaling weak|strong] [--workload ...]
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
+    (N>1 without WORLD_SIZE in the environment: bench.py starts its own N ranks — `python -m torch.distributed.run --nnodes=1
+     --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N` as a child process, before anything touches the GPU — and
+     forwards rank 0's JSON line and the exit code; under torchrun it is a rank.)
 """
 import argparse
 import json
@@ -83,6 +85,31 @@ def committed_mfma(workload):
             return None
         return {"kernel": mj["kernel"], "insts_mfma_per_launch": e["SQ_INSTS_MFMA"], "mfma_busy_cycles_per_launch": e["SQ_VALU_MFMA_BUSY_CYCLES"],
                 "busy_frac_of_simd_time": e.get("mfma_busy_frac_of_simd_time"), "source": "profiles/r02_mfma.json"}
+    except Exception:
+        return None
+
+
+def status_fractions(st):
+    """what the per-problem status words (include/mpcmp.h MPCMP_STATUS_*) say about a batch"""
+    st = np.asarray(st)
+    return {"status_ok_frac": float((st == 0).mean()),                       # converged QPs AND an iterate inside every tolerance
+            "hard_fail_frac": float(((st & 7) != 0).mean()),                 # NaN / lost positive definiteness / dead exchange
+            "qp_capped_frac": float(((st & 8) != 0).mean()),                 # at least one QP stopped at qp_iters (truncated ADMM)
+            "outside_tol_frac": float(((st & 16) != 0).mean()),              # defect / path violation > eps_abs or terminal error > eps_target + eps_abs
+            "T_out_of_box_frac": float(((st & 32) != 0).mean())}
+
+
+def committed_counters(workload):
+    """FP64 VALU instruction counters of the dominant kernels from the committed rocprofv3 PMC pass (profiles/r03_fp64_counters.json, written
+    by tools/fp64_counters.py from `tools/profile_round.sh`): flops the ISA executed per ADMM iteration of one trajectory (factorisation
+    included in the ratio).  None if the profile is absent."""
+    try:
+        cj = json.load(open(os.path.join(ROOT, "profiles", "r03_fp64_counters.json")))
+        e = cj["workloads"].get(workload)
+        if e is None:
+            return None
+        return {"flops_per_admm_iter": float(e["fp64_flops_per_traj_admm_iter"]), "source": "profiles/r03_fp64_counters.json", "build": cj.get("build"),
+                "counters": "64 x (2 SQ_INSTS_VALU_FMA_F64 + SQ_INSTS_VALU_ADD_F64 + SQ_INSTS_VALU_MUL_F64) + MFMA MOPS, of every QP kernel"}
     except Exception:
         return None
 
@@ -161,11 +188,13 @@ def bench_receding_horizon(args, M, scenarios, local):
             "config": {"workload": "512 Panda instances x 200 re-solves, N=13, 2 SQP iters/re-solve, dt=10 ms, hipGraph replay of the two-stream step "
                                    "(BASELINE.json configs[4])"},
             "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": out["graph"] * flops / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": out["graph"] * flops / 1e12 / FP64_PEAK_TFLOPS, "traffic": None, "mfma_busy": 0.0,
+                         "frac": (out["graph"] * admm_per_resolve * committed_counters("batch")["flops_per_admm_iter"] / 1e12 / FP64_PEAK_TFLOPS) if committed_counters("batch") else None,
+                         "frac_def": "FP64 flops the QP kernel executed (instruction counters of the N = 13 kernel x 64 lanes) over the wall clock / peak",
+                         "canonical_frac": out["graph"] * flops / 1e12 / FP64_PEAK_TFLOPS, "traffic": None, "mfma_busy": 0.0,
                          "avg_launch_ms_eager": (k_ms / max(k_n, 1)) if k_n else None, "launches_eager": k_n,
                          "admm_iters_per_resolve": admm_per_resolve, "canonical_gflop_per_resolve": flops / 1e9,
                          "note": "whole re-solve on the wall clock (canonical dense-equivalent flops, SURVEY.md 8d); the kernel uses no MFMA"},
-            "quality": {"status_ok_frac": float((info["status"] == 0).mean()), "T_mean_remaining": float(sT.mean())}}
+            "quality": dict(status_fractions(info["status"]), T_mean_remaining=float(sT.mean()))}
     if not args.no_cpu_baseline:
         # CPU baseline: the oracle's re-solve (2 SQP iterations from the previous solution) on a sample of the instances
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -183,7 +212,62 @@ def bench_receding_horizon(args, M, scenarios, local):
         el = time.perf_counter() - t0
         line["cpu_baseline"] = {"value": ns * reps / el, "unit": "re-solves/s", "cores": 1, "kind": "port", "single_thread": ns * reps / el,
                                 "nproc": os.cpu_count(), "sample": "oracle, %d instances x %d re-solves, 1 thread, %.1f s" % (ns, reps, el)}
-    print(json.dumps(line))
+    return line
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as a CHILD process (torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1) and forward rank 0's JSON line (the ranks inherit stdout) and the exit code.  Nothing here touches the GPU: a process that
+    has initialised it must not be replaced or re-executed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_rank(args, rank, world):
+    """CPU stand-in of one rank (tests/test_bench_launcher.py): gloo instead of RCCL, a deterministic fill instead of the device solve —
+    everything else (sharding, the single gather, barrier + max-over-ranks timing, the JSON line) is the code path of the real bench."""
+    import torch
+    import torch.distributed as dist
+    from mpc_motion_planner_amd import sharding
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, batch = 13, args.batch or 8
+    total = sharding.global_total(args.scaling, batch, world)
+    sb = sharding.ShardedBatch(total, rank, world, N, torch.device("cpu"), dist if world > 1 else None)
+    idx = torch.arange(sb.lo, sb.hi, dtype=torch.float64)
+    sol_x = idx[:, None, None] + torch.zeros(sb.count, N, 14, dtype=torch.float64)
+    sol_u = -idx[:, None, None] + torch.zeros(sb.count, N, 7, dtype=torch.float64)
+    sol_T = 0.5 * idx
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sb.pack_and_gather(sol_x, sol_u, sol_T)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        g = sb.assemble()
+        ok = bool(torch.equal(g[:, 0], torch.arange(total, dtype=torch.float64)) and torch.equal(g[:, -1], 0.5 * torch.arange(total, dtype=torch.float64)))
+        print(json.dumps({"metric": "stub (launcher self-test, no GPU work)", "value": total * args.steps / max(elapsed, 1e-9), "unit": "records/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling, "stub": True, "gather_ok": ok,
+                          "config": {"batch": batch, "problems_total": total, "rccl_world_size": world, "backend": "gloo"}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -201,18 +285,24 @@ def main():
     ap.add_argument("--workload", choices=["batch", "rh", "shipped", "dual14"], default="batch",
                     help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon; shipped: the reference-as-shipped "
                          "solver depth (N=19, 2 SQP iterations; SURVEY.md 8d); dual14: configs[3], 14-DoF dual-Panda, N=25")
+    ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the brief runs of the three other workloads")
+    ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # launcher self-test on a CPU-only box (gloo, no solve)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: this process only starts the ranks and waits (no GPU call before or after)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE = %d" % (args.gpus, world))
+    if args.stub_cpu:
+        return stub_rank(args, rank, world)
 
     import torch
     import mpc_motion_planner_amd as M
     from mpc_motion_planner_amd import scenarios, sharding
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
-                     "bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the mpcmp product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -223,12 +313,42 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     if args.workload == "rh":
-        return bench_receding_horizon(args, M, scenarios, local)
-    if args.workload == "dual14":
+        line = bench_receding_horizon(args, M, scenarios, local)
+    elif args.workload == "dual14":
         import bench_dual14
-        return bench_dual14.run(args, rank, world, local, dist)
-    nseg, sqp, narm, bytes_per_traj, metric = WORKLOADS[args.workload]
-    batch = args.batch or 1024
+        line = bench_dual14.run(args, rank, world, local, dist)
+    else:
+        line = run_batch_workload(args, args.workload, args.steps, args.warmup, rank, world, local, dist, args.cpu_sample, args.batch or 1024)
+    if line is not None and args.workload == "batch" and world == 1 and not args.no_secondary:
+        # the other three workloads, briefly, inside the ONE contract line: value, ms_per_step, roofline fractions, CPU baseline
+        import bench_dual14
+        sec = {}
+        for name, fn in (("shipped", lambda: run_batch_workload(args, "shipped", 5, 1, 0, 1, local, None, 128, 1024, host_to_host=False)),
+                         ("rh", lambda: bench_receding_horizon(args, M, scenarios, local)),
+                         ("dual14", lambda: bench_dual14.run(args, 0, 1, local, None, steps=2, warmup=1, batch=4096))):
+            t0 = time.perf_counter()
+            try:
+                d = fn()
+                sec[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"],
+                             "roofline": {k: d["roofline"].get(k) for k in ("kernel", "frac", "canonical_frac", "avg_launch_ms", "admm_iters_per_traj", "admm_iters_per_resolve")
+                                          if k in d["roofline"]},
+                             "cpu_baseline": {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "single_thread")} if "cpu_baseline" in d else None,
+                             "quality": d.get("quality"), "config": d["config"]["workload"], "wall_s": time.perf_counter() - t0}
+            except Exception as e:      # a secondary workload must never cost the contract line
+                sec[name] = {"error": repr(e)}
+        line["secondary"] = sec
+    if line is not None:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, cpu_sample, batch, host_to_host=True):
+    """one batch workload (`batch` = BASELINE.json configs[1], `shipped` = the reference-as-shipped depth) on this rank; rank 0 returns the line"""
+    import torch
+    import mpc_motion_planner_amd as M
+    from mpc_motion_planner_amd import scenarios, sharding
+    nseg, sqp, narm, bytes_per_traj, metric = WORKLOADS[workload]
     N = 3 * nseg + 1
     total = sharding.global_total(args.scaling, batch, world)
     dev = torch.device("cuda", local)
@@ -264,12 +384,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
     solver.kernel_timing(reset=True)          # switches the HIP-event timing of the dominant kernel on
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
@@ -281,14 +401,14 @@ def main():
 
     if rank == 0:
         inf = np.frombuffer(info.cpu().numpy().tobytes(), dtype=M.INFO_DTYPE)
-        value = total * args.steps / elapsed
+        value = total * steps / elapsed
         admm_mean = float(inf["qp_iters_total"].mean())
         flops_traj = canonical_flops(N, sqp, admm_mean, narm)
         flops_qp_traj = flops_traj - sqp * N * 2.0e4 * narm                 # the dominant kernel's share: factorisations + ADMM iterations
         k_avg_s = (k_ms / max(k_launches, 1)) * 1e-3
         # a large batch is solved as several parts on as many streams (mpcmp.hip: solve_impl), so a launch of the dominant kernel
         # covers B / parts problems and `parts` launches are in flight together; durations are HIP events on the launch's own stream
-        parts = max(1, round(k_launches / float(args.steps * sqp)))
+        parts = max(1, round(k_launches / float(steps * sqp)))
         problems_per_launch = B / parts
         flops_launch = problems_per_launch * flops_qp_traj / sqp
         per_gpu = value / world
@@ -296,45 +416,54 @@ def main():
         alg_bytes_launch = problems_per_launch * bytes_per_traj / sqp
         traffic, mfma_busy = committed_traffic(kname, problems_per_launch)
         peak_meas = measured_fp64_peak()
+        # executed FP64 flops: from the committed counter pass (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 of the QP kernels), per ADMM iteration actually run;
+        # the round-1/2 hand count (EXECUTED_FMA) only if no counter profile is committed
+        cc = committed_counters(workload)
         ex = EXECUTED_FMA.get(nseg)
-        executed = per_gpu * 2.0 * (admm_mean * ex[0] + sqp * ex[1]) / 1e12 if ex else None
-        feasible = (inf["defect_inf"] < 1e-3) & (inf["path_viol_inf"] < 1e-3) & (inf["term_err_inf"] <= 1.1e-2) & (inf["status"] == 0)
+        if cc is not None:
+            executed = per_gpu * admm_mean * cc["flops_per_admm_iter"] / 1e12
+        else:
+            executed = per_gpu * 2.0 * (admm_mean * ex[0] + sqp * ex[1]) / 1e12 if ex else None
+        feasible = (inf["status"] & (1 | 2 | 4 | 16 | 32)) == 0           # inside every tolerance and no hard failure (capped QPs allowed)
         out = {
-            "metric": metric, "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "metric": metric, "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d-problem random batch %s, 7-DoF Panda, N=%d Chebyshev nodes (cubic x %d segments), "
                                    "%d SQP iters, <=700 ADMM iters, %s warm start computed in the timed step (%s)"
                                    % (batch, "per GPU" if args.scaling == "weak" else "in the whole job, sliced [r*B/G,(r+1)*B/G)", N, nseg, sqp,
                                       "jerk-limited (Ruckig-equivalent)" if args.warm == "jerk" else "quintic",
-                                      "BASELINE.json configs[1]" if args.workload == "batch" else "reference as shipped: robot_ocp.hpp:32, motionPlanner.cpp:15"),
+                                      "BASELINE.json configs[1]" if workload == "batch" else "reference as shipped: robot_ocp.hpp:32, motionPlanner.cpp:15"),
                        "batch": batch, "problems_total": total, "problems_rank0": B, "rccl_world_size": world,
                        "seed": scenarios.SEED, "margins": list(MARGINS), "timed": "device-resident inputs and outputs (value); host_to_host beside it"},
             # the binding resource is FP64 vector issue + LDS + workgroup barriers: not HBM, not MFMA
             "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS,
-                         "executed_frac": (executed / FP64_PEAK_TFLOPS) if executed is not None else None,
+                         "frac": (executed / FP64_PEAK_TFLOPS) if executed is not None else None,
+                         "frac_def": "FP64 flops the QP kernels executed (instruction counters x 64 lanes) per GPU over the wall clock of the timed region / peak",
+                         "executed_source": cc if cc is not None else "hand count (bench.py EXECUTED_FMA): no counter profile committed",
+                         "canonical_frac": achieved / FP64_PEAK_TFLOPS,
                          "peak_measured": peak_meas, "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None,
                          "traffic": traffic, "mfma_busy": 0.0 if mfma_busy is None else mfma_busy,
-                         "mfma_factor_kernel": committed_mfma(args.workload),
+                         "mfma_factor_kernel": committed_mfma(workload),
                          "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts, "problems_per_launch": problems_per_launch,
                          "canonical_gflop_per_launch": flops_launch / 1e9,
                          "per_launch_tflops": flops_launch / k_avg_s / 1e12 if k_avg_s > 0 else None,
                          "canonical_gflop_per_traj": flops_traj / 1e9, "admm_iters_per_traj": admm_mean,
                          "hbm": {"algorithmic_bytes_per_launch": alg_bytes_launch, "achieved_gbs": alg_bytes_launch / k_avg_s / 1e9 if k_avg_s > 0 else None,
                                  "peak_gbs": HBM_PEAK_GBS, "frac": alg_bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS if k_avg_s > 0 else None},
-                         "note": "achieved = canonical dense-equivalent FP64 flops (SURVEY.md 8d) of the QP kernel per GPU over the wall clock of the "
-                                 "timed region; `launches_in_flight` launches overlap, so avg_launch_ms is not exclusive GPU time; executed_frac counts "
-                                 "the FMAs the ISA executes; mfma_busy is that of the dominant kernel (the ADMM loop has one right-hand side per problem and issues no MFMA); "
+                         "note": "frac = executed flops (counters) / peak; achieved / canonical_frac = canonical dense-equivalent FP64 flops (SURVEY.md 8d) of the "
+                                 "QP kernel per GPU over the wall clock of the timed region (an algorithm-speed figure, not a utilisation); "
+                                 "`launches_in_flight` launches overlap, so avg_launch_ms is not exclusive GPU time; mfma_busy is that of the dominant kernel (the ADMM loop has one right-hand side per problem and issues no MFMA); "
                                  "for N >= 19 the factorisation kernel k_qp3f runs the QP's block GEMMs (Schur complement products) on the matrix cores: mfma_factor_kernel"},
-            "quality": {"status_ok_frac": float((inf["status"] == 0).mean()), "feasible_frac": float(feasible.mean()),
+            "quality": {**status_fractions(inf["status"]), "feasible_frac": float(feasible.mean()),
                         "T_mean": float(inf["T"].mean()),
                         "defect_inf_median": float(np.median(inf["defect_inf"])),
                         "term_err_inf_median": float(np.median(inf["term_err_inf"])),
                         "path_viol_inf_max": float(inf["path_viol_inf"].max()),
-                        "feasible_def": "status 0, collocation defect < 1e-3, path violation < 1e-3, terminal error <= 1.1e-2"},
+                        "feasible_def": "no hard failure, collocation defect and path violation <= eps_abs (1e-3), terminal error <= eps_target + eps_abs "
+                                        "(1.1e-2), T inside its box: status bits 1, 2, 4, 16, 32 clear (include/mpcmp.h)"},
         }
-        if world == 1:
+        if world == 1 and host_to_host:
             # host -> host (inputs and outputs in host memory, PCIe inclusive): warm, median of 5 repeats
             ts = []
             for _ in range(6):
@@ -344,13 +473,12 @@ def main():
             ts = sorted(ts[1:])
             out["host_to_host"] = {"trajectories_per_s": B / ts[len(ts) // 2], "repeats": len(ts), "min_ms": 1e3 * ts[0], "max_ms": 1e3 * ts[-1],
                                    "note": "SURVEY.md 8(d) defines the metric host->host; `value` is the device-resident rate the bench contract asks for"}
-            if not args.no_cpu_baseline:
-                cb, T_cpu = cpu_baseline(nseg, sqp, x0_h, xf_h, args.warm, args.cpu_sample, max(16, args.cpu_sample // 4))
-                out["cpu_baseline"] = cb
-                out["quality"]["max_rel_dT_vs_cpu_sample"] = float(np.max(np.abs(inf["T"][:len(T_cpu)] - T_cpu) / np.abs(T_cpu)))
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        if world == 1 and not args.no_cpu_baseline:
+            cb, T_cpu = cpu_baseline(nseg, sqp, x0_h, xf_h, args.warm, cpu_sample, max(16, cpu_sample // 4))
+            out["cpu_baseline"] = cb
+            out["quality"]["max_rel_dT_vs_cpu_sample"] = float(np.max(np.abs(inf["T"][:len(T_cpu)] - T_cpu) / np.abs(T_cpu)))
+        return out
+    return None
 
 
 if __name__ == "__main__":

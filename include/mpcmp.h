@@ -81,9 +81,18 @@ typedef struct {
     double last_alpha;    /* step length of the last SQP iteration                        */
     int    qp_iters_total;/* ADMM iterations executed over all SQP iterations             */
     int    sqp_iters;
-    int    status;        /* 0 ok; bit0 NaN/Inf in the iterate; bit1 KKT factorisation lost positive definiteness */
-    int    pad;
+    int    status;        /* 0 = converged QPs and an iterate inside every tolerance; else MPCMP_STATUS_* bits              */
+    int    qp_capped;     /* number of SQP iterations whose QP ran out of qp_iters before its termination test was met    */
 } mpcmp_info;
+/* status bits.  The reference never reads mpc.info().status (motionPlanner.cpp:191); this record is the only failure channel a
+ * batched caller has ("Failure detection"). */
+#define MPCMP_STATUS_NAN          1   /* NaN / Inf in the returned iterate                                                   */
+#define MPCMP_STATUS_NOT_PD       2   /* a KKT factorisation lost positive definiteness                                      */
+#define MPCMP_STATUS_XCH_DEAD     4   /* multi-arm OCP: the partner workgroup never answered an exchange                     */
+#define MPCMP_STATUS_QP_CAPPED    8   /* at least one QP stopped at qp_iters (qp_capped counts them): a truncated-ADMM step  */
+#define MPCMP_STATUS_OUTSIDE_TOL 16   /* returned iterate outside tolerance: collocation defect or path violation > eps_abs,
+                                         or terminal error > eps_target + eps_abs                                           */
+#define MPCMP_STATUS_T_OUT_OF_BOX 32  /* final time outside [lbT, ubT]                                                       */
 
 /* ---- configuration helpers (host, no GPU needed) ---- */
 int mpcmp_default_model(mpcmp_model *m);                                    /* Panda arm, panda_arm.urdf */

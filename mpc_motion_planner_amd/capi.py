@@ -34,12 +34,12 @@ class Config(C.Structure):
 class Info(C.Structure):
     _fields_ = [("T", C.c_double), ("viol_l1", C.c_double), ("defect_inf", C.c_double),
                 ("path_viol_inf", C.c_double), ("term_err_inf", C.c_double), ("last_alpha", C.c_double),
-                ("qp_iters_total", C.c_int), ("sqp_iters", C.c_int), ("status", C.c_int), ("pad", C.c_int)]
+                ("qp_iters_total", C.c_int), ("sqp_iters", C.c_int), ("status", C.c_int), ("qp_capped", C.c_int)]
 
 
 INFO_DTYPE = np.dtype([("T", "f8"), ("viol_l1", "f8"), ("defect_inf", "f8"), ("path_viol_inf", "f8"),
                        ("term_err_inf", "f8"), ("last_alpha", "f8"), ("qp_iters_total", "i4"),
-                       ("sqp_iters", "i4"), ("status", "i4"), ("pad", "i4")])
+                       ("sqp_iters", "i4"), ("status", "i4"), ("qp_capped", "i4")])
 
 # every symbol include/mpcmp.h declares (the CPU test suite checks the library exports all of them)
 SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_models_from_urdf", "mpcmp_default_limits", "mpcmp_default_config",

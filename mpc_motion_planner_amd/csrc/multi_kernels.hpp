@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512) void k_step_m(mpcmp_config cfg, const mpcmp_mo
             mpcmp_info o;
             o.T = zl[n - 1]; o.viol_l1 = s1[0]; o.defect_inf = mxs[0]; o.path_viol_inf = mxs[1]; o.term_err_inf = mxs[2];
             o.last_alpha = alpha; o.qp_iters_total = ws.qp_total[b]; o.sqp_iters = sqp_it + 1;
-            o.status = ws.status[b] | (anybad ? 1 : 0); o.pad = 0;
+            report_status(cfg, ws.status[b], anybad, o);
             info[b] = o;
         }
     }

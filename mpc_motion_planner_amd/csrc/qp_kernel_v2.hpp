@@ -389,9 +389,10 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         STAMP2(8);
         if (done) break;
     }
-    if (it > cfg.qp_iters) it = cfg.qp_iters;
+    const bool capped = it > cfg.qp_iters;             // ran out of iterations without meeting the termination test
+    if (capped) it = cfg.qp_iters;
     BUSY_DUMP;
-    if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; }
+    if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; if (capped) atomicAdd(&c.ws.status[c.b], MPCMP_ST_CAP_ONE); }
 #ifdef MPCMP_STAMPS
     if (tid == 0) { unsigned long long *o = c.ws.dbg + (size_t)c.b * MPCMP_DBG_WORDS; for (int k = 3; k < 9; k++) o[k] = stamp_acc[k]; o[12] = stamp_acc[12]; o[15] = it; }
 #endif

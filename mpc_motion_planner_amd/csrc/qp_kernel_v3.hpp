@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     {
         const int any = __syncthreads_or(dead ? 4 : 0);         // bit 2: the partner workgroup never answered
         if (tid == 0) {
-            if (arm == 0) { ws.qpit[b] = it; ws.qp_total[b] += it; }
+            if (arm == 0) { ws.qpit[b] = it; ws.qp_total[b] += it; if (!done) atomicAdd(&ws.status[b], MPCMP_ST_CAP_ONE); }
             if (any) atomicOr(&ws.status[b], any);
         }
     }

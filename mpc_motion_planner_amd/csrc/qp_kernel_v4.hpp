@@ -841,6 +841,7 @@ __global__ __launch_bounds__(384, 3) void k_qp4(mpcmp_config cfg, WS ws, const u
             ws.p[(size_t)b * n_tot + na] = misc[L::M_xT];
             ws.y[(size_t)b * mn_tot + mn_tot - 1] = misc[L::M_ybT];
             ws.qpit[b] = it; ws.qp_total[b] += it;
+            if (!done) atomicAdd(&ws.status[b], MPCMP_ST_CAP_ONE);
         }
     }
 }

@@ -44,6 +44,9 @@ struct WS {
     unsigned long long *dbg;  // [B][MPCMP_DBG_WORDS] phase cycle stamps (diagnostic builds with -DMPCMP_STAMPS only)
 };
 
+// ws.status[b] while a solve runs: bits 0..7 = status bits of mpcmp_info (include/mpcmp.h), bits 8..15 = number of QPs that ran out of
+// iterations (every QP kernel adds MPCMP_ST_CAP_ONE then); k_step / k_step_m fold it into the record
+#define MPCMP_ST_CAP_ONE 0x100
 #define MPCMP_DBG_WORDS 160   /* 16 workgroup stamps + [16 waves][8] per-wave busy cycles of k_qp2 + 16 stamps of k_step */
 #ifdef MPCMP_STAMPS
 #define STAMP(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
@@ -82,6 +85,15 @@ __device__ __forceinline__ double viol(double v, double lo, double hi) {
     return v < lo ? lo - v : (v > hi ? v - hi : 0.0);
 }
 __device__ __forceinline__ double clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// status word and capped-QP count of the result record (include/mpcmp.h: MPCMP_STATUS_*; the oracle's orc_solve_multi does the same)
+__device__ __forceinline__ void report_status(const mpcmp_config &cfg, int st, int anybad, mpcmp_info &o) {
+    int s = (st & 0xFF) | (anybad ? MPCMP_STATUS_NAN : 0);
+    o.qp_capped = (st >> 8) & 0xFF;
+    if (o.qp_capped) s |= MPCMP_STATUS_QP_CAPPED;
+    if (o.defect_inf > cfg.eps_abs || o.path_viol_inf > cfg.eps_abs || o.term_err_inf > cfg.eps_target + cfg.eps_abs) s |= MPCMP_STATUS_OUTSIDE_TOL;
+    if (!(o.T >= cfg.lbT - 1e-9 && o.T <= cfg.ubT + 1e-9)) s |= MPCMP_STATUS_T_OUT_OF_BOX;
+    o.status = s;
+}
 
 // variable box of external variable v (motionPlanner.cpp:33,47,66-79)
 template <int NSEG>
@@ -683,7 +695,8 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
         STAMP(8);
         if (done) break;
     }
-    if (it > cfg.qp_iters) it = cfg.qp_iters;
+    const bool capped = it > cfg.qp_iters;             // ran out of iterations without meeting the termination test
+    if (capped) it = cfg.qp_iters;
     // ---------------- results ----------------
     if (isVar) {
         ws.p[(size_t)b * n + tid] = x;
@@ -699,6 +712,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
             ws.qpit[b] = it;
             ws.qp_total[b] += it;
             if (any) ws.status[b] |= any;
+            if (capped) ws.status[b] += MPCMP_ST_CAP_ONE;
         }
     }
 }
@@ -880,7 +894,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
             mpcmp_info o;
             o.T = zl[n - 1]; o.viol_l1 = s1[0]; o.defect_inf = mxs[0]; o.path_viol_inf = mxs[1]; o.term_err_inf = mxs[2];
             o.last_alpha = alpha; o.qp_iters_total = ws.qp_total[b]; o.sqp_iters = sqp_it + 1;
-            o.status = ws.status[b] | (anybad ? 1 : 0); o.pad = 0;
+            report_status(cfg, ws.status[b], anybad, o);
             info[b] = o;
         }
     }

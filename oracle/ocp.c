@@ -422,7 +422,7 @@ static int admm(const orc_config *c, work *w, double *x, double *y, int *status)
             }
         }
     }
-    if (it > c->qp_iters) it = c->qp_iters;
+    if (it > c->qp_iters) { it = c->qp_iters; *status |= 8; }    /* ran out of iterations without meeting the termination test */
 done:
     free(zz); free(xt); free(rhs); free(zt); free(tmp); free(wv); free(t1); free(t2);
     return it;
@@ -450,6 +450,7 @@ void orc_solve_multi(const orc_model *mdl, int narm, const orc_config *c, const 
         int st;
         inf.qp_iters_total += admm(c, w, p, y, &st);
         if (st) inf.status |= st;
+        if (st & 8) inf.qp_capped++;
         /* l1 merit line search, polympc_redef.hpp:73-121 */
         double mu = inf_norm(lam, mn);                                   /* :86 */
         double constr = l1_violation(w, c, z, w->ceq, w->g);             /* :79 */
@@ -477,6 +478,8 @@ void orc_solve_multi(const orc_model *mdl, int narm, const orc_config *c, const 
     }
     for (int r = 0; r < w->nx; r++) { double d = fabs(z[IX(w, w->N - 1, r)] - xf[r]); if (d > inf.term_err_inf) inf.term_err_inf = d; }
     for (int k = 0; k < n; k++) if (!isfinite(z[k])) inf.status |= 1;
+    if (inf.defect_inf > c->eps_abs || inf.path_viol_inf > c->eps_abs || inf.term_err_inf > c->eps_target + c->eps_abs) inf.status |= 16;
+    if (!(inf.T >= c->lbT - 1e-9 && inf.T <= c->ubT + 1e-9)) inf.status |= 32;
     memcpy(xs, z, sizeof(double) * w->nx * w->N); memcpy(us, z + w->nx * w->N, sizeof(double) * w->nu * w->N); *Tout = z[n - 1];
     if (info) *info = inf;
     free(z); free(lam); free(p); free(y); free(zs); free(ce); free(gg);
@@ -517,7 +520,7 @@ int orc_debug_qp_multi(const orc_model *mdl, int narm, const orc_config *c, cons
     linearise(mdl, c, w, z, lam ? lam : l0);
     int st, it = admm(c, w, p, y, &st);
     free(z); free(l0); work_free(w);
-    return st ? -it : it;
+    return (st & ~8) ? -it : it;        /* (bit 3: the QP hit qp_iters — not an error of the leaf call) */
 }
 
 int orc_debug_qp(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,

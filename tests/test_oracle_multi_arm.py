@@ -39,7 +39,7 @@ def test_dual_arm_solution_is_feasible_for_both_arms_and_slower_than_either_alon
         xg, ug, Tg = o.warm_start_jerk_multi(4, *_limits(), x0[b], xf[b])
         assert np.array_equal(xg[0], x0[b]) and np.array_equal(xg[-1], xf[b])
         xs, us, T, info = o.solve_multi(models, cfg, x0[b], xf[b], xg, ug, Tg)
-        assert info.status == 0 and info.defect_inf < 2e-2 and info.path_viol_inf < 2e-2 and info.term_err_inf < 2e-2
+        assert (info.status & 7) == 0 and info.defect_inf < 2e-2 and info.path_viol_inf < 2e-2 and info.term_err_inf < 2e-2
         singles = []
         for (s0, sf, mdl) in ((a0[b], af[b], o.arm_models(o.DUAL_BASES[:1])), (b0[b], bf[b], o.arm_models(o.DUAL_BASES[1:]))):
             wg = o.warm_start_jerk(4, *_limits(), s0, sf)

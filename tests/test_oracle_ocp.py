@@ -74,7 +74,7 @@ def test_gold_traj_fit(golden_dir):
     xg, ug, Tg = jerk_warm_start(g, x0, xf, 6)
     assert abs(Tg - g["T_ruckig"]) < 2e-6
     xs, us, T, info = o.solve(cfg, x0, xf, xg, ug, Tg)
-    assert info.status == 0 and info.qp_iters_total == 700 and info.last_alpha == 1.0
+    assert (info.status & 7) == 0 and info.status & 8 and info.qp_capped == 1 and info.qp_iters_total == 700 and info.last_alpha == 1.0
     dT, dq, dv, da = gold_residuals(g, xs, us, T, x0, xf)
     assert dT < GOLD_FIT["dT"] and dq < GOLD_FIT["dq"] and dv < GOLD_FIT["dv"] and da < GOLD_FIT["da"], (dT, dq, dv, da)
     assert info.path_viol_inf < 1e-6 and np.abs(xs[0] - x0).max() < 1e-4     # truncated ADMM returns x, not the clipped z

@@ -28,7 +28,7 @@ int main(void) {
         int n = 21 * N + 1, mm = 14 * (N - 1) + 8 * N;
         double *p = calloc(n, 8), *y = calloc(mm + n, 8);
         orc_debug_qp(&m, &c, x0, xf, xg, ug, Tg, 0, p, y);
-        printf("nseg %d T %.6f status %d\n", nseg, T, info.status);
+        printf("nseg %d T %.6f status %d\n", nseg, T, info.status & 7);
         free(xg); free(ug); free(xs); free(us); free(smp); free(p); free(y);
     }
     /* threaded batch helper */
