@@ -65,7 +65,7 @@ def measured_fp64_peak():
 
 def committed_traffic(kname, problems_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json)"""
-    for f in ("r02_traffic.json", "r01_traffic.json"):
+    for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", f)))
             if tj.get("kernel") == kname and tj.get("problems_per_launch") == problems_per_launch:
@@ -79,12 +79,12 @@ def committed_mfma(workload):
     """MFMA counters of the factorisation kernel k_qp3f (its Schur complement products run on the matrix cores) from the committed
     rocprofv3 PMC pass (profiles/r02_mfma.json); None for the N = 13 path, whose kernel k_qp2 issues no MFMA"""
     try:
-        mj = json.load(open(os.path.join(ROOT, "profiles", "r02_mfma.json")))
+        mj = json.load(open(os.path.join(ROOT, "profiles", "r03_mfma.json")))
         e = mj.get(workload)
         if e is None:
             return None
         return {"kernel": mj["kernel"], "insts_mfma_per_launch": e["SQ_INSTS_MFMA"], "mfma_busy_cycles_per_launch": e["SQ_VALU_MFMA_BUSY_CYCLES"],
-                "busy_frac_of_simd_time": e.get("mfma_busy_frac_of_simd_time"), "source": "profiles/r02_mfma.json"}
+                "busy_frac_of_simd_time": e.get("mfma_busy_frac_of_simd_time"), "source": "committed_profile: profiles/r03_mfma.json"}
     except Exception:
         return None
 
@@ -443,7 +443,8 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
                          "executed_source": cc if cc is not None else "hand count (bench.py EXECUTED_FMA): no counter profile committed",
                          "canonical_frac": achieved / FP64_PEAK_TFLOPS,
                          "peak_measured": peak_meas, "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None,
-                         "traffic": traffic, "mfma_busy": 0.0 if mfma_busy is None else mfma_busy,
+                         "traffic": traffic, "traffic_source": "committed_profile: profiles/r03_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE of the dominant kernel, per launch)",
+                         "mfma_busy": 0.0 if mfma_busy is None else mfma_busy,
                          "mfma_factor_kernel": committed_mfma(workload),
                          "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts, "problems_per_launch": problems_per_launch,
                          "canonical_gflop_per_launch": flops_launch / 1e9,
