@@ -156,6 +156,9 @@ static void work_free(work *w) {
     free(w->first); free(w->K); free(w);
 }
 
+/* structure probes against the reference's ONE stored solve; a bit mask in the environment, 0 = the specification */
+static int orc_probe(void) { const char *e = getenv("ORC_PROBE"); return e ? atoi(e) : 0; }
+
 static void set_boxes(work *w, const orc_config *c, const double *x0, const double *xf) {
     int N = w->N;
     for (int k = 0; k < N; k++) {
@@ -276,8 +279,12 @@ static void linearise(const orc_model *mdl, const orc_config *c, work *w, const 
     }
     for (int i = 0; i < n; i++) { w->l[w->m + i] = w->zlb[i] - z[i]; w->u[w->m + i] = w->zub[i] - z[i]; }
     /* per-row rho: OSQP rule, equality rows (l==u) scaled by rho_eq_scale */
-    for (int i = 0; i < w->m + n; i++)
+    for (int i = 0; i < w->m + n; i++) {
         w->rho[i] = (w->u[i] - w->l[i] < 1e-4) ? c->rho * c->rho_eq_scale : c->rho;
+        /* HYPOTHESIS PROBE (tools/polympc_param_fit.py --probe; off unless ORC_PROBE has bit 0): variable boxes keep the plain rho even when
+           they pin a variable (x_0); only general equality rows get rho_eq */
+        if (orc_probe() & 1 && i >= w->m) w->rho[i] = c->rho;
+    }
 }
 
 /* K = H + sigma I + diag(rho_box) + A^T diag(rho) A in the chain ordering, then skyline Cholesky */
@@ -423,6 +430,7 @@ static int admm(const orc_config *c, work *w, double *x, double *y, int *status)
         }
     }
     if (it > c->qp_iters) { it = c->qp_iters; *status |= 8; }    /* ran out of iterations without meeting the termination test */
+    if (orc_probe() & 2) for (int i = 0; i < n; i++) x[i] = zz[m + i];      /* PROBE: return the projected copy z of the step, not x */
 done:
     free(zz); free(xt); free(rhs); free(zt); free(tmp); free(wv); free(t1); free(t2);
     return it;
@@ -445,6 +453,7 @@ void orc_solve_multi(const orc_model *mdl, int narm, const orc_config *c, const 
     orc_info inf; memset(&inf, 0, sizeof inf);
     pack(w, xg, ug, Tg, z);
     set_boxes(w, c, x0, xf);
+    if (orc_probe() & 4) for (int r = 0; r < w->nu; r++) w->zlb[IU(w, w->N - 1, r)] = w->zub[IU(w, w->N - 1, r)] = z[IU(w, w->N - 1, r)];   /* PROBE: u_{N-1} pinned to the warm start */
     linearise(mdl, c, w, z, lam);
     for (int it = 0; it < c->sqp_iters; it++) {
         int st;

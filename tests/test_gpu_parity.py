@@ -96,6 +96,28 @@ def test_qp_full_vs_oracle(M):
     _qp_case(M, 4, 4, 700)       # includes termination tests every 25 iterations
 
 
+@pytest.mark.parametrize("kern", ["3", "4"])
+def test_n13_e_free_kernels_vs_oracle(M, kern, monkeypatch):
+    """N = 13 through the E-free kernels (MPCMP_QP13 picks them at mpcmp_create): 3 = k_qp3f + k_qp3<4, 1>; 4 = k_qp3f<4, 1, 4> + k_qp4, the
+    384-thread / 80 KB loop sized for two OCPs per CU (it does not co-reside at its 168 VGPRs, kept as a measured
+    alternative).  One full QP and a 3-iteration solve against the oracle, identical ADMM iteration counts."""
+    monkeypatch.setenv("MPCMP_QP13", kern)
+    _qp_case(M, 4, 3, 700)
+    cfg, ocfg = _cfgs(M, 4, 3)
+    from mpc_motion_planner_amd import scenarios
+    B = 3
+    x0, xf = scenarios.make_batch(B, stream_offset=40)
+    s = M.Solver(cfg, B)
+    wx = np.zeros((B, 13, 14)); wu = np.zeros((B, 13, 7)); wT = np.zeros(B)
+    for b in range(B):
+        wx[b], wu[b], wT[b] = o.warm_start(ocfg, x0[b], xf[b])
+    sx, su, sT, info = s.solve(x0, xf, (wx, wu, wT))
+    for b in range(B):
+        xs, us, T, oi = o.solve(ocfg, x0[b], xf[b], wx[b], wu[b], wT[b])
+        assert abs(sT[b] - T) <= 1e-6 * T and np.abs(sx[b] - xs).max() <= 1e-6
+        assert info["qp_iters_total"][b] == oi.qp_iters_total and info["status"][b] == oi.status
+
+
 @pytest.mark.parametrize("nseg,B,iters", [(6, 2, 5), (6, 3, 700), (8, 2, 5), (8, 3, 700)])
 def test_qp3_vs_oracle(M, nseg, B, iters):
     """k_qp3 (N = 19 as shipped, N = 25): T bordered out, E-free interior solve — one QP against the oracle's skyline Cholesky"""

@@ -56,14 +56,60 @@ def residuals(g, xs, us, T, nseg=6):
     return abs(T - g["T_mpc"]), dq, dv, da
 
 
+def probe(g, x0, xf):
+    lim = o.default_limits(); m = g["margins"]
+    xg, ug, Tg = o.warm_start_jerk(6, m[1] * lim["vmax"], m[2] * lim["amax"], m[4] * lim["jmax"], x0, xf)
+    def run(mask, **kw):
+        os.environ["ORC_PROBE"] = str(mask)
+        try:
+            cfg = o.default_config(6, 1, margins=g["margins"], **kw)
+            xs, us, T, info = o.solve(cfg, x0, xf, xg, ug, Tg)
+        finally:
+            os.environ.pop("ORC_PROBE", None)
+        return xs, us, T, info
+    out = {"scenario": "GOLD-TRAJ, N = 19, ONE SQP iteration, QP cap 700, defaults rho 0.02 / alpha 1.4 / rho_eq_scale 1e3 (profiles/r02_polympc_param_fit.json)",
+           "adopt_if": "q'' residual < 0.09 rad/s^2 (5 x below the 0.45 floor) with default-looking parameters", "variants": {}}
+    names = {0: "specification (oracle default)",
+             4: "(i) u_{N-1} pinned to the warm start (its collocation row is absent, SURVEY section 4: the stored control at tau = 1 stays ~0)",
+             1: "(iii) variable boxes keep the plain rho even when they pin a variable (x_0): only general equality rows get rho_eq",
+             2: "(iv) the QP returns the projected copy z of the step instead of x",
+             5: "(i) + (iii)", 6: "(i) + (iv)", 3: "(iii) + (iv)", 7: "(i) + (iii) + (iv)"}
+    print("%-100s %-9s %-8s %-8s %-8s %-8s" % ("variant", "T", "dT", "dq", "dv", "da"))
+    for mask, nm in names.items():
+        xs, us, T, info = run(mask)
+        dT, dq, dv, da = residuals(g, xs, us, T)
+        out["variants"][nm] = {"ORC_PROBE": mask, "T": T, "dT": dT, "dq": dq, "dv": dv, "da": da, "status": info.status}
+        print("%-100s %-9.5f %-8.5f %-8.4f %-8.4f %-8.3f" % (nm[:100], T, dT, dq, dv, da))
+    out["variants"]["(ii) duals of the first QP warm-started instead of cold"] = {
+        "not_applicable": "the stored solve is ONE SQP iteration from lambda = 0 (figure title 1SQP_700QP, and the fit): its only QP has no previous duals to start from; "
+                          "the ADMM multipliers y start at 0 either way"}
+    # where the residual of the specification sits: per sample block (node interval) and joint, accelerations
+    xs, us, T, info = run(0)
+    xs = np.array(xs); xs[0] = np.array(g["q0"] + g["v0"]); xs[-1] = np.array(g["qT"] + g["vT"])
+    smp = o.sample(6, xs, us, T, 200)
+    ra = np.abs(smp[:, 15:22] - np.array(g["a_mpc"]))
+    seg = [float(ra[int(round(200 * k / 18.0)):int(round(200 * (k + 1) / 18.0)) + 1].max()) for k in range(18)]
+    out["q_ddot_residual_max_per_node_interval"] = seg
+    out["q_ddot_residual_max_per_joint"] = [float(v) for v in ra.max(axis=0)]
+    out["q_ddot_residual_argmax_sample"] = int(ra.max(axis=1).argmax())
+    print("max |q'' - stored| per node interval:", " ".join("%.2f" % v for v in seg))
+    print("per joint:", " ".join("%.2f" % v for v in out["q_ddot_residual_max_per_joint"]), " worst sample", out["q_ddot_residual_argmax_sample"], "of 200")
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_polympc_structure_probe.json"), "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="finer grid (minutes instead of seconds)")
     ap.add_argument("--warm", choices=["jerk", "stored"], default="jerk",
                     help="jerk: the oracle's Ruckig stand-in at the node times (default); stored: the 201 stored Ruckig samples, interpolated")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_polympc_param_fit.json"))
+    ap.add_argument("--probe", action="store_true",
+                    help="structure probe (VERDICT r2 item 7): where the best setting's residual sits (per node and joint), and four structural "
+                         "hypotheses (oracle/ocp.c ORC_PROBE) against the stored solve; writes profiles/r03_polympc_structure_probe.json")
     args = ap.parse_args()
     g, x0, xf = gold()
+    if args.probe:
+        return probe(g, x0, xf)
     if args.warm == "stored":
         xg, ug, Tg = rk_nodes(g, x0, 6)
     else:
