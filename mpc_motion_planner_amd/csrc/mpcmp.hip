@@ -1371,7 +1371,7 @@ extern "C" int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name,
     }
     ctx->ev_used = 0;
     ctx->timing = true;            // event recording starts with the first call (bench.py calls it once before the timed region)
-    if (name) *name = ctx->nseg >= 6 ? "k_qp3" : ((ctx->nseg == 2 || ctx->nseg == 4) ? "k_qp2" : "k_qp");
+    if (name) *name = ctx->nseg >= 6 ? "k_qp3" : (ctx->nseg == 4 && ctx->qp13 == 3 ? "k_qp3" : (ctx->nseg == 4 && ctx->qp13 == 4 ? "k_qp4" : ((ctx->nseg == 2 || ctx->nseg == 4) ? "k_qp2" : "k_qp")));
     if (ms_total) *ms_total = ctx->qp_ms;
     if (launches) *launches = ctx->qp_launches;
     if (reset) { ctx->qp_ms = 0.0; ctx->qp_launches = 0; }
