@@ -9,7 +9,7 @@ if len(sys.argv) <= 1:
                            '-DMPCMP_SPLIT_N25', *os.environ.get('EXTRA', '').split(), '-S', '--cuda-device-only', '-o', asm, os.path.join(ROOT, 'mpc_motion_planner_amd/csrc/mpcmp.hip')],
                           stderr=subprocess.DEVNULL)
 s = open(asm).read()
-name = '_ZN5mpcmp5k_qp4ILi4EEEv12mpcmp_configNS_2WSEPKjiPKd'
+name = os.environ.get('KNAME', '_ZN5mpcmp5k_qp4ILi4EEEv12mpcmp_configNS_2WSEPKjiPKd')
 i = s.index(name + ':'); j = s.index('.end_amdhsa_kernel', i)
 lines = s[i:j].split('\n')
 labels = {}
@@ -25,7 +25,7 @@ for n, l in enumerate(lines):
     if t in labels and labels[t] < n and (t not in seen):
         seg = lines[labels[t]:n]
         nb = sum(1 for x in seg if 's_barrier' in x)
-        if nb < 7: continue
+        if nb < int(os.environ.get('MINB', '7')): continue
         seen.add(t)
         ns = sum(1 for x in seg if x.strip().startswith('scratch_'))
         print('loop', t, 'lines', labels[t], n, 'len', n - labels[t], 'barriers', nb, 'scratch', ns)
