@@ -37,6 +37,10 @@ class Info(C.Structure):
                 ("qp_iters_total", C.c_int), ("sqp_iters", C.c_int), ("status", C.c_int), ("qp_capped", C.c_int)]
 
 
+# status bits of mpcmp_info.status (include/mpcmp.h)
+STATUS_NAN, STATUS_NOT_PD, STATUS_XCH_DEAD, STATUS_QP_CAPPED, STATUS_OUTSIDE_TOL, STATUS_T_OUT_OF_BOX = 1, 2, 4, 8, 16, 32
+STATUS_HARD = STATUS_NAN | STATUS_NOT_PD | STATUS_XCH_DEAD        # the solve itself failed (the other bits grade the returned iterate)
+
 INFO_DTYPE = np.dtype([("T", "f8"), ("viol_l1", "f8"), ("defect_inf", "f8"), ("path_viol_inf", "f8"),
                        ("term_err_inf", "f8"), ("last_alpha", "f8"), ("qp_iters_total", "i4"),
                        ("sqp_iters", "i4"), ("status", "i4"), ("qp_capped", "i4")])

@@ -205,3 +205,30 @@ def test_jerk_limited_warm_start_random_states():
         dq = np.cumsum(0.5 * (v[1:] + v[:-1]) * np.diff(out[:, 0])[:, None], axis=0)
         assert np.abs(q[1:] - q[0] - dq).max() < 5e-3
     assert worst <= 1.0 + 1e-9 or worst < 1.6     # (a joint that fell back to a quintic may overshoot a limit)
+
+
+def test_status_word_semantics():
+    """mpcmp_info.status / orc_info.status (include/mpcmp.h MPCMP_STATUS_*; the reference never reads mpc.info().status, motionPlanner.cpp:191):
+    bit 8 = a QP stopped at qp_iters (qp_capped counts them), bit 16 = returned iterate outside tolerance, bit 32 = T outside its box,
+    0 = converged QPs and an iterate inside every tolerance.  The kernels report the same word (tests/test_gpu_parity.py)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mpcmp.h")).read()
+    bits = {k: int(v) for k, v in re.findall(r"#define MPCMP_STATUS_(\w+)\s+(\d+)", hdr)}
+    assert bits == {"NAN": 1, "NOT_PD": 2, "XCH_DEAD": 4, "QP_CAPPED": 8, "OUTSIDE_TOL": 16, "T_OUT_OF_BOX": 32}
+    margins = (0.9, 0.9, 0.5, 0.9, 0.1)
+    x0 = np.array([0.0, -0.5, 0.0, -2.0, 0.0, 1.6, 0.0] + [0.0] * 7); xf = x0.copy(); xf[:7] += 0.05         # an easy problem
+    # (a) every QP is cut off after 5 iterations: capped, the count says how often
+    cfg = o.default_config(4, 3, margins=margins, qp_iters=5, check_every=5)
+    xg, ug, Tg = o.warm_start(cfg, x0, xf)
+    _, _, _, info = o.solve(cfg, x0, xf, xg, ug, Tg)
+    assert info.status & 8 and info.qp_capped == 3 and info.qp_iters_total == 15
+    # (b) the same problem solved to the end: QPs converge, the iterate is inside every tolerance -> status 0, nothing capped
+    cfg = o.default_config(4, 8, margins=margins)
+    _, _, T, info = o.solve(cfg, x0, xf, xg, ug, Tg)
+    outside = info.defect_inf > cfg.eps_abs or info.path_viol_inf > cfg.eps_abs or info.term_err_inf > cfg.eps_target + cfg.eps_abs
+    assert bool(info.status & 16) == outside and bool(info.status & 8) == (info.qp_capped > 0) and not info.status & 7
+    assert cfg.lbT <= T <= cfg.ubT and not info.status & 32
+    # (c) a final-time box that excludes the answer is reported
+    cfg = o.default_config(4, 2, margins=margins); cfg.ubT = 0.05
+    _, _, T, info = o.solve(cfg, x0, xf, xg, ug, Tg)
+    assert (T > cfg.ubT + 1e-9) == bool(info.status & 32)
