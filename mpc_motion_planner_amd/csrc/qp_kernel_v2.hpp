@@ -223,6 +223,7 @@ struct Qp2Ctx {
 #ifdef MPCMP_STAMPS
 // the accumulators of the loop stamps live in LDS: role A1 has no registers to spare
 #define STAMP2(slot) do { if (c.tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
+#ifndef MPCMP_STAMPS_LIGHT      // (-DMPCMP_STAMPS_LIGHT: wave 0's phase stamps only; they perturb the loop by < 1 %, the busy counters by ~30 %)
 // per-wave busy time of each ADMM phase (barrier exit -> arrival at the phase's closing barrier): dbg[16 + wave*8 + phase]
 #define BUSY_DECL unsigned long long busy_t = clock64(); \
     unsigned long long *busy_acc = reinterpret_cast<unsigned long long *>(c.lds + L::oBusy) + (c.tid >> 6) * 8; \
@@ -230,6 +231,11 @@ struct Qp2Ctx {
 #define BUSY_SYNC(ph) do { if ((c.tid & 63) == 0) busy_acc[ph] += clock64() - busy_t; __syncthreads(); busy_t = clock64(); } while (0)
 #define BUSY_DUMP do { if ((c.tid & 63) == 0) for (int k_ = 0; k_ < 8; k_++) \
     c.ws.dbg[(size_t)c.b * MPCMP_DBG_WORDS + 16 + (c.tid >> 6) * 8 + k_] = busy_acc[k_]; } while (0)
+#else
+#define BUSY_DECL do { } while (0)
+#define BUSY_SYNC(ph) __syncthreads()
+#define BUSY_DUMP do { } while (0)
+#endif
 #else
 #define STAMP2(slot) do { } while (0)
 #define BUSY_DECL do { } while (0)

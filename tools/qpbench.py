@@ -5,6 +5,9 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import mpc_motion_planner_amd.capi as _capi
+if os.environ.get("QPB_LIB"):
+    _capi._SO = os.path.abspath(os.environ["QPB_LIB"])      # A/B against another build of the library
 import mpc_motion_planner_amd as M
 from mpc_motion_planner_amd import scenarios
 nseg = int(os.environ.get("QPB_NSEG", "4"))
