@@ -172,8 +172,9 @@ class PandaWrapper {
 class MotionPlanner;
 namespace mpcmp_shim {
 // What a reference caller can reach through the public member `mpc` (motionPlanner.hpp:28-29: polympc's MPC<> object),
-// reduced to the read-side calls the facade itself uses (motionPlanner.cpp:15-20,184-207; motionPlanner.hpp:106-125):
-// settings, the solution and its interpolation, and the solver info.  The polympc object itself does not exist here.
+// reduced to the calls the facade itself makes (motionPlanner.cpp:15-20,33,47,72-97,172-174,184-207; motionPlanner.hpp:106-125):
+// settings, guesses, bounds, solve, the solution and its interpolation, and the solver info.  The polympc object itself does
+// not exist here: the setters write the planner's configuration record and guess, which the next solve hands to the library.
 struct MpcView {
     struct Settings { int &max_iter; int &line_search_max_iter; };
     struct QpSettings { int &max_iter; double &eps_rel; double &eps_abs; };
@@ -189,6 +190,49 @@ struct MpcView {
     Mat<NDOF, 1> solution_u_at(double t) const;
     InfoView info() const;
     std::vector<double> time_nodes() const;                // mpc.ocp().time_nodes
+    // ---- write side ----
+    // guesses in the layout of solution_x() / solution_u(): node-major, node 0 = the current state (motionPlanner.cpp:172-174,205-207)
+    void x_guess(const std::vector<double> &x);            // [14 N]
+    void u_guess(const std::vector<double> &u);            // [7 N]
+    void p_guess(const std::array<double, 1> &p);          // final time
+    void p_guess(double T) { p_guess(std::array<double, 1>{T}); }
+    // bounds (motionPlanner.cpp:72,75,80,97); they are overwritten by the next set_constraint_margins(), as in the reference
+    void state_bounds(const Mat<2 * NDOF, 1> &lb, const Mat<2 * NDOF, 1> &ub);
+    void control_bounds(const Mat<NDOF, 1> &lb, const Mat<NDOF, 1> &ub);
+    void parameters_bounds(const std::array<double, 1> &lb, const std::array<double, 1> &ub);
+    void constraints_bounds(const Mat<NDOF + 1, 1> &lb, const Mat<NDOF + 1, 1> &ub);      // 7 torques, tool height
+    // motionPlanner.cpp:47 / :33: the solver pins the first node to the centre of the box and keeps the last node within its
+    // half-width (one half-width for all 14 entries: the largest given)
+    void initial_state_bounds(const Mat<2 * NDOF, 1> &lb, const Mat<2 * NDOF, 1> &ub);
+    void final_state_bounds(const Mat<2 * NDOF, 1> &lb, const Mat<2 * NDOF, 1> &ub);
+    void solve();                                          // motionPlanner.cpp:184, from the guess set above
+  private:
+    MotionPlanner *owner;
+};
+
+// Look-alikes of the three Ruckig members (motionPlanner.hpp:34-37) for callers that touch them directly: the input record
+// (ruckig::InputParameter's field names), the trajectory (get_duration / at_time) and `otg.calculate(input, trajectory)`.
+// Behind them is the library's jerk-limited, time-synchronised generator (mpcmp_jerk_point_batch); target / current
+// accelerations other than zero are not supported by it and are ignored.
+enum Result { Working = 0, Finished = 1, Error = -1 };     // ruckig::Result, the values motionPlanner.cpp:149 can see
+struct InputParameter {
+    std::array<double, NDOF> current_position{}, current_velocity{}, current_acceleration{};
+    std::array<double, NDOF> target_position{}, target_velocity{}, target_acceleration{};
+    std::array<double, NDOF> max_velocity{}, max_acceleration{}, max_jerk{};
+};
+struct Trajectory {
+    double get_duration() const { return duration; }
+    // position, velocity, acceleration at min(time, duration) (ruckig::Trajectory::at_time, motionPlanner.cpp:160)
+    void at_time(double time, std::array<double, NDOF> &position, std::array<double, NDOF> &velocity, std::array<double, NDOF> &acceleration) const;
+  private:
+    friend struct Otg;
+    MotionPlanner *owner = nullptr;
+    InputParameter in;
+    mutable double duration = 0.0;
+};
+struct Otg {
+    explicit Otg(MotionPlanner *o) : owner(o) {}
+    Result calculate(const InputParameter &input, Trajectory &trajectory);    // motionPlanner.cpp:149
   private:
     MotionPlanner *owner;
 };
@@ -202,6 +246,9 @@ class MotionPlanner {
     mpc_t mpc{this};                                                     // motionPlanner.hpp:28-29 (view, see MpcView)
 
     PandaWrapper robot;
+    mpcmp_shim::Otg otg{this};                                           // motionPlanner.hpp:35-37 (look-alikes, see above)
+    mpcmp_shim::Trajectory trajectory;
+    mpcmp_shim::InputParameter input;
     Vec14 current_state, target_state;
     const double eps = 1e-2;                                            // motionPlanner.hpp:44
     const double inf = std::numeric_limits<double>::infinity();
@@ -227,11 +274,17 @@ class MotionPlanner {
     MotionPlanner(const MotionPlanner &) = delete;
     MotionPlanner &operator=(const MotionPlanner &) = delete;
 
-    void set_target_state(Vec7 target_position, Vec7 target_velocity, Vec7 = Vec7::Zero()) {     // motionPlanner.cpp:27-39
-        for (int j = 0; j < 7; j++) { target_state(j) = target_position(j); target_state(7 + j) = target_velocity(j); }
+    void set_target_state(Vec7 target_position, Vec7 target_velocity, Vec7 target_acceleration = Vec7::Zero()) {     // motionPlanner.cpp:27-39
+        for (int j = 0; j < 7; j++) {
+            target_state(j) = target_position(j); target_state(7 + j) = target_velocity(j);
+            input.target_position[j] = target_position(j); input.target_velocity[j] = target_velocity(j); input.target_acceleration[j] = target_acceleration(j);
+        }
     }
-    void set_current_state(Vec7 current_position, Vec7 current_velocity, Vec7 = Vec7::Zero()) {  // motionPlanner.cpp:41-54
-        for (int j = 0; j < 7; j++) { current_state(j) = current_position(j); current_state(7 + j) = current_velocity(j); }
+    void set_current_state(Vec7 current_position, Vec7 current_velocity, Vec7 current_acceleration = Vec7::Zero()) {  // motionPlanner.cpp:41-54
+        for (int j = 0; j < 7; j++) {
+            current_state(j) = current_position(j); current_state(7 + j) = current_velocity(j);
+            input.current_position[j] = current_position(j); input.current_velocity[j] = current_velocity(j); input.current_acceleration[j] = current_acceleration(j);
+        }
     }
     void set_constraint_margins(double margin_position, double margin_velocity, double margin_acceleration,
                                 double margin_torque, double margin_jerk) {                          // motionPlanner.cpp:56-90
@@ -240,6 +293,11 @@ class MotionPlanner {
         mpcmp_set_margins(&config, margin_position, margin_velocity, margin_acceleration, margin_torque);
         mpcmp_set_min_height(&config, robot.min_height);
         push_config();
+        for (int j = 0; j < 7; j++) {                                    // motionPlanner.cpp:86-88
+            input.max_velocity[j] = margin_velocity * robot.max_velocity(j);
+            input.max_acceleration[j] = margin_acceleration * robot.max_acceleration(j);
+            input.max_jerk[j] = margin_jerk * robot.max_jerk(j);
+        }
     }
     void set_min_height(double min_height) { mpcmp_set_min_height(&config, min_height); push_config(); }  // :92-100
 
@@ -318,11 +376,7 @@ class MotionPlanner {
             guess_is_profile_ = true;
             for (int r = 0; r < 14; r++) { guess_x0_[r] = current_state(r); guess_xf_[r] = target_state(r); }
         } else { guess_x_ = warm_x_; guess_u_ = warm_u_; guess_T_ = warm_T_; guess_is_profile_ = false; }
-        chk(mpcmp_solve_batch(ctx_, 1, current_state.data(), target_state.data(), guess_x_.data(), guess_u_.data(), &guess_T_,
-                              sol_x_.data(), sol_u_.data(), &sol_T_, &last_info));
-        // "Fix initial and final point at correct place" (motionPlanner.cpp:199-207)
-        warm_x_ = sol_x_; warm_u_ = sol_u_; warm_T_ = sol_T_; have_warm_ = true;
-        for (int r = 0; r < 14; r++) { warm_x_[r] = current_state(r); warm_x_[(size_t)14 * (N_ - 1) + r] = target_state(r); }
+        solve_from_guess();
     }
 
     // B independent problems in one call (the loop of examples/benchmark.cpp:16). x0/xf: [B][14]
@@ -445,16 +499,25 @@ class MotionPlanner {
 
   private:
     friend struct mpcmp_shim::MpcView;
+    friend struct mpcmp_shim::Trajectory;
+    friend struct mpcmp_shim::Otg;
     mpcmp_ctx *ctx_ = nullptr;
     int N_ = 0, max_batch_ = 0;
     std::vector<double> sol_x_, sol_u_, warm_x_, warm_u_, guess_x_, guess_u_;
     double sol_T_ = 0, warm_T_ = 0, guess_T_ = 0;
     bool guess_is_profile_ = false;                 // the last guess came from the jerk-limited generator
     double guess_x0_[14] = {0}, guess_xf_[14] = {0};
-    void jerk_limits(double *jm) const { for (int j = 0; j < 7; j++) jm[j] = margin_jerk_ * robot.max_jerk(j); }   // motionPlanner.cpp:86-88
+    void jerk_limits(double *jm) const { for (int j = 0; j < 7; j++) jm[j] = input.max_jerk[j]; }   // motionPlanner.cpp:86-88,149 (margin_jerk * max_jerk unless the caller wrote `input`)
     bool have_warm_ = false;
     uint64_t rng_ = 20240001ull;
 
+    // mpc.solve() from (guess_x_, guess_u_, guess_T_), then "Fix initial and final point at correct place" (motionPlanner.cpp:184-207)
+    void solve_from_guess() {
+        chk(mpcmp_solve_batch(ctx_, 1, current_state.data(), target_state.data(), guess_x_.data(), guess_u_.data(), &guess_T_,
+                              sol_x_.data(), sol_u_.data(), &sol_T_, &last_info));
+        warm_x_ = sol_x_; warm_u_ = sol_u_; warm_T_ = sol_T_; have_warm_ = true;
+        for (int r = 0; r < 14; r++) { warm_x_[r] = current_state(r); warm_x_[(size_t)14 * (N_ - 1) + r] = target_state(r); }
+    }
     void chk(int rc) { if (rc) throw std::runtime_error(std::string("mpcmp: ") + mpcmp_last_error(ctx_)); }
     void push_config() { if (ctx_) chk(mpcmp_set_config(ctx_, &config)); }
     double uniform() {   // [-1,1), SplitMix64
@@ -511,4 +574,76 @@ inline std::vector<double> mpcmp_shim::MpcView::time_nodes() const {
     std::vector<double> t((size_t)owner->N_);
     mpcmp_time_nodes(owner->config.num_seg, t.data());
     return t;
+}
+// write side
+inline void mpcmp_shim::MpcView::x_guess(const std::vector<double> &x) {
+    if (x.size() != (size_t)14 * owner->N_) throw std::invalid_argument("mpc.x_guess: expected 14 * N entries");
+    owner->warm_x_ = x; owner->have_warm_ = true;
+    if (owner->warm_u_.size() != (size_t)7 * owner->N_) owner->warm_u_.assign((size_t)7 * owner->N_, 0.0);
+}
+inline void mpcmp_shim::MpcView::u_guess(const std::vector<double> &u) {
+    if (u.size() != (size_t)7 * owner->N_) throw std::invalid_argument("mpc.u_guess: expected 7 * N entries");
+    owner->warm_u_ = u;
+    if (owner->warm_x_.size() != (size_t)14 * owner->N_) owner->warm_x_.assign((size_t)14 * owner->N_, 0.0);
+}
+inline void mpcmp_shim::MpcView::p_guess(const std::array<double, 1> &p) { owner->warm_T_ = p[0]; }
+inline void mpcmp_shim::MpcView::state_bounds(const Mat<2 * NDOF, 1> &lb, const Mat<2 * NDOF, 1> &ub) {
+    for (int r = 0; r < 14; r++) { owner->config.lbx[r] = lb(r); owner->config.ubx[r] = ub(r); }
+    owner->push_config();
+}
+inline void mpcmp_shim::MpcView::control_bounds(const Mat<NDOF, 1> &lb, const Mat<NDOF, 1> &ub) {
+    for (int r = 0; r < 7; r++) { owner->config.lbu[r] = lb(r); owner->config.ubu[r] = ub(r); }
+    owner->push_config();
+}
+inline void mpcmp_shim::MpcView::parameters_bounds(const std::array<double, 1> &lb, const std::array<double, 1> &ub) {
+    owner->config.lbT = lb[0]; owner->config.ubT = ub[0];
+    owner->push_config();
+}
+inline void mpcmp_shim::MpcView::constraints_bounds(const Mat<NDOF + 1, 1> &lb, const Mat<NDOF + 1, 1> &ub) {
+    for (int r = 0; r < 8; r++) { owner->config.lbg[r] = lb(r); owner->config.ubg[r] = ub(r); }
+    owner->push_config();
+}
+inline void mpcmp_shim::MpcView::initial_state_bounds(const Mat<2 * NDOF, 1> &lb, const Mat<2 * NDOF, 1> &ub) {
+    for (int r = 0; r < 14; r++) owner->current_state(r) = 0.5 * (lb(r) + ub(r));
+}
+inline void mpcmp_shim::MpcView::final_state_bounds(const Mat<2 * NDOF, 1> &lb, const Mat<2 * NDOF, 1> &ub) {
+    double hw = 0.0;
+    for (int r = 0; r < 14; r++) { owner->target_state(r) = 0.5 * (lb(r) + ub(r)); hw = std::fmax(hw, 0.5 * (ub(r) - lb(r))); }
+    owner->config.eps_target = hw;
+    owner->push_config();
+}
+inline void mpcmp_shim::MpcView::solve() {
+    if (!owner->have_warm_) throw std::logic_error("mpc.solve: no guess (x_guess / u_guess / p_guess, warm_start or a previous solve)");
+    owner->guess_x_ = owner->warm_x_; owner->guess_u_ = owner->warm_u_; owner->guess_T_ = owner->warm_T_; owner->guess_is_profile_ = false;
+    owner->solve_from_guess();
+}
+
+// Ruckig look-alikes.  The generator takes its velocity / acceleration limits from the context's bounds: a caller-written
+// input.max_velocity / max_acceleration is applied for the duration of the call and the planner's own bounds are restored.
+inline mpcmp_shim::Result mpcmp_shim::Otg::calculate(const InputParameter &input, Trajectory &trajectory) {
+    trajectory.owner = owner; trajectory.in = input;
+    std::array<double, NDOF> p, v, a;
+    trajectory.duration = -1.0;
+    trajectory.at_time(0.0, p, v, a);                       // (fills the duration)
+    return trajectory.duration >= 0.0 ? Working : Error;    // ruckig's offline calculate() returns Working on success
+}
+inline void mpcmp_shim::Trajectory::at_time(double time, std::array<double, NDOF> &position, std::array<double, NDOF> &velocity,
+                                            std::array<double, NDOF> &acceleration) const {
+    if (!owner) throw std::logic_error("Trajectory::at_time before otg.calculate");
+    double x0[14], xf[14], o[28], T = 0.0;
+    for (int j = 0; j < 7; j++) { x0[j] = in.current_position[j]; x0[7 + j] = in.current_velocity[j]; xf[j] = in.target_position[j]; xf[7 + j] = in.target_velocity[j]; }
+    const mpcmp_config keep = owner->config;
+    mpcmp_config tmp = keep;
+    bool differs = false;
+    for (int j = 0; j < 7; j++) {
+        differs |= tmp.ubx[7 + j] != in.max_velocity[j] || tmp.ubu[j] != in.max_acceleration[j];
+        tmp.ubx[7 + j] = in.max_velocity[j]; tmp.lbx[7 + j] = -in.max_velocity[j];
+        tmp.ubu[j] = in.max_acceleration[j]; tmp.lbu[j] = -in.max_acceleration[j];
+    }
+    if (differs) owner->chk(mpcmp_set_config(owner->ctx_, &tmp));
+    const int rc = mpcmp_jerk_point_batch(owner->ctx_, 1, x0, xf, in.max_jerk.data(), &time, o, &T);
+    if (differs) owner->chk(mpcmp_set_config(owner->ctx_, &keep));
+    owner->chk(rc);
+    duration = T;
+    for (int j = 0; j < 7; j++) { position[j] = o[j]; velocity[j] = o[7 + j]; acceleration[j] = o[14 + j]; }
 }

@@ -72,6 +72,26 @@ def test_cpp_shim_warm_start_solve_points_vs_oracle(M, tmp_path):
     assert np.abs(pb[:14] - xf).max() < 1e-9 and np.abs(pb[14:21]).max() < 1e-6
     assert np.abs(pb[21:] - o.rnea(xf[:7], xf[7:], pb[14:21])).max() < 1e-9
     assert abs(r["tool_z"] - o.fk(xf[:7])[3][2]) < 1e-12
+    # write side of `mpc` (motionPlanner.hpp:28-29): the same guess handed over through x_guess / u_guess / p_guess + mpc.solve()
+    # is the same solve, bit for bit
+    assert r["T_guess_api"] == r["T_warm"] and r["iters_guess_api"] == r["iters_warm"]
+    # mpc.control_bounds (motionPlanner.cpp:75) at 40 % of the limits, solved from the previous solution with its end states
+    # re-pinned (motionPlanner.cpp:199-207): the oracle with the same box
+    lim = o.default_limits()
+    _, obox = _cfgs(M, 4, 3)
+    for j in range(7):
+        obox.lbu[j] = -0.4 * lim["amax"][j]; obox.ubu[j] = 0.4 * lim["amax"][j]
+    gx = xs.copy(); gx[0] = x0; gx[-1] = xf
+    xs3, us3, T3, oi3 = o.solve(obox, x0, xf, gx, us, T)
+    assert abs(r["T_ctrl_box"] - T3) <= 1e-6 * T3 and r["iters_ctrl_box"] == oi3.qp_iters_total
+    assert np.abs(np.array(r["u_max_ctrl_box"]) - np.abs(us3).max(axis=0) / lim["amax"]).max() < 1e-6
+    assert np.abs(us3).max() > 0 and (np.abs(us3).max(axis=0) / lim["amax"]).max() < 0.45       # the box is what binds
+    # the Ruckig members: otg.calculate(input, trajectory) / trajectory.at_time are get_RK_point's trajectory; caller-written
+    # limits in the input record are honoured (half the jerk, 80 % of the velocity: the oracle generator with those limits)
+    assert r["otg_result"] == 0 and abs(r["rk_duration"] - Trk) <= 1e-9 * Trk
+    assert np.abs(np.array(r["rk_at_time"]) - pin[:21]).max() == 0.0
+    _, Tslow = o.jerk_trajectory(0.8 * vmax, amax, 0.5 * jmax, x0, xf, 10)
+    assert abs(r["rk_duration_slow"] - Tslow) <= 1e-9 * Tslow and Tslow > Trk
 
 
 def test_python_batch_motion_planner_vs_oracle(M):
