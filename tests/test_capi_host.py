@@ -122,10 +122,18 @@ def test_cpp_shim_and_example_compile(M, tmp_path):
                            os.path.join(ROOT, "examples", "offline_trajectory.cpp"),
                            "-L" + os.path.join(ROOT, "mpc_motion_planner_amd"), "-lmpcmp",
                            "-Wl,-rpath," + os.path.join(ROOT, "mpc_motion_planner_amd"), "-o", exe])
+    # the selftest touches every member of the mirror, incl. the write side of `mpc` and the Ruckig look-alikes (-Wall -Werror:
+    # the header must stay warning-free for a caller's build)
+    exe2 = str(tmp_path / "shim_selftest")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "shim_selftest.cpp"),
+                           "-L" + os.path.join(ROOT, "mpc_motion_planner_amd"), "-lmpcmp",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mpc_motion_planner_amd"), "-o", exe2])
     import torch
     if not torch.cuda.is_available():
-        r = subprocess.run([exe], capture_output=True, text=True)
-        assert r.returncode == 1 and "no CPU fallback" in r.stderr
+        for e in (exe, exe2):
+            r = subprocess.run([e], capture_output=True, text=True)
+            assert r.returncode == 1 and "no CPU fallback" in r.stderr
 
 
 # ---- scenario helpers of the robot wrapper (robot_utils/pandaWrapper.cpp:14-107): host code, no GPU needed ----
