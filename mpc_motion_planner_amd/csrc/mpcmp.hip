@@ -20,6 +20,7 @@
 #include "qp_kernel_v2.hpp"
 #include "qp_kernel_v3.hpp"
 #include "qp_kernel_v4.hpp"
+#include "qp_kernel_v5.hpp"
 #include "multi_kernels.hpp"
 #include "kinematics_host.hpp"
 #include "jerk_device.hpp"
@@ -67,6 +68,7 @@ struct mpcmp_ctx {
     uint32_t *d3_terms = nullptr;
     uint32_t *d_lane4 = nullptr;   // lane-constant table of k_qp4 (qp4_build_lanes)
     int qp13 = 2;                  // QP kernel of num_seg 4: 2 = k_qp2, 3 = k_qp3f + k_qp3, 4 = k_qp3f + k_qp4 (env MPCMP_QP13)
+    int qp19 = 5;                  // QP kernel of num_seg 6, one arm: 5 = k_qp3f<6, 1, 5> + k_qp5 (factor resident in registers), 3 = k_qp3f + k_qp3 (env MPCMP_QP19)
     // timing of the dominant kernel (k_qp)
     struct EvPair { hipEvent_t e[2]; };
     std::vector<EvPair> ev;          // at most MAX_EV pairs are ever created; launches beyond that are not timed until the
@@ -642,7 +644,11 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
         }
         return true;
     };
-    auto fac_doubles = [](int nseg) -> size_t { return nseg == 4 ? std::max<size_t>(Qp3<4>::FAC, Qp4Fac<4>::FAC) : (nseg == 6 ? Qp3<6>::FAC : Qp3<8>::FAC); };
+    auto fac_doubles = [](int nseg) -> size_t { return nseg == 4 ? std::max<size_t>(Qp3<4>::FAC, Qp4Fac<4>::FAC) : (nseg == 6 ? std::max<size_t>(Qp3<6>::FAC, Qp5Fac<6>::FAC) : Qp3<8>::FAC); };
+    if (cfg->num_seg == 6 && narm == 1) {
+        if (const char *e = std::getenv("MPCMP_QP19")) ctx->qp19 = std::atoi(e);
+        if (ctx->qp19 != 3 && ctx->qp19 != 5) { ctx->err = "MPCMP_QP19 must be 3 (k_qp3) or 5 (k_qp5)"; return fail(MPCMP_EINVAL); }
+    }
     if (cfg->num_seg >= 6) {
         Qp3Pat pat;
         if (!build_v3(cfg->num_seg, tab, pat)) { ctx->err = "internal: structure table generation failed"; return fail(MPCMP_EINVAL); }
@@ -763,6 +769,10 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     const bool V2 = V2C && !force_v1 && !V3C && !V4;
     const size_t l_qp3 = Qp3<V3T ? NSEG : 6>::sizeL * sizeof(double), l_qp3f = Qp3<V3T ? NSEG : 6>::sizeF * sizeof(double);
     if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3T ? NSEG : 6, 1>, l_qp3)) return rc; if (int rc = set_lds(ctx, k_qp3f<V3T ? NSEG : 6, 1>, l_qp3f)) return rc; }
+    if (NSEG == 6 && ctx->qp19 == 5) {
+        if (int rc = set_lds(ctx, k_qp5<6>, Qp5<6>::size5 * sizeof(double))) return rc;
+        if (int rc = set_lds(ctx, k_qp3f<6, 1, 5>, Qp3<6>::sizeF * sizeof(double))) return rc;
+    }
     const size_t l_qp4 = Qp4<4>::size * sizeof(double);
     if (V4) {
         if (int rc = set_lds(ctx, k_qp4<4>, l_qp4)) return rc;
@@ -819,6 +829,11 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
                 double *fh = ctx->d_fac + (size_t)boff[h] * Qp4Fac<4>::FAC;
                 hipLaunchKernelGGL((k_qp3f<4, 1, 4>), dim3(Bh[h]), dim3(1024), Qp3<4>::sizeF * sizeof(double), sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
                 hipLaunchKernelGGL((k_qp4<4>), dim3(Bh[h]), dim3(384), l_qp4, sh[h], ctx->cfg, w3, (const uint32_t *)ctx->d_lane4, Bh[h], (const double *)fh);
+            }
+            else if (NSEG == 6 && ctx->qp19 == 5) {
+                double *fh = ctx->d_fac + (size_t)boff[h] * Qp5Fac<6>::FAC;
+                hipLaunchKernelGGL((k_qp3f<6, 1, 5>), dim3(Bh[h]), dim3(1024), Qp3<6>::sizeF * sizeof(double), sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);
+                hipLaunchKernelGGL((k_qp5<6>), dim3(Bh[h]), dim3(768), Qp5<6>::size5 * sizeof(double), sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
             }
             else if (V3C) {
                 WS w3 = wh[h];
@@ -1371,7 +1386,7 @@ extern "C" int mpcmp_kernel_timing(mpcmp_ctx *ctx, int reset, const char **name,
     }
     ctx->ev_used = 0;
     ctx->timing = true;            // event recording starts with the first call (bench.py calls it once before the timed region)
-    if (name) *name = ctx->nseg >= 6 ? "k_qp3" : (ctx->nseg == 4 && ctx->qp13 == 3 ? "k_qp3" : (ctx->nseg == 4 && ctx->qp13 == 4 ? "k_qp4" : ((ctx->nseg == 2 || ctx->nseg == 4) ? "k_qp2" : "k_qp")));
+    if (name) *name = (ctx->nseg == 6 && ctx->narm == 1 && ctx->qp19 == 5) ? "k_qp5" : ctx->nseg >= 6 ? "k_qp3" : (ctx->nseg == 4 && ctx->qp13 == 3 ? "k_qp3" : (ctx->nseg == 4 && ctx->qp13 == 4 ? "k_qp4" : ((ctx->nseg == 2 || ctx->nseg == 4) ? "k_qp2" : "k_qp")));
     if (ms_total) *ms_total = ctx->qp_ms;
     if (launches) *launches = ctx->qp_launches;
     if (reset) { ctx->qp_ms = 0.0; ctx->qp_launches = 0; }

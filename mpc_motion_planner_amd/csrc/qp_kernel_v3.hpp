@@ -158,6 +158,23 @@ struct Qp4Fac {
     static constexpr int FAC = fG + 28 * 384;
 };
 
+// factor workspace of k_qp3f<NSEG, 1, 5> -> k_qp5 (qp_kernel_v5.hpp), doubles per problem: Qp3's up to the G blocks, then S^-1 in
+// 4 x 13 blocks (eight lanes per group of four rows: lane ls = 8 gs + c8 keeps rows 4 gs + ((c8 & 3) ^ pos), columns 13 c8 .. + 12,
+// entry 13 pos + j at [entry][NSL lanes]), then E_s = G_s K_JC,s in 4 x 14 blocks (two lanes per group of four rows: lane
+// le = 26 s + 2 g + h keeps rows 4 g + (a ^ 2 h), a = 0..3, columns 14 h .. + 13 of E_s, entry 14 a + j at [entry][ELS lanes];
+// "segment" NSEG is E_u = G_u K_UX, 7 x 14; unused lanes hold zeros)
+template <int NSEG>
+struct Qp5Fac {
+    using Q3 = Qp3<NSEG>;
+    static constexpr int NSL = 8 * ((Q3::D::nI + 3) / 4);           // S lanes (200 at N = 19)
+    static constexpr int NEL = 26 * NSEG + 4;                       // E lanes in use (160)
+    static constexpr int ELS = (768 - NSL - 64 * NSEG + 31) / 32 * 32;   // lane stride of the E blocks: every lane of k_qp5 between the G waves and the S lanes (192)
+    static constexpr int oFS = Q3::oFS;                             // [52][NSL]
+    static constexpr int oFE = Q3::FAC;                             // [56][ELS]
+    static constexpr int FAC = oFE + 56 * ELS;
+    static_assert(52 * NSL <= 4 * Q3::SC * 512, "the S^-1 blocks of k_qp5 must fit the area of k_qp3's");
+};
+
 __device__ __forceinline__ void wave_sync() {
     // LDS traffic of one wave is executed in order; this only keeps the compiler from moving accesses across the hand-off
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -263,9 +280,10 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
     return x + dpp_mov<0x128>(x);                                                   // row_ror:8
 }
 
-#define QP3_PROLOGUE(NT_, FILL_CT_) \
+#define QP3_PROLOGUE(NT_, FILL_CT_) QP3_PROLOGUE_L(Qp3<NSEG>, NT_, FILL_CT_)
+#define QP3_PROLOGUE_L(LT_, NT_, FILL_CT_) \
     using D = Dim3<NSEG>; \
-    using L = Qp3<NSEG>; \
+    using L = LT_; \
     constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = NT_, GS = L::GS, JS = L::JS, SC = L::SC; \
     constexpr int n_tot = NARM * na + 1, mn_tot = NARM * (ma + na) + 1; \
     extern __shared__ __attribute__((aligned(16))) double lds[]; \
@@ -380,7 +398,8 @@ template <int NSEG, int NARM, int LAY = 3>
 __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp3Pat *__restrict__ pat, Xch xch, int B, double *__restrict__ fac) {
     QP3_PROLOGUE(1024, true)
     using L4 = Qp4Fac<NSEG>;                         // LAY == 4: hand-over in the layout of k_qp4 (qp_kernel_v4.hpp)
-    constexpr int FACSZ = LAY == 4 ? L4::FAC : L::FAC;
+    using L5 = Qp5Fac<NSEG>;                        // LAY == 5: hand-over in the layout of k_qp5 (qp_kernel_v5.hpp): + E_s, S^-1 in 4 x 13 blocks
+    constexpr int FACSZ = LAY == 4 ? L4::FAC : (LAY == 5 ? L5::FAC : L::FAC);
 #ifdef MPCMP_STAMPS
     unsigned long long fst_t = clock64();
 #define FST(k) do { if (tid == 0 && arm == 0) { const unsigned long long n_ = clock64(); ws.dbg[(size_t)b * MPCMP_DBG_WORDS + 128 + (k)] = n_ - fst_t; fst_t = n_; } } while (0)
@@ -629,6 +648,21 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
 #pragma unroll
                 for (int mt = 0; mt < 4; mt++) e[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mt], bf, e[mt], 0, 0, 0);
             }
+            if (LAY == 5) {
+                // E_s leaves for the loop kernel straight from the accumulators: register r of row tile mt holds E[16 mt + (lane >> 4) + 4 r][16 nt + (lane & 15)]
+                // (rows 49..51 of the last row group are exact zeros: their A operands were)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int R = 16 * mt + lk + 4 * r, Cc = 16 * nt + li;
+                        if (R < 52 && Cc < 28) {
+                            const int g = R >> 2, h = Cc >= 14 ? 1 : 0, a = (R & 3) ^ (2 * h), j = Cc - 14 * h;
+                            fa[L5::oFE + (14 * a + j) * L5::ELS + 26 * sw + 2 * g + h] = e[mt][r];
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 13; ks++) {
                 int lkk = lk, lii = li;
@@ -740,6 +774,22 @@ __global__ __launch_bounds__(1024) void k_qp3f(mpcmp_config cfg, WS ws, const Qp
     if (tid == 0) fa[L::oFH] = misc[L::M_sumha];
     if (LAY == 4) {
         for (int i = tid; i < nI * L4::SRS; i += NT) { const int r = i / L4::SRS, c = i % L4::SRS; fa[L4::fS + i] = c < nI ? -S[packed(r, c)] : 0.0; }
+    } else if (LAY == 5) {
+        for (int i = tid; i < 52 * L5::NSL; i += NT) {
+            const int e = i / L5::NSL, ls = i % L5::NSL, c8 = ls & 7;
+            const int row = 4 * (ls >> 3) + ((c8 & 3) ^ (e / 13)), col = 13 * c8 + e % 13;
+            fa[L5::oFS + i] = (row < nI && col < nI) ? -S[packed(row, col)] : 0.0;
+        }
+        // E_u = G_u K_UX (7 x 14) as "segment" NSEG of the E blocks (columns 14 .. 27: zero); zeros in the lanes nobody owns
+        constexpr int NU = L5::ELS - 26 * NSEG;
+        for (int i = tid; i < 56 * NU; i += NT) {
+            const int e = i / NU, lu = i % NU, g = lu >> 1, a = e / 14, c = e % 14, r = 4 * g + a;
+            double val = 0.0;
+            if (lu < 4 && (lu & 1) == 0 && r < 7) {
+                for (int q = 0; q < 7; q++) val -= lds[L::oGu + packed(r, q)] * lds[L::oKuX + q * 14 + c];      // (oGu holds -(K_UU^-1))
+            }
+            fa[L5::oFE + e * L5::ELS + 26 * NSEG + lu] = val;
+        }
     } else if (wave >= 8) {
         const int si = tid - 512, row0 = 4 * (si >> 4), mpos = si & 3, col0 = SC * (si & 15);
         for (int e = 0; e < 4 * SC; e++) {
