@@ -40,12 +40,16 @@ struct Qp5 : Qp3<NSEG> {
     static constexpr int NE = tS0 - NG;                              // lanes of the E role incl. spares
     static constexpr int NEL = F::NEL;
     static_assert(NEL <= NE && NE <= F::ELS && NG < tS0, "role map");
-    static constexpr int tP0 = NG + 64;                              // first path-row lane (448): sixteen lanes per node
-    static constexpr int NPL = NT - tP0;                             // lanes of the path-row tables (320)
-    static constexpr int tV0 = tP0 + 16 * D::N;                      // behind the path rows: the variables that have no lane on the G waves, then T (752..767)
-    static constexpr int NVL = NG + (NT - tV0);                      // variable lanes: vi = tid on the G waves, NG + (tid - tV0) behind the path rows (400)
-    static_assert(tV0 % 16 == 0 && tV0 / 64 == NWV - 1 && D::na == NVL - 1 && D::meq <= NG, "row / variable map");
-    static constexpr int tidT = NT - 1;                              // the lane that carries the ADMM state of T (vi = na)
+    static constexpr int NPN = 16 * D::N;                            // path-row lanes: sixteen per node, on the G waves (tid < 304)
+    static constexpr int tV5 = 64 * (NSEG - 1);                      // the last G wave carries no path rows: its first sixteen lanes take the variables NG .. and T
+    static constexpr int NPL = tV5;                                  // lanes of the path-row tables (320)
+    static constexpr int NVL = NG + 16;                              // variable lanes: vi = vi_of(tid) on the E / S waves, NG + (tid - tV5) on the last G wave (400)
+    static constexpr int tSP = 64 * (tS0 / 64 + 1);                  // first pure S wave (576): these waves have 8 registers more to spare than the E waves, so they take
+    static constexpr int DR0 = NT - tSP;                             // dynamics rows 0 .. DR0 - 1 on the pure S lanes (row = vi), rows DR0 .. meq - 1 on the first lanes of the last G wave
+    static constexpr int ND5 = D::meq - DR0;
+    static_assert(ND5 >= 16 && ND5 <= 64 && DR0 % 8 == 0, "dynamics rows of the last G wave");
+    __host__ __device__ static constexpr int vi_of(int tid) { return tid >= tSP ? tid - tSP : tid - NG + (NT - tSP); }      // vi = 0 .. 191 (all with a dynamics row); the E waves vi = 192 .. 383
+    static_assert(NPN <= tV5 && D::na == NVL - 1, "row / variable map");
     static constexpr int GS = 24;                                    // row stride of the path Jacobians (22 + 2 zero pads: 16-byte reads of six columns)
     static constexpr int XS = 24;                                    // node stride of x~, w of the border, gp: [x_k (14) | u_k (7) | T | pad pad]
     static constexpr int NX = XS * D::N, NXP = NX + 8;               // (slots NX, NX + 1: pads for lanes without an output)
@@ -67,8 +71,9 @@ struct Qp5 : Qp3<NSEG> {
     static constexpr int vDT = vZR + 16;                             // [5][3] columns of the differentiation matrix (column 4: zeros), [1] pad
     static constexpr int vVc = vDT + 16;                             // [6][NVL] variable constants: cf, lb, ub, ha, rho_b, 1 / rho_b
     static constexpr int vPc = vVc + 6 * NVL;                       // [4][NPL] path rows: lg, ug, rho, 1 / rho
-    static constexpr int vRc = vPc + 4 * NPL;                        // [2][NG] dynamics rows: l = u = -c_eq, T coefficient -ts f
-    static constexpr int vZ0 = vRc + 2 * NG;                         // ---- zero-initialised from here ----
+    static constexpr int NRC = (D::meq + 7) / 8 * 8;                 // rows of the dynamics-row tables
+    static constexpr int vRc = vPc + 4 * NPL;                        // [2][NRC] dynamics rows: l = u = -c_eq, T coefficient -ts f
+    static constexpr int vZ0 = vRc + 2 * NRC;                         // ---- zero-initialised from here ----
     static constexpr int vRhsJ = vZ0;                                // [NSEG][JS]
     static constexpr int vRhsU = vRhsJ + NSEG * JS;                  // [JS]
     static constexpr int vRhsI = vRhsU + JS;                         // [RIW]
@@ -91,31 +96,55 @@ struct Qp5 : Qp3<NSEG> {
     static constexpr int vPadW = vRedT + 64;                         // [8] write-only pad (16-byte stores)
     static constexpr int vVst = vPadW + 8;                           // [3][16] ADMM state x, z_b, y_b of the variables behind the path rows
     static constexpr int vZ1 = vVst + 48;                            // ---- to here ----
-    static constexpr int NF = 8;                                     // lane-constant table: [NF][NT] 32-bit words (q5_lc)
+    static constexpr int NF = 6;                                     // lane-constant table: [NF][NT] 32-bit words (q5_lc)
     static constexpr int vLCT = vZ1;
-    static constexpr int size5 = vLCT + NF * NT / 2;
+    static constexpr int vL5 = vLCT + NF * NT / 2;                   // [4][64] 32-bit words: variable / dynamics-row constants of the last G wave (q5_l5)
+    // The tail of every lane's factor block lives in LDS, lane-transposed (read with the operands of the product: same round trip): the
+    // register budget of a lane (168) minus its block leaves too little for the rows and variables otherwise (scratch reloads cost ~ 500 cycles each)
+    static constexpr int RG = 2, RE = 4, RS = 4;
+    static constexpr int vTG = vL5 + 128;                            // [RG][NG]  entries 12, 25 of the 4 x 13 blocks of G (column 12 of rows 0, 1)
+    static constexpr int vTE = vTG + RG * NG;                        // [RE][ELS] entries 13, 27, 41, 55 of the 4 x 14 blocks of E (column 13)
+    static constexpr int vTS = vTE + RE * F::ELS;                    // [RS][NSL] entries 12, 25, 38, 51 of the 4 x 13 blocks of S^-1 (column 12)
+    static constexpr int size5 = vTS + RS * NSL;
     static_assert(size5 * 8 <= 160 * 1024 - 512, "LDS budget");
     static_assert(vXn % 2 == 0 && vGp % 2 == 0 && vGpy % 2 == 0 && vXx % 2 == 0 && vPadW % 2 == 0 && oGk % 2 == 0, "16-byte accesses");
 };
 
-// 4 x 13 block of S^-1, eight lanes per group of four rows: quad reduce-scatter (g_blk), then the group's two quads are added
-// (operand reads in two batches: the lane's register budget)
-__device__ __forceinline__ double s_blk8(const double (&m)[52], const double *op) {
+// Register-resident block products.  m: the lane's block without its tail entries, tl: the lane's tail in LDS (stride ts between entries).
+// G: 4 x 13 block, four lanes per group of four rows (k_qp3's g_blk: lane (quad g, m) holds rows 4 g + (m ^ pos) x columns 13 m .. + 12; a
+// reduce-scatter over the quad leaves row 4 g + m in lane 4 g + m); entries 12 and 25 (column 12 of pos 0, 1) come from LDS.
+__device__ __forceinline__ double q5_gprod(const double (&m)[50], const double *tl, const int ts, const double *op) {
+    double o[13];
+#pragma unroll
+    for (int j = 0; j < 13; j++) o[j] = ldv(op + j);
+    const double t0 = ldv(tl), t1 = ldv(tl + ts);
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) { p0 += m[j] * o[j]; p1 += m[12 + j] * o[j]; p2 += m[24 + j] * o[j]; p3 += m[37 + j] * o[j]; }
+    p0 += t0 * o[12]; p1 += t1 * o[12]; p2 += m[36] * o[12]; p3 += m[49] * o[12];
+    const double q0 = p0 + dpp_mov<0x4E>(p2), q1 = p1 + dpp_mov<0x4E>(p3);          // lanes m, m ^ 2
+    return q0 + dpp_mov<0xB1>(q1);                                                  // lanes m, m ^ 1
+}
+// S^-1: 4 x 13 block, eight lanes per group of four rows: quad reduce-scatter as above, then the group's two quads are added; column 12 of
+// every row (entries 12, 25, 38, 51) comes from LDS.  Operand reads in two batches.
+__device__ __forceinline__ double q5_sprod(const double (&m)[48], const double *tl, const int ts, const double *op) {
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
     {
         double o[7];
 #pragma unroll
         for (int j = 0; j < 7; j++) o[j] = ldv(op + j);
 #pragma unroll
-        for (int j = 0; j < 7; j++) { p0 += m[j] * o[j]; p1 += m[13 + j] * o[j]; p2 += m[26 + j] * o[j]; p3 += m[39 + j] * o[j]; }
+        for (int j = 0; j < 7; j++) { p0 += m[j] * o[j]; p1 += m[12 + j] * o[j]; p2 += m[24 + j] * o[j]; p3 += m[36 + j] * o[j]; }
     }
-    __builtin_amdgcn_sched_barrier(0);          // (the second batch is not fetched ahead of the first batch's products)
     {
-        double o[6];
+        double o[6], t[4];
 #pragma unroll
         for (int j = 0; j < 6; j++) o[j] = ldv(op + 7 + j);
 #pragma unroll
-        for (int j = 0; j < 6; j++) { p0 += m[7 + j] * o[j]; p1 += m[20 + j] * o[j]; p2 += m[33 + j] * o[j]; p3 += m[46 + j] * o[j]; }
+        for (int q = 0; q < 4; q++) t[q] = ldv(tl + q * ts);
+#pragma unroll
+        for (int j = 0; j < 5; j++) { p0 += m[7 + j] * o[j]; p1 += m[19 + j] * o[j]; p2 += m[31 + j] * o[j]; p3 += m[43 + j] * o[j]; }
+        p0 += t[0] * o[5]; p1 += t[1] * o[5]; p2 += t[2] * o[5]; p3 += t[3] * o[5];
     }
     const double q0 = p0 + dpp_mov<0x4E>(p2), q1 = p1 + dpp_mov<0x4E>(p3);
     const double x = q0 + dpp_mov<0xB1>(q1);
@@ -151,6 +180,12 @@ __device__ __forceinline__ void q5_reduce(double (&v)[K], double *red, int tid) 
     for (int k = 0; k < K; k++) v[k] = red[NW * K + k];
 }
 
+// what-if profiling (tools/ablate5.py): -DQ5_ABL=n removes one piece of the ADMM iteration (results are then wrong); the change in run time at a
+// fixed iteration count is that piece's share of the critical path.  0 = product build.
+#ifndef Q5_ABL
+#define Q5_ABL 0
+#endif
+#define Q5_ON(n) (Q5_ABL != (n) && Q5_ABL != 10)      /* 10: every piece off (the bare loop: barriers and lane-constant fetches) */
 template <int NSEG>
 struct Qp5Ctx {
     const mpcmp_config *cfg;
@@ -158,19 +193,35 @@ struct Qp5Ctx {
     double *lds;
     const double *fa;
     int tid, b;
-    double tsT, rho_in, rho_eq, sigma, alpha;
+    double tsT, rho_in, rho_eq, sigma, alpha, oma;     // (oma = 1 - alpha)
 };
+// a workgroup-uniform double that vector instructions produced, moved to scalar registers (it would otherwise occupy two vector registers of every role's loop)
+__device__ __forceinline__ double q5_uniform(double x) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 
+// diagnostic builds (-DMPCMP_STAMPS, tools/stamps5.py): cycles per phase of the ADMM loop as wave 0 sees them (Q5S: after a barrier) and the busy
+// part of each phase per wave (Q5B: in front of the barrier).  -DMPCMP_STAMPS_LIGHT: wave 0's phase stamps only (the per-wave counters cost ~ 20 %).
 #ifdef MPCMP_STAMPS
-#define Q5_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_busy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64(), st_m = 0; (void)st_m
+#define Q5_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_busy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64(); const bool st_on = c.tid < 64; (void)st_on; (void)st_busy
 #define Q5_STAMP_RESET do { for (int k_ = 0; k_ < 8; k_++) st_acc[k_] = st_busy[k_] = 0; st_t = clock64(); } while (0)
 #define Q5_STAMP_DUMP(it_) do { if ((c.tid & 63) == 0) { unsigned long long *o_ = c.ws.dbg + (size_t)c.b * MPCMP_DBG_WORDS; \
         for (int k_ = 0; k_ < 8; k_++) o_[16 + (c.tid >> 6) * 8 + k_] = st_busy[k_]; \
         if (c.tid == 0) { for (int k_ = 0; k_ < 7; k_++) o_[k_] = st_acc[k_]; o_[15] = (it_); } } } while (0)
+#ifdef MPCMP_STAMPS_LIGHT
+#define Q5S(k) do { if (st_on) { const unsigned long long n_ = clock64(); st_acc[k] += n_ - st_t; st_t = n_; } } while (0)
+#define Q5B(k) do { } while (0)
+#else
+#define Q5S(k) do { const unsigned long long n_ = clock64(); st_acc[k] += n_ - st_t; st_t = n_; } while (0)
+#define Q5B(k) do { st_busy[k] += clock64() - st_t; } while (0)
+#endif
 #else
 #define Q5_STAMP_DECL do { } while (0)
 #define Q5_STAMP_RESET do { } while (0)
 #define Q5_STAMP_DUMP(it_) do { } while (0)
+#define Q5S(k) do { } while (0)
+#define Q5B(k) do { } while (0)
 #endif
 
 // Lane-constant table [NF][NT] of 32-bit words in LDS: every per-lane loop-invariant integer of the ADMM loop (LDS addresses in doubles,
@@ -188,15 +239,22 @@ __device__ __forceinline__ int q5_lc(const Qp5Ctx<NSEG> &c, int t, int f) {
     const int *lct = reinterpret_cast<const int *>(c.lds + L::vLCT);
     return *(const volatile __attribute__((address_space(3))) int *)(lct + f * L::NT + t);
 }
+template <int NSEG>
+__device__ __forceinline__ int q5_l5(const Qp5Ctx<NSEG> &c, int lane, int f) {       // last G wave: 0 pxr, 1 prf, 2 prb, 3 ixr of the lane's variable / dynamics row
+    using L = Qp5<NSEG>;
+    const int *t5 = reinterpret_cast<const int *>(c.lds + L::vL5);
+    return *(const volatile __attribute__((address_space(3))) int *)(t5 + f * 64 + lane);
+}
 __device__ __forceinline__ int lo16(int w) { return w & 0xFFFF; }
 __device__ __forceinline__ int hi16(int w) { return (int)((unsigned)w >> 16); }
 
 // ---- the three products of one solve with K_0 ----
 // P1 (role G): t = G b_J (k_qp3's block product), then inside the wave part = K_CJ t
 template <int NSEG>
-__device__ __forceinline__ void q5_p1(const Qp5Ctx<NSEG> &c, const double (&fm)[52], int k0, int k1, int k2, int k3) {
+__device__ __forceinline__ void q5_p1(const Qp5Ctx<NSEG> &c, const double (&fm)[50], int t, int k0, int k1, int k2, int k3) {
+    using L = Qp5<NSEG>;
     double *lds = c.lds;
-    lds[lo16(k0)] = g_blk<false>(fm, lds + hi16(k0));
+    lds[lo16(k0)] = q5_gprod(fm, lds + L::vTG + t, L::NG, lds + hi16(k0));
     wave_sync();
     const double *kc = lds + lo16(k1), *tc = lds + hi16(k1);
     double kq[7], tv[7];
@@ -223,7 +281,7 @@ __device__ __forceinline__ void q5_p1_xT(const Qp5Ctx<NSEG> &c, int t) {
 }
 // P2 (waves with S lanes): r_I = b_I - part (every wave its own, identical copy), y_I = S^-1 r_I, interface rows of x~
 template <int NSEG>
-__device__ __forceinline__ void q5_p2(const Qp5Ctx<NSEG> &c, const double (&fm)[52], int t, int k0, int k1, const bool laneS, const bool use_xT) {
+__device__ __forceinline__ void q5_p2(const Qp5Ctx<NSEG> &c, const double (&fm)[48], int t, int k0, int k1, const bool laneS, const bool use_xT) {
     using L = Qp5<NSEG>;
     double *lds = c.lds;
     double *rIw = lds + L::vRIw;
@@ -243,30 +301,40 @@ __device__ __forceinline__ void q5_p2(const Qp5Ctx<NSEG> &c, const double (&fm)[
     const double wds = ldv(lds + xds + (L::vWv - L::vXn));
     const double xT = use_xT ? ldv(lds + L::oMisc + L::M_xtT) : 0.0;
     wave_sync();
-    const double yi = s_blk8(fm, lds + (laneS ? lo16(k0) : L::vRIw));
+    const double yi = q5_sprod(fm, lds + L::vTS + (laneS ? t - L::tS0 : 0), L::NSL, lds + (laneS ? lo16(k0) : L::vRIw));
     lds[ysl] = yi;                                                            // (lanes without an output row: pad slots)
     lds[xds] = yi - wds * xT;
 }
-// P3 (waves with E lanes): x_J = t - E y_C - w x~_T
+// P3 (waves with E lanes): x_J = t - E y_C - w x~_T.  4 x 14 block, two lanes per group of four rows (lane h of a pair: rows 4 g + (a ^ 2 h),
+// columns 14 h .. + 13); column 13 of every row comes from LDS.  Operand reads in two batches.
 template <int NSEG>
-__device__ __forceinline__ void q5_p3(const Qp5Ctx<NSEG> &c, const double (&fm)[56], int k0, int k1, const bool laneE, const bool use_xT) {
+__device__ __forceinline__ void q5_p3(const Qp5Ctx<NSEG> &c, const double (&fm)[52], int t, int k0, int k1, const bool laneE, const bool use_xT) {
     using L = Qp5<NSEG>;
     double *lds = c.lds;
     constexpr int dW = L::vWv - L::vXn;
     const int xd0 = laneE ? lo16(k1) : L::vXn + L::NX, xd1 = laneE ? hi16(k1) : L::vXn + L::NX + 1;      // (the S lanes of the mixed wave: pad slots)
-    const double *yc = lds + (laneE ? lo16(k0) : L::vYI), *ts = lds + (laneE ? hi16(k0) : L::vTU + 8);
+    const double *yc = lds + (laneE ? lo16(k0) : L::vYI), *ts = lds + (laneE ? hi16(k0) : L::vTU + 8), *tl = lds + L::vTE + (laneE ? t - L::NG : 0);
     const double t0 = ldv(ts), t1 = ldv(ts + 1);
     const double w0 = ldv(lds + xd0 + dW), w1 = ldv(lds + xd1 + dW);
     const double xT = use_xT ? ldv(lds + L::oMisc + L::M_xtT) : 0.0;
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-    for (int j0 = 0; j0 < 14; j0 += 7) {            // (two batches of operand reads: register budget)
+    {
         double o[7];
 #pragma unroll
-        for (int j = 0; j < 7; j++) o[j] = ldv(yc + j0 + j);
+        for (int j = 0; j < 7; j++) o[j] = ldv(yc + j);
 #pragma unroll
-        for (int j = 0; j < 7; j++) { p0 += fm[j0 + j] * o[j]; p1 += fm[14 + j0 + j] * o[j]; p2 += fm[28 + j0 + j] * o[j]; p3 += fm[42 + j0 + j] * o[j]; }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 7; j++) { p0 += fm[j] * o[j]; p1 += fm[13 + j] * o[j]; p2 += fm[26 + j] * o[j]; p3 += fm[39 + j] * o[j]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        double o[7], tq[4];
+#pragma unroll
+        for (int j = 0; j < 7; j++) o[j] = ldv(yc + 7 + j);
+#pragma unroll
+        for (int q = 0; q < 4; q++) tq[q] = ldv(tl + q * L::F::ELS);
+#pragma unroll
+        for (int j = 0; j < 6; j++) { p0 += fm[7 + j] * o[j]; p1 += fm[20 + j] * o[j]; p2 += fm[33 + j] * o[j]; p3 += fm[46 + j] * o[j]; }
+        p0 += tq[0] * o[6]; p1 += tq[1] * o[6]; p2 += tq[2] * o[6]; p3 += tq[3] * o[6];
     }
     const double e0 = p0 + dpp_mov<0xB1>(p2), e1 = p1 + dpp_mov<0xB1>(p3);      // rows 4 g + 2 h, + 1: the own half + the partner's
     lds[xd0] = (t0 - e0) - w0 * xT;                                            // (rows 49..51, spare lanes: pad)
@@ -340,27 +408,286 @@ __device__ __forceinline__ double q5_col_gather(const double *lds, int pxr, int 
     return s;
 }
 
-// ---- role G: waves 0 .. NSEG - 1.  P1; a variable per lane, a dynamics row per lane of the first meq lanes ----
+// ---- the path rows (k_qp2's scheme): four lanes per pair of rows (six columns each), sixteen lanes per node; lanes 0, 1 of a quad own
+// the rows 2 prp, 2 prp + 1.  z~ of the owned row and, from the same Jacobian operands, this node's path-row part of A^T w: every lane
+// forms its six columns of g_row0 w0 + g_row1 w1, the four row pairs of the node (lane bits 2, 3 of the DPP row) are summed with two
+// row rotations, and the lanes of pair 0 publish the node's 24 padded columns.
+struct PathOp5 { v2d pa[3], pb[3]; double lgp, ugp, rr, rri; };      // Jacobian operands (the row of the lane's parity first) and constants of the owned row
+template <int NSEG>
+__device__ __forceinline__ PathOp5 q5_path_fetch(const double *lds, int gro, int t) {
+    using L = Qp5<NSEG>;
+    const int par = (gro >> 16) & 1, go = lo16(gro);
+    const double *g0 = lds + go + par * L::GS, *g1 = lds + go + (1 - par) * L::GS, *pcl = lds + L::vPc + t;
+    PathOp5 o;
+#pragma unroll
+    for (int j = 0; j < 3; j++) o.pa[j] = ldv2(g0 + 2 * j);
+#pragma unroll
+    for (int j = 0; j < 3; j++) o.pb[j] = ldv2(g1 + 2 * j);
+    o.lgp = ldv(pcl); o.ugp = ldv(pcl + L::NPL); o.rr = ldv(pcl + 2 * L::NPL); o.rri = ldv(pcl + 3 * L::NPL);
+    return o;
+}
+template <int NSEG, class F>
+__device__ __forceinline__ double q5_path_rows(double *lds, int gro, int xno, int t, const double *xe, double *gdst, F &&row_update) {
+    using L = Qp5<NSEG>;
+    const int first = (gro >> 17) & 1;
+    const double *xv = xe + xno;
+    v2d x2[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) x2[j] = ldv2(xv + 2 * j);
+    const PathOp5 o = q5_path_fetch<NSEG>(lds, gro, t);                  // (all operand reads of the phase in flight at once: one LDS round trip)
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        a0 += o.pa[j].x * x2[j].x; a1 += o.pb[j].x * x2[j].x;
+        a0 += o.pa[j].y * x2[j].y; a1 += o.pb[j].y * x2[j].y;
+    }
+    const double ax = quad_sum2(a0, a1);
+    const double wq = row_update(ax, o);                                // owners: the row's multiplier-like value
+    const double w0 = dpp_mov<0x44>(wq), w1 = dpp_mov<0x11>(wq);        // quad broadcasts: owner of the own row, of the other row
+    double *dst = first ? gdst + xno : lds + L::vPadW;                  // (pairs 1..3 of a node: pad)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double cx = o.pa[j].x * w0 + o.pb[j].x * w1, cy = o.pa[j].y * w0 + o.pb[j].y * w1;
+        cx += dpp_mov<0x128>(cx); cy += dpp_mov<0x128>(cy);             // row_ror:8
+        cx += dpp_mov<0x124>(cx); cy += dpp_mov<0x124>(cy);             // row_ror:4
+        D2 q; q.x = cx; q.y = cy;
+        *reinterpret_cast<D2 *>(dst + 2 * j) = q;
+    }
+    return ax;
+}
+
+// ---- role G: waves 0 .. NSEG - 1.  P1 (wave = segment).  The path rows live here, sixteen lanes per node on the lanes below NPN: these
+// waves are idle in P2 and P3 (their Jacobian operands and row constants are fetched then) and their factor block leaves the most
+// registers.  The first sixteen lanes of the last G wave carry the variables that have no lane on the E / S waves, and T (state in LDS). ----
 template <int NSEG>
 __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
     using L = Qp5<NSEG>;
     using D = Dim3<NSEG>;
-    constexpr int meq = D::meq, XS = L::XS;
+    constexpr int N = D::N, na = D::na, XS = L::XS;
     double *lds = c.lds;
     const mpcmp_config &cfg = *c.cfg;
     const int tid = c.tid, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    double *misc = lds + L::oMisc;
     Q5_STAMP_DECL;
-    double fm[52];
+    double fm[50];              // the lane's 4 x 13 block of G_s without the entries 12, 25 (LDS: vTG)
     {
         typedef const __attribute__((address_space(1))) double *gptr_t;
         gptr_t p = (gptr_t)(c.fa + L::oFG + (size_t)(wave * 52) * 64 + lane);
 #pragma unroll
-        for (int j = 0; j < 52; j++) fm[j] = p[j * 64];
+        for (int e = 0; e < 52; e++) {
+            const double q = p[e * 64];
+            if (e == 12) lds[L::vTG + tid] = q;
+            else if (e == 25) lds[L::vTG + L::NG + tid] = q;
+            else fm[e < 12 ? e : (e < 25 ? e - 1 : e - 2)] = q;
+        }
     }
+    const bool isPath = tid < L::NPN, ownsRow = isPath && (tid & 3) < 2;
+    const bool wavePath = (tid & ~63) < L::NPN;
+    const bool laneV = tid >= L::tV5 && tid < L::tV5 + 16, laneD = tid >= L::tV5 && tid < L::tV5 + L::ND5;
+    double zg = 0.0, yg = 0.0;          // ADMM state of the owned path row (last G wave: yg = the dual of the lane's dynamics row)
+    const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq, mtsT = -c.tsT;
+    auto row_dot_dyn = [&](const double *xe, int ixo, int cro, double rcT) -> double {
+        const int ix0 = lo16(ixo), ixf = hi16(ixo);
+        const double c0 = ldv(lds + cro), c1 = ldv(lds + cro + 1), c2 = ldv(lds + cro + 2), c3 = ldv(lds + cro + 3);
+        const double x0 = ldv(xe + ix0), x1 = ldv(xe + ix0 + XS), x2 = ldv(xe + ix0 + 2 * XS), x3 = ldv(xe + ix0 + 3 * XS), xf = ldv(xe + ixf), xT = ldv(xe + 21);
+        return ((c0 * x0 + c1 * x1) + (c2 * x2 + c3 * x3)) + (mtsT * xf + rcT * xT);
+    };
+    // ---- K_0 w = k (the T border) ----
+    {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        q5_p1<NSEG>(c, fm, t, q5_lc<NSEG>(c, t, 0), q5_lc<NSEG>(c, t, 1), q5_lc<NSEG>(c, t, 2), q5_lc<NSEG>(c, t, 3));
+    }
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    q5_finish_border<NSEG>(c);
+    Q5_STAMP_RESET;
+    int it = 0, done = 0, until_check = cfg.check_every;
+    int pxr, prf, prb;          // last G wave: constants of phase A, fetched ahead of the barrier that ends the previous iteration
+    {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        pxr = q5_l5<NSEG>(c, t & 63, 0); prf = q5_l5<NSEG>(c, t & 63, 1); prb = q5_l5<NSEG>(c, t & 63, 2);
+    }
+    for (it = 1; it <= cfg.qp_iters; it++) {
+        int sio = tid;
+        asm volatile("" : "+v"(sio));
+        const int k0 = q5_lc<NSEG>(c, sio, 0), k1 = q5_lc<NSEG>(c, sio, 1), k2 = q5_lc<NSEG>(c, sio, 2), k3 = q5_lc<NSEG>(c, sio, 3);
+        // ---- A: the variables of the last G wave ----
+        if (laneV && Q5_ON(1)) {
+            const int vi = L::NG + (sio - L::tV5);
+            const double *vst = lds + L::vVst + (sio - L::tV5), *vcl = lds + L::vVc + vi;
+            const double vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32), rb = ldv(vcl + 4 * L::NVL);
+            const double wb = ldv(lds + L::vWv + lo16(pxr));
+            const double r = (sigma * vx + (rb * vzb - vyb)) + q5_col_gather<NSEG>(lds, pxr, prf, prb, vcl, lds + L::vWg, lds + L::vGp);
+            lds[hi16(pxr)] = r;                             // (T: the pad slot; its w of the border is zero)
+            const double bp = sum8(wb * r);
+            lds[L::vRedB + (vi >> 3)] = bp;
+        }
+        Q5B(0); __syncthreads(); Q5S(0);
+        if (Q5_ON(2)) q5_p1<NSEG>(c, fm, sio, k0, k1, k2, k3);
+        Q5B(1); __syncthreads(); Q5S(1);
+        // ---- P2 (role S); this role is idle: the lane constants of phase E ----
+        const int gro = q5_lc<NSEG>(c, sio, 4), xno = q5_lc<NSEG>(c, sio, 5);
+        Q5B(2); __syncthreads(); Q5S(2);
+        // ---- P3 (role E) ----
+        Q5B(3); __syncthreads(); Q5S(3);
+        // ---- E: the path rows; the last G wave's variables ----
+        const bool check = (--until_check == 0);
+        if (check) until_check = cfg.check_every;
+        if (wavePath) {
+            if (isPath && Q5_ON(5)) {
+                q5_path_rows<NSEG>(lds, gro, xno, sio, lds + L::vXn, lds + L::vGp, [&](double zt, const PathOp5 &po) -> double {
+                    double w = 0.0;
+                    if (ownsRow) {
+                        const double zr = alpha * zt + c.oma * zg;
+                        const double zn = clip(zr + yg * po.rri, po.lgp, po.ugp);
+                        yg += po.rr * (zr - zn);
+                        zg = zn;
+                        w = po.rr * zg - yg;
+                    }
+                    return w;
+                });
+            }
+        } else if (Q5_ON(6)) {
+            if (laneD) {        // dynamics rows DR0 .. meq - 1
+                const int r = L::DR0 + (sio - L::tV5);
+                const double *rcl = lds + L::vRc + r;
+                const double lgd = ldv(rcl), rcT = ldv(rcl + L::NRC);
+                const double zt = row_dot_dyn(lds + L::vXn, q5_l5<NSEG>(c, sio & 63, 3), L::oCD + 4 * ((prb >> 17) & 3), rcT);
+                const double zr = alpha * zt + c.oma * (it > 1 ? lgd : 0.0);
+                yg += rho_eq * (zr - lgd);                  // the row is an equality: the projection of anything onto [l, l] is l
+                const double w = rho_eq * lgd - yg;
+                lds[L::vWg + r] = w;
+                const double tp = sum8(rcT * w);            // (ND5 is not a multiple of 8: the lanes behind the last row are masked off, their partial sum slot gets the sum of the group's rows from a lane that is not)
+                lds[L::vRedT + (r >> 3)] = tp;
+                if (check) lds[L::vYs + r] = yg;
+            }
+            if (laneV) {
+                const int vi = L::NG + (sio - L::tV5);
+                double *vst = lds + L::vVst + (sio - L::tV5);
+                const double *vcl = lds + L::vVc + vi;
+                double vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32);
+                const int xpos = lo16(pxr);
+                const double xtv = ldv(lds + L::vXn + xpos), vlb = ldv(vcl + 1 * L::NVL), vub = ldv(vcl + 2 * L::NVL);
+                const double rb = ldv(vcl + 4 * L::NVL), rbi = ldv(vcl + 5 * L::NVL);
+                vx = alpha * xtv + c.oma * vx;
+                const double zrv = alpha * xtv + c.oma * vzb;
+                const double znv = clip(zrv + vyb * rbi, vlb, vub);
+                vyb += rb * (zrv - znv);
+                vzb = znv;
+                vst[0] = vx; vst[16] = vzb; vst[32] = vyb;
+                if (vi == na) {     // the shared variable T: its state is published for the border solve and the tests
+                    misc[L::M_xT] = vx; misc[L::M_zbT] = vzb; misc[L::M_ybT] = vyb;
+                    misc[L::M_baseT] = (sigma * vx - 1.0) + (rb * vzb - vyb);
+                    if (check) { for (int k = 0; k < N; k++) lds[L::vXx + k * XS + 21] = vx; }
+                } else if (check) lds[L::vXx + xpos] = vx;
+            }
+        }
+        pxr = q5_l5<NSEG>(c, sio & 63, 0); prf = q5_l5<NSEG>(c, sio & 63, 1); prb = q5_l5<NSEG>(c, sio & 63, 2);
+        Q5B(4); __syncthreads(); Q5S(4);
+#ifndef Q5_NOTEST
+        if (__builtin_expect(check, 0)) {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            double sums[2] = {0.0, 0.0};
+            double mx[6] = {0, 0, 0, 0, 0, 0};
+            if (isPath) {       // A x of the owned row and the path-row part of A^T y (read by the variable lanes after the reduction's barriers)
+                const int gro2 = q5_lc<NSEG>(c, t, 4), xno2 = q5_lc<NSEG>(c, t, 5);
+                const double ygc = yg;
+                const double ax = q5_path_rows<NSEG>(lds, gro2, xno2, t, lds + L::vXx, lds + L::vGpy, [&](double, const PathOp5 &) -> double { return ownsRow ? ygc : 0.0; });
+                if (ownsRow) {
+                    sums[0] = lds[lo16(gro2) - (xno2 % XS) + ((gro2 >> 16) & 1) * L::GS + 21] * yg;      // T coefficient of the owned row (column 21)
+                    mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg);
+                }
+            }
+            double rcT5 = 0.0;
+            if (laneD) { rcT5 = ldv(lds + L::vRc + L::NRC + L::DR0 + (t - L::tV5)); sums[0] = rcT5 * yg; }
+            const int vi = laneV ? L::NG + (t - L::tV5) : 0;
+            const bool isVar = laneV && vi < na;
+            const double *vcl = lds + L::vVc + vi, *vst = lds + L::vVst + (laneV ? t - L::tV5 : 0);
+            const double ha = isVar ? ldv(vcl + 3 * L::NVL) : 0.0, vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32);
+            if (isVar) sums[1] = ha * vx;
+            q5_reduce<L::NWV, 2, false>(sums, lds + L::oRedP, tid);
+            if (laneD) {
+                const double zgd = ldv(lds + L::vRc + L::DR0 + (t - L::tV5));
+                const double ax = row_dot_dyn(lds + L::vXx, q5_l5<NSEG>(c, t & 63, 3), L::oCD + 4 * ((q5_l5<NSEG>(c, t & 63, 2) >> 17) & 3), rcT5);
+                mx[0] = fabs(ax - zgd); mx[1] = fabs(ax); mx[2] = fabs(zgd);
+            }
+            if (isVar) {
+                const double hx = (fabs(ha) + cfg.hess_reg) * vx + ha * lds[L::vXx + 21];
+                const double aty = q5_col_gather<NSEG>(lds, q5_l5<NSEG>(c, t & 63, 0), q5_l5<NSEG>(c, t & 63, 1), q5_l5<NSEG>(c, t & 63, 2), vcl, lds + L::vYs, lds + L::vGpy) + vyb;
+                mx[0] = fmax(mx[0], fabs(vx - vzb)); mx[1] = fmax(mx[1], fabs(vx)); mx[2] = fmax(mx[2], fabs(vzb));
+                mx[3] = fabs(hx + aty); mx[4] = fabs(hx); mx[5] = fabs(aty);
+            }
+            done = q5_check_tail<NSEG>(c, sums, mx);
+            Q5S(5);
+        }
+#endif
+        if (done) break;
+    }
+    const bool capped = it > cfg.qp_iters;
+    if (capped) it = cfg.qp_iters;
+    Q5_STAMP_DUMP(it);
+    if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; if (capped) atomicAdd(&c.ws.status[c.b], MPCMP_ST_CAP_ONE); }
+    if (laneV) {
+        const int vi = L::NG + (tid - L::tV5);
+        const double *vst = lds + L::vVst + (tid - L::tV5);
+        c.ws.p[(size_t)c.b * (na + 1) + vi] = vst[0];
+        c.ws.y[(size_t)c.b * (D::ma + na + 1) + D::ma + vi] = vst[32];
+    }
+    if (ownsRow) c.ws.y[(size_t)c.b * (D::ma + na + 1) + D::meq + 8 * (tid >> 4) + 2 * ((tid & 15) >> 2) + (tid & 3)] = yg;
+    if (laneD) c.ws.y[(size_t)c.b * (D::ma + na + 1) + L::DR0 + (tid - L::tV5)] = yg;
+}
+
+// ---- roles E and S: waves NSEG .. 11.  EP = waves NSEG .. wS0: P3 on the E lanes (the S lanes of the mixed wave wS0 take part in P2);
+// !EP = the pure S waves: P2, and the last wave sums the T border's partial sums and replicates x~_T.  Every lane carries the variable
+// vi = tid - NG, the lanes vi < meq also the dynamics row vi (k_qp2's role B). ----
+template <int NSEG, bool EP>
+__device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
+    using L = Qp5<NSEG>;
+    using D = Dim3<NSEG>;
+    constexpr int meq = D::meq, XS = L::XS, NFM = EP ? 52 : 48;
+    double *lds = c.lds;
+    const mpcmp_config &cfg = *c.cfg;
+    const int tid = c.tid, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Q5_STAMP_DECL;
+    const bool laneS = !EP || tid >= L::tS0, laneE = !laneS;
+    const bool waveS = !EP || wave >= L::wS0, waveX = !EP && wave == L::NWV - 1;
+    // the lane's block without its tail column (LDS: vTS / vTE): S lanes 4 x 12 of the 4 x 13 block of S^-1, E lanes 4 x 13 of the 4 x 14 block of E_s
+    double fm[NFM];
+    {
+        typedef const __attribute__((address_space(1))) double *gptr_t;
+        if (laneS) {
+            gptr_t p = (gptr_t)(c.fa + L::F::oFS + (tid - L::tS0));
+#pragma unroll
+            for (int pos = 0; pos < 4; pos++) {
+#pragma unroll
+                for (int j = 0; j < 13; j++) {
+                    const double q = p[(13 * pos + j) * L::F::NSL];
+                    if (j < 12) fm[12 * pos + j] = q; else lds[L::vTS + pos * L::NSL + (tid - L::tS0)] = q;
+                }
+            }
+#pragma unroll
+            for (int j = 48; j < NFM; j++) fm[j] = 0.0;
+        } else {
+            gptr_t p = (gptr_t)(c.fa + L::F::oFE + (tid - L::NG));
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int j = 0; j < 14; j++) {
+                    const double q = p[(14 * a + j) * L::F::ELS];
+                    if (j < 13) fm[(13 * a + j) < NFM ? 13 * a + j : 0] = q; else lds[L::vTE + a * L::F::ELS + (tid - L::NG)] = q;
+                }
+            }
+        }
+    }
+    const double (&fs)[48] = reinterpret_cast<const double (&)[48]>(fm);
     // ADMM state of the lane's variable and of its dynamics row (z of an equality row is its bound l from the first update on)
     double vx = 0.0, vzb = 0.0, vyb = 0.0, ygd = 0.0;
-    const bool isDyn = tid < meq;
-    const bool waveDyn = (tid & ~63) < meq;
+    const int vi0 = L::vi_of(tid);
+    constexpr bool isDyn = !EP;         // (every lane of the pure S waves carries the dynamics row vi; the E waves carry none)
     const double mtsT = -c.tsT, alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq;
     auto row_dot_dyn = [&](const double *xe, int ixo, int cro, double rcT) -> double {
         const int ix0 = lo16(ixo), ixf = hi16(ixo);
@@ -372,11 +699,14 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
     {
         int t = tid;
         asm volatile("" : "+v"(t));
-        q5_p1<NSEG>(c, fm, q5_lc<NSEG>(c, t, 0), q5_lc<NSEG>(c, t, 1), q5_lc<NSEG>(c, t, 2), q5_lc<NSEG>(c, t, 3));
+        const int k0 = q5_lc<NSEG>(c, t, 0), k1 = q5_lc<NSEG>(c, t, 1);
+        __syncthreads();
+        if (waveS) q5_p2<NSEG>(c, fs, t, k0, k1, laneS, false);
+        __syncthreads();
+        if (EP) q5_p3<NSEG>(c, reinterpret_cast<const double (&)[52]>(fm), t, k0, k1, laneE, false);
+        else if (waveX) q5_p3_xT<NSEG>(c, t, false);
+        __syncthreads();
     }
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
     q5_finish_border<NSEG>(c);
     Q5_STAMP_RESET;
     int it = 0, done = 0, until_check = cfg.check_every;
@@ -384,66 +714,70 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
     {
         int t = tid;
         asm volatile("" : "+v"(t));
-        apx = q5_lc<NSEG>(c, t, 4); apf = q5_lc<NSEG>(c, t, 5); apb = q5_lc<NSEG>(c, t, 6);
+        apx = q5_lc<NSEG>(c, t, 2); apf = q5_lc<NSEG>(c, t, 3); apb = q5_lc<NSEG>(c, t, 4);
     }
     for (it = 1; it <= cfg.qp_iters; it++) {
         int sio = tid;
         asm volatile("" : "+v"(sio));
+        const int vi = L::vi_of(sio);
         // ---- A: rhs = sigma x - q + rho_b z_b - y_b + A^T w; partial sums of w^T rhs ----
-        {
-            const double rb = ldv(lds + L::vVc + sio + 4 * L::NVL);
+        if (Q5_ON(1)) {
+            const double *vcl = lds + L::vVc + vi;
+            const double rb = ldv(vcl + 4 * L::NVL);
             const double wb = ldv(lds + L::vWv + lo16(apx));
-            const double r = (sigma * vx + (rb * vzb - vyb)) + q5_col_gather<NSEG>(lds, apx, apf, apb, lds + L::vVc + sio, lds + L::vWg, lds + L::vGp);
+            const double r = (sigma * vx + (rb * vzb - vyb)) + q5_col_gather<NSEG>(lds, apx, apf, apb, vcl, lds + L::vWg, lds + L::vGp);
             lds[hi16(apx)] = r;
             const double bp = sum8(wb * r);
-            lds[L::vRedB + (sio >> 3)] = bp;              // (all eight lanes of a group hold the sum and store it)
+            lds[L::vRedB + (vi >> 3)] = bp;               // (all eight lanes of a group hold the sum and store it)
         }
-        const int k0 = q5_lc<NSEG>(c, sio, 0), k1 = q5_lc<NSEG>(c, sio, 1), k2 = q5_lc<NSEG>(c, sio, 2), k3 = q5_lc<NSEG>(c, sio, 3);
-        QB(0); __syncthreads(); QS(0);
-        q5_p1<NSEG>(c, fm, k0, k1, k2, k3);
-        QB(1); __syncthreads(); QS(1);
-        // ---- P2 (role S) ----
-        QB(2); __syncthreads(); QS(2);
-        // ---- P3 (role E); this role is idle: the constants of phase E ----
-        const int epx = q5_lc<NSEG>(c, sio, 4), epb = q5_lc<NSEG>(c, sio, 6), eix = q5_lc<NSEG>(c, sio, 7);
-        QB(3); __syncthreads(); QS(3);
+        Q5B(0); __syncthreads(); Q5S(0);
+        // ---- P1 (role G); the last wave sums the border's partial sums ----
+        if (waveX) q5_p1_xT<NSEG>(c, sio);
+        const int k0 = q5_lc<NSEG>(c, sio, 0), k1 = q5_lc<NSEG>(c, sio, 1);
+        Q5B(1); __syncthreads(); Q5S(1);
+        if (waveS && Q5_ON(3)) q5_p2<NSEG>(c, fs, sio, k0, k1, laneS, true);
+        Q5B(2); __syncthreads(); Q5S(2);
+        const int epx = q5_lc<NSEG>(c, sio, 2), epb = isDyn ? q5_lc<NSEG>(c, sio, 4) : 0, eix = isDyn ? q5_lc<NSEG>(c, sio, 5) : 0;      // (constants of phase E: in flight during the product)
+        if (EP && Q5_ON(4)) q5_p3<NSEG>(c, reinterpret_cast<const double (&)[52]>(fm), sio, k0, k1, laneE, true);
+        else if (waveX) q5_p3_xT<NSEG>(c, sio, true);
+        Q5B(3); __syncthreads(); Q5S(3);
         // ---- E: the variable and the dynamics row of the lane ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
-        {
-            const double *vcl = lds + L::vVc + sio, *rcl = lds + L::vRc + sio;
+        apx = q5_lc<NSEG>(c, sio, 2); apf = q5_lc<NSEG>(c, sio, 3); apb = q5_lc<NSEG>(c, sio, 4);      // (constants of the next phase A: not behind this phase's work)
+        if (Q5_ON(6)) {
+            const double *vcl = lds + L::vVc + vi, *rcl = lds + L::vRc + (isDyn ? vi : 0);
             const int xpos = lo16(epx);
             const double xtv = ldv(lds + L::vXn + xpos), vlb = ldv(vcl + 1 * L::NVL), vub = ldv(vcl + 2 * L::NVL);
             const double rb = ldv(vcl + 4 * L::NVL), rbi = ldv(vcl + 5 * L::NVL);
-            if (waveDyn) {
-                // (lanes past the last row compute on row 0's operands and store into the pad)
-                const double lgd = ldv(rcl), rcT = ldv(rcl + L::NG);
+            if (isDyn) {
+                const double lgd = ldv(rcl), rcT = ldv(rcl + L::NRC);
                 const double zt = row_dot_dyn(lds + L::vXn, eix, L::oCD + 4 * ((epb >> 17) & 3), rcT);
-                const double zr = alpha * zt + (1.0 - alpha) * (it > 1 ? lgd : 0.0);
+                const double zr = alpha * zt + c.oma * (it > 1 ? lgd : 0.0);
                 ygd += rho_eq * (zr - lgd);                 // the row is an equality: the projection of anything onto [l, l] is l
                 const double w = rho_eq * lgd - ygd;
-                lds[L::vWg + (isDyn ? sio : meq + 1)] = w;
-                const double tp = sum8(isDyn ? rcT * w : 0.0);
-                lds[L::vRedT + (sio >> 3)] = tp;
-                if (check) lds[L::vYs + (isDyn ? sio : meq + 1)] = ygd;
+                lds[L::vWg + vi] = w;
+                const double tp = sum8(rcT * w);
+                lds[L::vRedT + (vi >> 3)] = tp;
+                if (check) lds[L::vYs + vi] = ygd;
             }
-            vx = alpha * xtv + (1.0 - alpha) * vx;
-            const double zrv = alpha * xtv + (1.0 - alpha) * vzb;
+            vx = alpha * xtv + c.oma * vx;
+            const double zrv = alpha * xtv + c.oma * vzb;
             const double znv = clip(zrv + vyb * rbi, vlb, vub);
             vyb += rb * (zrv - znv);
             vzb = znv;
             if (check) lds[L::vXx + xpos] = vx;
         }
-        apx = q5_lc<NSEG>(c, sio, 4); apf = q5_lc<NSEG>(c, sio, 5); apb = q5_lc<NSEG>(c, sio, 6);
-        QB(4); __syncthreads(); QS(4);
+        Q5B(4); __syncthreads(); Q5S(4);
 #ifndef Q5_NOTEST
         if (__builtin_expect(check, 0)) {
             int t = tid;
             asm volatile("" : "+v"(t));
-            const double *vcl = lds + L::vVc + t, *rcl = lds + L::vRc + t, *xx = lds + L::vXx;
-            const int pxc = q5_lc<NSEG>(c, t, 4), prfc = q5_lc<NSEG>(c, t, 5), prbc = q5_lc<NSEG>(c, t, 6), ixc = q5_lc<NSEG>(c, t, 7);
+            const int vc_ = L::vi_of(t);
+            const double *vcl = lds + L::vVc + vc_, *rcl = lds + L::vRc + (isDyn ? vc_ : 0), *xx = lds + L::vXx;
+            const int pxc = q5_lc<NSEG>(c, t, 2), prfc = q5_lc<NSEG>(c, t, 3), prbc = q5_lc<NSEG>(c, t, 4), ixc = q5_lc<NSEG>(c, t, 5);
             const double ha = ldv(vcl + 3 * L::NVL);
-            const double rcT = ldv(rcl + L::NG), zgd = ldv(rcl);
+            const double rcT = isDyn ? ldv(rcl + L::NRC) : 0.0, zgd = isDyn ? ldv(rcl) : 0.0;
             double sums[2] = {isDyn ? rcT * ygd : 0.0, ha * vx};
             q5_reduce<L::NWV, 2, false>(sums, lds + L::oRedP, tid);      // (its barriers publish gpy)
             double mx[6] = {0, 0, 0, 0, 0, 0};
@@ -457,293 +791,15 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
                 mx[3] = fabs(hx + aty); mx[4] = fabs(hx); mx[5] = fabs(aty);
             }
             done = q5_check_tail<NSEG>(c, sums, mx);
-            QS(5);
-        }
-#endif
-        if (done) break;
-    }
-    const bool capped = it > cfg.qp_iters;
-    if (capped) it = cfg.qp_iters;
-    Q5_STAMP_DUMP(it);
-    if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; if (capped) atomicAdd(&c.ws.status[c.b], MPCMP_ST_CAP_ONE); }
-    c.ws.p[(size_t)c.b * (D::na + 1) + tid] = vx;
-    c.ws.y[(size_t)c.b * (D::ma + D::na + 1) + D::ma + tid] = vyb;
-    if (isDyn) c.ws.y[(size_t)c.b * (D::ma + D::na + 1) + tid] = ygd;
-}
-
-// ---- the path rows (k_qp2's scheme): four lanes per pair of rows (six columns each), sixteen lanes per node; lanes 0, 1 of a quad own
-// the rows 2 prp, 2 prp + 1.  z~ of the owned row and, from the same Jacobian operands, this node's path-row part of A^T w: every lane
-// forms its six columns of g_row0 w0 + g_row1 w1, the four row pairs of the node (lane bits 2, 3 of the DPP row) are summed with two
-// row rotations, and the lanes of pair 0 publish the node's 24 padded columns.  The Jacobian rows are read twice (volatile reads in
-// program order: x~, the own row, the other row; after the row update both rows again): the lane's factor block leaves ~ 50 registers.
-template <int NSEG, class F>
-__device__ __forceinline__ double q5_path_rows(double *lds, int gro, int xno, const double *xe, double *gdst, F &&row_update) {
-    using L = Qp5<NSEG>;
-    const int par = (gro >> 16) & 1, first = (gro >> 17) & 1, go = lo16(gro);
-    const double *g0 = lds + go + par * L::GS, *g1 = lds + go + (1 - par) * L::GS;     // the row of the lane's parity first (quad_sum2)
-    const double *xv = xe + xno;
-    v2d x2[3], pa[3], pb[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) x2[j] = ldv2(xv + 2 * j);
-#pragma unroll
-    for (int j = 0; j < 3; j++) pa[j] = ldv2(g0 + 2 * j);
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 3; j++) { a0 += pa[j].x * x2[j].x; a0 += pa[j].y * x2[j].y; }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 3; j++) pb[j] = ldv2(g1 + 2 * j);
-#pragma unroll
-    for (int j = 0; j < 3; j++) { a1 += pb[j].x * x2[j].x; a1 += pb[j].y * x2[j].y; }
-    const double ax = quad_sum2(a0, a1);
-    const double wq = row_update(ax);                                   // owners: the row's multiplier-like value
-    const double w0 = dpp_mov<0x44>(wq), w1 = dpp_mov<0x11>(wq);        // quad broadcasts: owner of the own row, of the other row
-    double *dst = first ? gdst + xno : lds + L::vPadW;                  // (pairs 1..3 of a node: pad)
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const v2d qa = ldv2(g0 + 2 * j), qb = ldv2(g1 + 2 * j);
-        double cx = qa.x * w0 + qb.x * w1, cy = qa.y * w0 + qb.y * w1;
-        cx += dpp_mov<0x128>(cx); cy += dpp_mov<0x128>(cy);             // row_ror:8
-        cx += dpp_mov<0x124>(cx); cy += dpp_mov<0x124>(cy);             // row_ror:4
-        D2 o; o.x = cx; o.y = cy;
-        *reinterpret_cast<D2 *>(dst + 2 * j) = o;
-    }
-    return ax;
-}
-// one ADMM update of the path rows of this lane's quad (zg, yg: state of the owned row)
-template <int NSEG>
-__device__ __forceinline__ void q5_path_E(const Qp5Ctx<NSEG> &c, double &zg, double &yg, int gro, int xno, int et, bool ownsRow) {
-    using L = Qp5<NSEG>;
-    double *lds = c.lds;
-    const double *pcl = lds + L::vPc + et;
-    const double alpha = c.alpha;
-    q5_path_rows<NSEG>(lds, gro, xno, lds + L::vXn, lds + L::vGp, [&](double zt) -> double {
-        const double lgp = ldv(pcl), ugp = ldv(pcl + L::NPL), rr = ldv(pcl + 2 * L::NPL), rri = ldv(pcl + 3 * L::NPL);
-        double w = 0.0;
-        if (ownsRow) {
-            const double zr = alpha * zt + (1.0 - alpha) * zg;
-            const double zn = clip(zr + yg * rri, lgp, ugp);
-            yg += rr * (zr - zn);
-            zg = zn;
-            w = rr * zg - yg;
-        }
-        return w;
-    });
-}
-// termination test, path rows: A x of the owned row, the path-row part of A^T y (read by the variable lanes after the reduction's barriers)
-template <int NSEG>
-__device__ __forceinline__ void q5_path_check(const Qp5Ctx<NSEG> &c, double zg, double yg, int gro, int xno, bool ownsRow, double (&sums)[2], double (&mx)[6]) {
-    using L = Qp5<NSEG>;
-    double *lds = c.lds;
-    const double ax = q5_path_rows<NSEG>(lds, gro, xno, lds + L::vXx, lds + L::vGpy, [&](double) -> double { return ownsRow ? yg : 0.0; });
-    if (ownsRow) {
-        sums[0] = lds[lo16(gro) - (xno % L::XS) + ((gro >> 16) & 1) * L::GS + 21] * yg;      // T coefficient of the owned row (column 21)
-        mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg);
-    }
-}
-
-// ---- role EP: waves NSEG .. wS0.  P3 (E lanes); the S lanes of the mixed wave wS0 take part in P2; path rows from lane tP0 on ----
-template <int NSEG>
-__device__ __forceinline__ void qp5_role_ep(const Qp5Ctx<NSEG> &c) {
-    using L = Qp5<NSEG>;
-    using D = Dim3<NSEG>;
-    double *lds = c.lds;
-    const mpcmp_config &cfg = *c.cfg;
-    const int tid = c.tid, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    Q5_STAMP_DECL;
-    const bool laneS = tid >= L::tS0, laneE = !laneS;
-    const bool waveS = wave >= L::wS0, waveP = wave > NSEG;
-    double fm[56];
-    {
-        typedef const __attribute__((address_space(1))) double *gptr_t;
-        gptr_t p = (gptr_t)(laneS ? c.fa + L::F::oFS + (tid - L::tS0) : c.fa + L::F::oFE + (tid - L::NG));
-        const int sd = laneS ? L::F::NSL : L::F::ELS;
-#pragma unroll
-        for (int j = 0; j < 52; j++) fm[j] = p[j * sd];
-#pragma unroll
-        for (int j = 52; j < 56; j++) { const double q = p[laneE ? j * sd : 0]; fm[j] = laneE ? q : 0.0; }
-    }
-    const double (&fs)[52] = reinterpret_cast<const double (&)[52]>(fm);
-    double zg = 0.0, yg = 0.0;
-    const bool ownsRow = waveP && (tid & 3) < 2;
-    // ---- K_0 w = k (the T border) ----
-    {
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        const int k0 = q5_lc<NSEG>(c, t, 0), k1 = q5_lc<NSEG>(c, t, 1);
-        __syncthreads();
-        if (waveS) q5_p2<NSEG>(c, fs, t, k0, k1, laneS, false);
-        __syncthreads();
-        q5_p3<NSEG>(c, fm, k0, k1, laneE, false);
-        __syncthreads();
-    }
-    q5_finish_border<NSEG>(c);
-    Q5_STAMP_RESET;
-    int it = 0, done = 0, until_check = cfg.check_every;
-    for (it = 1; it <= cfg.qp_iters; it++) {
-        int sio = tid;
-        asm volatile("" : "+v"(sio));
-        // ---- A (variable lanes) ----
-        QB(0); __syncthreads(); QS(0);
-        // ---- P1 (role G) ----
-        const int k0 = q5_lc<NSEG>(c, sio, 0), k1 = q5_lc<NSEG>(c, sio, 1);
-        QB(1); __syncthreads(); QS(1);
-        if (waveS) q5_p2<NSEG>(c, fs, sio, k0, k1, laneS, true);
-        QB(2); __syncthreads(); QS(2);
-        q5_p3<NSEG>(c, fm, k0, k1, laneE, true);
-        const int gro = q5_lc<NSEG>(c, sio, 2), xno = q5_lc<NSEG>(c, sio, 3);
-        QB(3); __syncthreads(); QS(3);
-        // ---- E ----
-        const bool check = (--until_check == 0);
-        if (check) until_check = cfg.check_every;
-#ifndef Q5_NOPATH
-        if (waveP) q5_path_E<NSEG>(c, zg, yg, gro, xno, sio - L::tP0, ownsRow);
-#endif
-        QB(4); __syncthreads(); QS(4);
-#ifndef Q5_NOTEST
-        if (__builtin_expect(check, 0)) {
-            int t = tid;
-            asm volatile("" : "+v"(t));
-            double sums[2] = {0.0, 0.0};
-            double mx[6] = {0, 0, 0, 0, 0, 0};
-            if (waveP) q5_path_check<NSEG>(c, zg, yg, q5_lc<NSEG>(c, t, 2), q5_lc<NSEG>(c, t, 3), ownsRow, sums, mx);
-            q5_reduce<L::NWV, 2, false>(sums, lds + L::oRedP, tid);
-            done = q5_check_tail<NSEG>(c, sums, mx);
-            QS(5);
+            Q5S(5);
         }
 #endif
         if (done) break;
     }
     Q5_STAMP_DUMP(it > cfg.qp_iters ? cfg.qp_iters : it);
-    if (ownsRow) c.ws.y[(size_t)c.b * (D::ma + D::na + 1) + D::meq + 8 * ((tid - L::tP0) >> 4) + 2 * (((tid - L::tP0) & 15) >> 2) + (tid & 3)] = yg;
-}
-
-// ---- role SP: waves wS0 + 1 .. 11.  P2; path rows; the last wave also sums the T border's partial sums, replicates x~_T, and carries
-// the variables that have no lane on the G waves (and T) in its lanes tV0 .. (their ADMM state lives in LDS: sixteen lanes) ----
-template <int NSEG>
-__device__ __forceinline__ void qp5_role_sp(const Qp5Ctx<NSEG> &c) {
-    using L = Qp5<NSEG>;
-    using D = Dim3<NSEG>;
-    constexpr int N = D::N, na = D::na, XS = L::XS;
-    double *lds = c.lds;
-    const mpcmp_config &cfg = *c.cfg;
-    const int tid = c.tid, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *misc = lds + L::oMisc;
-    Q5_STAMP_DECL;
-    const bool waveX = wave == L::NWV - 1;
-    double fm[52];
-    {
-        typedef const __attribute__((address_space(1))) double *gptr_t;
-        gptr_t p = (gptr_t)(c.fa + L::F::oFS + (tid - L::tS0));
-#pragma unroll
-        for (int j = 0; j < 52; j++) fm[j] = p[j * L::F::NSL];
-    }
-    const bool isPath = tid < L::tV0, laneV = !isPath;
-    double zg = 0.0, yg = 0.0;
-    const bool ownsRow = isPath && (tid & 3) < 2;
-    const double alpha = c.alpha, sigma = c.sigma;
-    // ---- K_0 w = k (the T border) ----
-    {
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        const int k0 = q5_lc<NSEG>(c, t, 0), k1 = q5_lc<NSEG>(c, t, 1);
-        __syncthreads();
-        q5_p2<NSEG>(c, fm, t, k0, k1, true, false);
-        __syncthreads();
-        if (waveX) q5_p3_xT<NSEG>(c, t, false);
-        __syncthreads();
-    }
-    q5_finish_border<NSEG>(c);
-    Q5_STAMP_RESET;
-    int it = 0, done = 0, until_check = cfg.check_every;
-    for (it = 1; it <= cfg.qp_iters; it++) {
-        int sio = tid;
-        asm volatile("" : "+v"(sio));
-        // ---- A: the last variables ----
-        if (waveX && laneV) {
-            const int vi = L::NG + (sio - L::tV0);
-            const int pxr = q5_lc<NSEG>(c, sio, 4), prf = q5_lc<NSEG>(c, sio, 5), prb = q5_lc<NSEG>(c, sio, 6);
-            const double *vst = lds + L::vVst + (sio - L::tV0);
-            const double vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32);
-            const double rb = ldv(lds + L::vVc + vi + 4 * L::NVL);
-            const double wb = ldv(lds + L::vWv + lo16(pxr));
-            const double r = (sigma * vx + (rb * vzb - vyb)) + q5_col_gather<NSEG>(lds, pxr, prf, prb, lds + L::vVc + vi, lds + L::vWg, lds + L::vGp);
-            lds[hi16(pxr)] = r;                             // (T: the pad slot; its w of the border is zero)
-            const double bp = sum8(wb * r);
-            lds[L::vRedB + (vi >> 3)] = bp;
-        }
-        QB(0); __syncthreads(); QS(0);
-        // ---- P1 (role G); the last wave sums the border's partial sums ----
-        if (waveX) q5_p1_xT<NSEG>(c, sio);
-        const int k0 = q5_lc<NSEG>(c, sio, 0), k1 = q5_lc<NSEG>(c, sio, 1);
-        QB(1); __syncthreads(); QS(1);
-        q5_p2<NSEG>(c, fm, sio, k0, k1, true, true);
-        QB(2); __syncthreads(); QS(2);
-        if (waveX) q5_p3_xT<NSEG>(c, sio, true);
-        const int gro = q5_lc<NSEG>(c, sio, 2), xno = q5_lc<NSEG>(c, sio, 3);
-        QB(3); __syncthreads(); QS(3);
-        // ---- E ----
-        const bool check = (--until_check == 0);
-        if (check) until_check = cfg.check_every;
-#ifndef Q5_NOPATH
-        if (isPath) q5_path_E<NSEG>(c, zg, yg, gro, xno, sio - L::tP0, ownsRow);
-        else
-#endif
-        {
-            const int vi = L::NG + (sio - L::tV0);
-            const int pxr = q5_lc<NSEG>(c, sio, 4);
-            double *vst = lds + L::vVst + (sio - L::tV0);
-            const double *vcl = lds + L::vVc + vi;
-            double vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32);
-            const int xpos = lo16(pxr);
-            const double xtv = ldv(lds + L::vXn + xpos), vlb = ldv(vcl + 1 * L::NVL), vub = ldv(vcl + 2 * L::NVL);
-            const double rb = ldv(vcl + 4 * L::NVL), rbi = ldv(vcl + 5 * L::NVL);
-            vx = alpha * xtv + (1.0 - alpha) * vx;
-            const double zrv = alpha * xtv + (1.0 - alpha) * vzb;
-            const double znv = clip(zrv + vyb * rbi, vlb, vub);
-            vyb += rb * (zrv - znv);
-            vzb = znv;
-            vst[0] = vx; vst[16] = vzb; vst[32] = vyb;
-            if (vi == na) {     // the shared variable T: its state is published for the border solve and the tests
-                misc[L::M_xT] = vx; misc[L::M_zbT] = vzb; misc[L::M_ybT] = vyb;
-                misc[L::M_baseT] = (sigma * vx - 1.0) + (rb * vzb - vyb);
-                if (check) { for (int k = 0; k < N; k++) lds[L::vXx + k * XS + 21] = vx; }
-            } else if (check) lds[L::vXx + xpos] = vx;
-        }
-        QB(4); __syncthreads(); QS(4);
-#ifndef Q5_NOTEST
-        if (__builtin_expect(check, 0)) {
-            int t = tid;
-            asm volatile("" : "+v"(t));
-            double sums[2] = {0.0, 0.0};
-            double mx[6] = {0, 0, 0, 0, 0, 0};
-            if (isPath) q5_path_check<NSEG>(c, zg, yg, q5_lc<NSEG>(c, t, 2), q5_lc<NSEG>(c, t, 3), ownsRow, sums, mx);
-            const int vi = laneV ? L::NG + (t - L::tV0) : 0;
-            const bool isVar = laneV && vi < na;
-            const double *vcl = lds + L::vVc + vi, *vst = lds + L::vVst + (laneV ? t - L::tV0 : 0);
-            const double ha = isVar ? ldv(vcl + 3 * L::NVL) : 0.0, vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32);
-            if (isVar) sums[1] = ha * vx;
-            q5_reduce<L::NWV, 2, false>(sums, lds + L::oRedP, tid);
-            if (isVar) {
-                const double hx = (fabs(ha) + cfg.hess_reg) * vx + ha * lds[L::vXx + 21];
-                const double aty = q5_col_gather<NSEG>(lds, q5_lc<NSEG>(c, t, 4), q5_lc<NSEG>(c, t, 5), q5_lc<NSEG>(c, t, 6), vcl, lds + L::vYs, lds + L::vGpy) + vyb;
-                mx[0] = fabs(vx - vzb); mx[1] = fabs(vx); mx[2] = fabs(vzb);
-                mx[3] = fabs(hx + aty); mx[4] = fabs(hx); mx[5] = fabs(aty);
-            }
-            done = q5_check_tail<NSEG>(c, sums, mx);
-            QS(5);
-        }
-#endif
-        if (done) break;
-    }
-    Q5_STAMP_DUMP(it > cfg.qp_iters ? cfg.qp_iters : it);
-    if (laneV) {
-        const int vi = L::NG + (tid - L::tV0);
-        const double *vst = lds + L::vVst + (tid - L::tV0);
-        c.ws.p[(size_t)c.b * (na + 1) + vi] = vst[0];
-        c.ws.y[(size_t)c.b * (D::ma + na + 1) + D::ma + vi] = vst[32];
-    }
-    if (ownsRow) c.ws.y[(size_t)c.b * (D::ma + na + 1) + D::meq + 8 * ((tid - L::tP0) >> 4) + 2 * (((tid - L::tP0) & 15) >> 2) + (tid & 3)] = yg;
+    c.ws.p[(size_t)c.b * (D::na + 1) + vi0] = vx;
+    c.ws.y[(size_t)c.b * (D::ma + D::na + 1) + D::ma + vi0] = vyb;
+    if (isDyn) c.ws.y[(size_t)c.b * (D::ma + D::na + 1) + vi0] = ygd;
 }
 
 template <int NSEG>
@@ -755,7 +811,7 @@ __global__ __launch_bounds__(768) void k_qp5(mpcmp_config cfg, WS ws, const Qp3P
     constexpr int XS = L::XS, NX = L::NX, TS = L::TS;
     Qp5Ctx<NSEG> c;
     c.cfg = &cfg; c.ws = ws; c.lds = lds; c.fa = fac + (size_t)b * F::FAC; c.tid = tid; c.b = b;
-    c.tsT = tsT; c.rho_in = rho_in; c.rho_eq = rho_eq; c.sigma = sigma; c.alpha = alpha;
+    c.tsT = tsT; c.rho_in = rho_in; c.rho_eq = rho_eq; c.sigma = sigma; c.alpha = alpha; c.oma = q5_uniform(1.0 - alpha);
     const double *fa = c.fa;
     // ---------------- the factor's LDS-resident parts, as k_qp3f<NSEG, 1, 5> left them ----------------
     for (int i = tid; i < L::NAP; i += NT) lds[L::vKT + i] = fa[L::oFT + i];
@@ -769,10 +825,9 @@ __global__ __launch_bounds__(768) void k_qp5(mpcmp_config cfg, WS ws, const Qp3P
     };
     auto node_slot = [&](int v) -> int { return v < 14 * N ? XS * (v / 14) + v % 14 : XS * ((v - 14 * N) / 7) + 14 + (v - 14 * N) % 7; };
     // lane jobs of the ADMM iteration: constants lane-transposed in LDS, addresses packed in the lane-constant table (q5_lc)
-    int f[L::NF] = {0, 0, 0, 0, 0, 0, 0, 0};
-    f[4] = NX | ((L::vXn + NX) << 16); f[6] = (4 << 19) | (4 << 22);      // (no variable: pad slots, rows with a zero coefficient)
-    if (tid < L::NG || tid >= L::tV0) {          // the variable of this lane
-        const int vi = tid < L::NG ? tid : L::NG + (tid - L::tV0);
+    int f[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 0..3: the solve, 4..7: pxr, prf, prb, ixr of the lane's variable / dynamics row (G lanes: 4, 5 = gro, xno of the path rows)
+    if (tid >= L::NG || (tid >= L::tV5 && tid < L::tV5 + 16)) {          // the variable of this lane
+        const int vi = tid >= L::NG ? L::vi_of(tid) : L::NG + (tid - L::tV5);
         double cf = 0.0, lo = 0.0, hi = 0.0, ha = 0.0, rb = rho_in;
         int rf = 0, rA = 0, rB = 0, colA = 4, colB = 4;        // (column 4 of the table: zeros)
         if (vi < na) {
@@ -805,27 +860,31 @@ __global__ __launch_bounds__(768) void k_qp5(mpcmp_config cfg, WS ws, const Qp3P
         vc[0] = cf; vc[1 * L::NVL] = lo; vc[2 * L::NVL] = hi; vc[3 * L::NVL] = ha; vc[4 * L::NVL] = rb; vc[5 * L::NVL] = 1.0 / rb;
     }
     if (tid < 16) lds[L::vDT + tid] = tid < 12 ? c_D[4 * (tid % 3) + tid / 3] : 0.0;
-    if (tid < L::NG) {          // the dynamics row of this lane (lanes past the last row: row 0's operands)
-        const int r = tid < meq ? tid : 0, k = r / 14, rr = r % 14;
-        lds[L::vRc + tid] = -ws.ceq[(size_t)b * meq + r];
-        lds[L::vRc + L::NG + tid] = coef_T(r);
-        f[6] |= (k % 3) << 17;
-        f[7] = (3 * (k / 3) * XS + rr) | ((k * XS + (rr < 7 ? 7 + rr : 14 + rr - 7)) << 16);
+    {                           // the dynamics row of this lane: rows 0 .. DR0 - 1 on the pure S lanes, the rest on the first lanes of the last G wave
+        const int r = tid >= L::tSP ? tid - L::tSP : (tid >= L::tV5 && tid < L::tV5 + L::ND5 ? L::DR0 + (tid - L::tV5) : -1);
+        if (r >= 0) {
+            const int k = r / 14, rr = r % 14;
+            lds[L::vRc + r] = -ws.ceq[(size_t)b * meq + r];
+            lds[L::vRc + L::NRC + r] = coef_T(r);
+            f[6] |= (k % 3) << 17;
+            f[7] = (3 * (k / 3) * XS + rr) | ((k * XS + (rr < 7 ? 7 + rr : 14 + rr - 7)) << 16);
+        }
     }
-    if (tid >= L::tP0) {        // path rows: four lanes per pair of rows, sixteen lanes per node
-        const int et = tid - L::tP0, pk = et >> 4, prp = (et & 15) >> 2, pq = et & 3, q = 2 * prp + pq;
+    if (tid < L::tV5) {         // path rows: four lanes per pair of rows, sixteen lanes per node
+        const int pk = tid >> 4, prp = (tid & 15) >> 2, pq = tid & 3, q = 2 * prp + pq;
         double lg = 0.0, ug = 0.0;
-        if (tid < L::tV0 && pq < 2) {
-            const double gv = ws.g[(size_t)b * 8 * N + 8 * pk + q];
-            lg = c_lbg[q] - gv; ug = c_ubg[q] - gv;
-        }
-        lds[L::vPc + et] = lg; lds[L::vPc + L::NPL + et] = ug;
-        { const double rr = (ug - lg < 1e-4) ? rho_eq : rho_in; lds[L::vPc + 2 * L::NPL + et] = rr; lds[L::vPc + 3 * L::NPL + et] = 1.0 / rr; }
-        if (tid < L::tV0) {
+        f[4] = L::oGk; f[5] = NX;                              // (no row: valid operands, nothing is stored)
+        if (tid < L::NPN) {
+            if (pq < 2) {
+                const double gv = ws.g[(size_t)b * 8 * N + 8 * pk + q];
+                lg = c_lbg[q] - gv; ug = c_ubg[q] - gv;
+            }
             // bits 0..15: Jacobian operand (columns 6 pq .. 6 pq + 5 of the 24-wide padded rows 2 prp, 2 prp + 1 of node pk); 16: parity; 17: publishes gp
-            f[2] = (L::oGk + (pk * 8 + 2 * prp) * L::GS + pq * 6) | ((pq & 1) << 16) | ((prp == 0 ? 1 : 0) << 17);
-            f[3] = pk * XS + pq * 6;
+            f[4] = (L::oGk + (pk * 8 + 2 * prp) * L::GS + pq * 6) | ((pq & 1) << 16) | ((prp == 0 ? 1 : 0) << 17);
+            f[5] = pk * XS + pq * 6;
         }
+        const double rr = (ug - lg < 1e-4) ? rho_eq : rho_in;
+        lds[L::vPc + tid] = lg; lds[L::vPc + L::NPL + tid] = ug; lds[L::vPc + 2 * L::NPL + tid] = rr; lds[L::vPc + 3 * L::NPL + tid] = 1.0 / rr;
     }
     // constants of the solve
     if (wave < NSEG) {                              // P1 (k_qp3's LaneC1)
@@ -864,7 +923,12 @@ __global__ __launch_bounds__(768) void k_qp5(mpcmp_config cfg, WS ws, const Qp3P
         f[0] = yop | (tsl << 16); f[1] = (L::vXn + xd0) | ((L::vXn + xd1) << 16);
     }
     {
-        int *lct = reinterpret_cast<int *>(lds + L::vLCT);
+        int *lct = reinterpret_cast<int *>(lds + L::vLCT), *t5 = reinterpret_cast<int *>(lds + L::vL5);
+        if (tid >= L::tV5 && tid < L::NG) {             // last G wave: the variable / dynamics-row words go to their own small table
+#pragma unroll
+            for (int q = 0; q < 4; q++) { t5[q * 64 + (tid - L::tV5)] = f[4 + q]; f[4 + q] = q < 2 ? (q == 0 ? L::oGk : NX) : 0; }
+        }
+        if (tid >= L::NG) { f[2] = f[4]; f[3] = f[5]; f[4] = f[6]; f[5] = f[7]; }      // E / S lanes: 0, 1 the solve, 2..5 pxr, prf, prb, ixr
 #pragma unroll
         for (int q = 0; q < L::NF; q++) lct[q * NT + tid] = f[q];
     }
@@ -872,8 +936,8 @@ __global__ __launch_bounds__(768) void k_qp5(mpcmp_config cfg, WS ws, const Qp3P
     for (int ip = tid; ip < na; ip += NT) lds[rhs_slot(ip)] = lds[L::vKT + ip];      // rhs of K_0 w = k
     __syncthreads();
     if (wave < NSEG) qp5_role_g<NSEG>(c);
-    else if (wave <= L::wS0) qp5_role_ep<NSEG>(c);
-    else qp5_role_sp<NSEG>(c);
+    else if (wave <= L::wS0) qp5_role_es<NSEG, true>(c);
+    else qp5_role_es<NSEG, false>(c);
 }
 
 }  // namespace mpcmp
