@@ -693,6 +693,8 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
     }
     if (cfg->num_seg == 4) {
         if (const char *e = std::getenv("MPCMP_QP13")) ctx->qp13 = std::atoi(e);
+        if (ctx->qp13 != 2 && ctx->qp13 != 3 && ctx->qp13 != 4) { ctx->err = "MPCMP_QP13 must be 2 (k_qp2), 3 (k_qp3) or 4 (k_qp4, experimental: slower than k_qp2)"; return fail(MPCMP_EINVAL); }
+        if (ctx->qp13 != 2 && std::getenv("MPCMP_FORCE_V1")) { ctx->err = "MPCMP_FORCE_V1 and MPCMP_QP13 != 2 exclude each other"; return fail(MPCMP_EINVAL); }
         if (ctx->qp13 != 2) {
             StructureTables t4;
             Qp3Pat pat;

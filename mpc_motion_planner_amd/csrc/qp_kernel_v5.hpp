@@ -1,27 +1,31 @@
 // qp_kernel_v5.hpp — k_qp5<NSEG>: the ADMM loop of the N = 19 QP (the reference as shipped, robot_ocp.hpp:31-32) with EVERY dense
-// factor of the solve resident in registers, loaded once.
+// factor of the solve resident on the CU, loaded once.
 //
 // Same arithmetic as k_qp3 (T bordered out, one arm; structure3.hpp) with k_qp2's solve and k_qp2's row / variable scheme: the
 // interior solve uses E_s = G_s K_JC,s (formed by k_qp3f on the matrix cores and handed over, LAY = 5) instead of a second product
 // with G_s,
 //     t = G b_J;   r_I = b_I - K_CJ t;   y_I = S^-1 r_I;   x_J = t - E y_C,
 // so one solve is three barrier phases, each ONE product on a register-resident block.  768 threads = 12 waves, three per SIMD,
-// 168 registers per lane; the factor (G 6 x 49 x 49, E 6 x 49 x 28, S^-1 98 x 98 = 32 k doubles, 35 k with padding) takes 104 - 112
-// registers of every lane:
+// 168 registers per lane; the factor (G 6 x 49 x 49, E 6 x 49 x 28, S^-1 98 x 98 = 32 k doubles, 35 k with padding) takes ~ 100
+// registers of every lane (the tail column of each block lives in LDS, read with the operands of the product):
 //     role G  waves 0..5, wave = segment: 4 x 13 block of G_s per lane (quad = four rows; lanes 56..62 of wave 5: G_u)   P1
 //     role E  lanes 384..567: 4 x 14 block of E_s per lane (two lanes = four rows; "segment" 6 = E_u)                     P3
 //     role S  lanes 568..767: 4 x 13 block of S^-1 per lane (eight lanes = four rows)                                     P2
 // E^T is not kept (it does not fit): K_CJ t is taken by the G waves from their own t (K_CJ is sparse plus one dense 7 x 14 block per
-// segment), inside the wave, as in k_qp3.  The rows and variables of the ADMM iteration are spread as in k_qp2: a variable and a
-// dynamics row per lane on the G waves (the last variables and T on wave 6), the path rows on sixteen lanes per node on waves 7..11
-// (four lanes per pair of rows, six columns each; the node's path-row part of A^T w is formed by the same lanes).  Five workgroup
-// barriers per ADMM iteration:
+// segment), inside the wave, as in k_qp3.  The rows and variables of the ADMM iteration are spread as in k_qp2, on the waves that have
+// the registers and the idle phases for them: the path rows on sixteen lanes per node on the G waves 0..4 (four lanes per pair of
+// rows, six columns each; the node's path-row part of A^T w is formed by the same lanes), a variable per lane on the E / S waves, a
+// dynamics row per lane on the pure S waves 9..11; the last G wave carries what is left (15 variables, T, 60 dynamics rows).  Five
+// workgroup barriers per ADMM iteration, three role loops (G; waves 6..8; waves 9..11):
 //     A   rhs = sigma x - q + rho_b z_b - y_b + A^T w                      (variable lanes)
-//     P1  t = G b_J, K_CJ t; x~_T of the T border                          (role G; one idle wave sums the border's partial sums)
-//     P2  r_I = b_I - K_CJ t, y_I = S^-1 r_I, interface rows of x~         (role S)
-//     P3  x_J = t - E y_C - w x~_T                                         (role E)
+//     P1  t = G b_J, K_CJ t; x~_T of the T border                          (role G; the last wave sums the border's partial sums)
+//     P2  r_I = b_I - K_CJ t, y_I = S^-1 r_I, interface rows of x~         (S lanes)
+//     P3  x_J = t - E y_C - w x~_T                                         (E lanes)
 //     E   z~ = A x~, relaxation, projection, dual update                   (every lane: its row and / or its variable)
-// The factor blocks are loaded ONCE (k_qp3 re-reads its blocks at every termination test: 2 GB per launch).
+// The factor is loaded ONCE (k_qp3 re-reads its blocks at every termination test: 2 GB per launch).  What makes that possible at 168
+// registers per lane: no per-lane integer lives in a register across the loop (lane-constant table in LDS, fetched in the idle phase
+// before its use), the termination test is a cold block with its own lean reductions, and the row / variable jobs sit where the
+// block leaves room.  DESIGN.md has the measurements (tools/ablate5.py: what-if profile; tools/stamps5.py: phase stamps).
 #pragma once
 #include "qp_kernel_v3.hpp"
 
@@ -126,26 +130,17 @@ __device__ __forceinline__ double q5_gprod(const double (&m)[50], const double *
     return q0 + dpp_mov<0xB1>(q1);                                                  // lanes m, m ^ 1
 }
 // S^-1: 4 x 13 block, eight lanes per group of four rows: quad reduce-scatter as above, then the group's two quads are added; column 12 of
-// every row (entries 12, 25, 38, 51) comes from LDS.  Operand reads in two batches.
+// every row (entries 12, 25, 38, 51) comes from LDS.
 __device__ __forceinline__ double q5_sprod(const double (&m)[48], const double *tl, const int ts, const double *op) {
+    double o[13], t[4];
+#pragma unroll
+    for (int j = 0; j < 13; j++) o[j] = ldv(op + j);
+#pragma unroll
+    for (int q = 0; q < 4; q++) t[q] = ldv(tl + q * ts);
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-    {
-        double o[7];
 #pragma unroll
-        for (int j = 0; j < 7; j++) o[j] = ldv(op + j);
-#pragma unroll
-        for (int j = 0; j < 7; j++) { p0 += m[j] * o[j]; p1 += m[12 + j] * o[j]; p2 += m[24 + j] * o[j]; p3 += m[36 + j] * o[j]; }
-    }
-    {
-        double o[6], t[4];
-#pragma unroll
-        for (int j = 0; j < 6; j++) o[j] = ldv(op + 7 + j);
-#pragma unroll
-        for (int q = 0; q < 4; q++) t[q] = ldv(tl + q * ts);
-#pragma unroll
-        for (int j = 0; j < 5; j++) { p0 += m[7 + j] * o[j]; p1 += m[19 + j] * o[j]; p2 += m[31 + j] * o[j]; p3 += m[43 + j] * o[j]; }
-        p0 += t[0] * o[5]; p1 += t[1] * o[5]; p2 += t[2] * o[5]; p3 += t[3] * o[5];
-    }
+    for (int j = 0; j < 12; j++) { p0 += m[j] * o[j]; p1 += m[12 + j] * o[j]; p2 += m[24 + j] * o[j]; p3 += m[36 + j] * o[j]; }
+    p0 += t[0] * o[12]; p1 += t[1] * o[12]; p2 += t[2] * o[12]; p3 += t[3] * o[12];
     const double q0 = p0 + dpp_mov<0x4E>(p2), q1 = p1 + dpp_mov<0x4E>(p3);
     const double x = q0 + dpp_mov<0xB1>(q1);
     return x + dpp_xor4(x);
@@ -155,13 +150,13 @@ __device__ __forceinline__ double q5_sprod(const double (&m)[48], const double *
 // their factor blocks): DPP inside the waves, one LDS slot per (wave, k), then the sixteen lanes of a DPP row combine the NW partials
 // of one k (k_qp2's scheme); the result is valid in every thread.  Two barriers; `red` (>= (NW + 1) K doubles) must not be shared
 // with a reduction issued right before or after.
-template <int NW, int K, bool MAX>
-__device__ __forceinline__ void q5_reduce(double (&v)[K], double *red, int tid) {
+template <int NW, int K, int KM>
+__device__ __forceinline__ void q5_reduce(double (&v)[K], double *red, int tid) {      // values 0 .. KM - 1: maxima (of magnitudes), KM .. K - 1: sums
     static_assert(NW <= 16 && 16 * K <= 64 * NW, "one DPP row per value");
 #pragma unroll
     for (int k = 0; k < K; k++) {
         double x = v[k];
-        if (MAX) {
+        if (k < KM) {
             x = fmax(x, dpp_mov<0xB1>(x)); x = fmax(x, dpp_mov<0x4E>(x)); x = fmax(x, dpp_mov<0x141>(x)); x = fmax(x, dpp_mov<0x140>(x));
             x = fmax(fmax(x, read_lane(x, 16)), fmax(read_lane(x, 32), read_lane(x, 48)));
         } else x = wave_sum(x);
@@ -170,8 +165,8 @@ __device__ __forceinline__ void q5_reduce(double (&v)[K], double *red, int tid) 
     __syncthreads();
     if (tid < 16 * K) {
         const int w = tid & 15, k = tid >> 4;
-        double a = w < NW ? red[w * K + k] : 0.0;             // (0: identity of both reductions, the maxima are of magnitudes)
-        if (MAX) { a = fmax(a, dpp_mov<0xB1>(a)); a = fmax(a, dpp_mov<0x4E>(a)); a = fmax(a, dpp_mov<0x141>(a)); a = fmax(a, dpp_mov<0x140>(a)); }
+        double a = w < NW ? red[w * K + k] : 0.0;             // (0: identity of both reductions)
+        if (k < KM) { a = fmax(a, dpp_mov<0xB1>(a)); a = fmax(a, dpp_mov<0x4E>(a)); a = fmax(a, dpp_mov<0x141>(a)); a = fmax(a, dpp_mov<0x140>(a)); }
         else { a += dpp_mov<0xB1>(a); a += dpp_mov<0x4E>(a); a += dpp_mov<0x141>(a); a += dpp_mov<0x140>(a); }
         if (w == 0) red[NW * K + k] = a;
     }
@@ -257,16 +252,16 @@ __device__ __forceinline__ void q5_p1(const Qp5Ctx<NSEG> &c, const double (&fm)[
     lds[lo16(k0)] = q5_gprod(fm, lds + L::vTG + t, L::NG, lds + hi16(k0));
     wave_sync();
     const double *kc = lds + lo16(k1), *tc = lds + hi16(k1);
-    double kq[7], tv[7];
+    double kq[7], tv[7], dk[4], dt[4];
 #pragma unroll
     for (int d = 0; d < 7; d++) { kq[d] = ldv(kc + 28 * d); tv[d] = ldv(tc + 7 * (d - 1)); }      // rows c % 14 + 7 (d - 1) of the segment
-    const double acc = ((kq[0] * tv[0] + kq[1] * tv[1]) + (kq[2] * tv[2] + kq[3] * tv[3])) + ((kq[4] * tv[4] + kq[5] * tv[5]) + kq[6] * tv[6]);
-    lds[lo16(k2)] = acc;
     // dense blocks (K_XU t of the columns x_3s; for the last segment also the U block): half a column per lane
-    double dk[4], dt[4];
+    // (every read of this part is issued before its first store: one LDS round trip, not two)
 #pragma unroll
     for (int d = 0; d < 4; d++) { dk[d] = ldv(lds + hi16(k2) + d); dt[d] = ldv(lds + lo16(k3) + d); }
+    const double acc = ((kq[0] * tv[0] + kq[1] * tv[1]) + (kq[2] * tv[2] + kq[3] * tv[3])) + ((kq[4] * tv[4] + kq[5] * tv[5]) + kq[6] * tv[6]);
     const double ad = (dk[0] * dt[0] + dk[1] * dt[1]) + (dk[2] * dt[2] + dk[3] * dt[3]);
+    lds[lo16(k2)] = acc;
     lds[hi16(k3)] = ad + dpp_mov<0xB1>(ad);                                   // (odd lanes, lanes without a column: pad slot)
 }
 // P1 (one idle wave): x~_T = (b_T - w^T b) / delta of the bordered solve; b_T = base + (T column of A^T w)
@@ -372,19 +367,21 @@ __device__ __forceinline__ void q5_finish_border(const Qp5Ctx<NSEG> &c) {
     __syncthreads();
 }
 
-// termination test, common tail (every thread): combine the maxima, add the row / column of T, decide.  Two barriers.
+// termination test, common tail (every thread): combine the maxima and the two sums of the T row / column in ONE reduction, add the row /
+// column of T, decide.  Two barriers.
 template <int NSEG>
-__device__ __forceinline__ int q5_check_tail(const Qp5Ctx<NSEG> &c, const double (&sums)[2], double (&mx)[6]) {
+__device__ __forceinline__ int q5_check_tail(const Qp5Ctx<NSEG> &c, const double (&sums)[2], const double (&mxi)[6]) {
     using L = Qp5<NSEG>;
     const double *misc = c.lds + L::oMisc;
-    q5_reduce<L::NWV, 6, true>(mx, c.lds + L::oRedP + 32, c.tid);
+    double v[8] = {mxi[0], mxi[1], mxi[2], mxi[3], mxi[4], mxi[5], sums[0], sums[1]};
+    q5_reduce<L::NWV, 8, 6>(v, c.lds + L::oRedP, c.tid);
     const double xTv = misc[L::M_xT], zT = misc[L::M_zbT], yT = misc[L::M_ybT];
-    const double hxT = misc[L::M_hdT] * xTv + sums[1], atyT = sums[0] + yT;
-    mx[0] = fmax(mx[0], fabs(xTv - zT)); mx[1] = fmax(mx[1], fabs(xTv)); mx[2] = fmax(mx[2], fabs(zT));
-    mx[3] = fmax(mx[3], fabs(hxT + atyT + 1.0)); mx[4] = fmax(mx[4], fabs(hxT)); mx[5] = fmax(mx[5], fabs(atyT));
-    const double ep = c.cfg->eps_abs + c.cfg->eps_rel * fmax(mx[1], mx[2]);
-    const double ed = c.cfg->eps_abs + c.cfg->eps_rel * fmax(fmax(mx[4], mx[5]), 1.0);      // ||q||_inf = 1
-    return (mx[0] <= ep && mx[3] <= ed) ? 1 : 0;
+    const double hxT = misc[L::M_hdT] * xTv + v[7], atyT = v[6] + yT;
+    const double m0 = fmax(v[0], fabs(xTv - zT)), m1 = fmax(v[1], fabs(xTv)), m2 = fmax(v[2], fabs(zT));
+    const double m3 = fmax(v[3], fabs(hxT + atyT + 1.0)), m4 = fmax(v[4], fabs(hxT)), m5 = fmax(v[5], fabs(atyT));
+    const double ep = c.cfg->eps_abs + c.cfg->eps_rel * fmax(m1, m2);
+    const double ed = c.cfg->eps_abs + c.cfg->eps_rel * fmax(fmax(m4, m5), 1.0);      // ||q||_inf = 1
+    return (m0 <= ep && m3 <= ed) ? 1 : 0;
 }
 
 // ---- a variable lane (k_qp2's role B): ADMM state of one variable, its constants lane-transposed in LDS ----
@@ -587,7 +584,6 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
         }
         pxr = q5_l5<NSEG>(c, sio & 63, 0); prf = q5_l5<NSEG>(c, sio & 63, 1); prb = q5_l5<NSEG>(c, sio & 63, 2);
         Q5B(4); __syncthreads(); Q5S(4);
-#ifndef Q5_NOTEST
         if (__builtin_expect(check, 0)) {
             int t = tid;
             asm volatile("" : "+v"(t));
@@ -609,7 +605,7 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
             const double *vcl = lds + L::vVc + vi, *vst = lds + L::vVst + (laneV ? t - L::tV5 : 0);
             const double ha = isVar ? ldv(vcl + 3 * L::NVL) : 0.0, vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32);
             if (isVar) sums[1] = ha * vx;
-            q5_reduce<L::NWV, 2, false>(sums, lds + L::oRedP, tid);
+            __syncthreads();                                      // (gpy published)
             if (laneD) {
                 const double zgd = ldv(lds + L::vRc + L::DR0 + (t - L::tV5));
                 const double ax = row_dot_dyn(lds + L::vXx, q5_l5<NSEG>(c, t & 63, 3), L::oCD + 4 * ((q5_l5<NSEG>(c, t & 63, 2) >> 17) & 3), rcT5);
@@ -624,7 +620,6 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
             done = q5_check_tail<NSEG>(c, sums, mx);
             Q5S(5);
         }
-#endif
         if (done) break;
     }
     const bool capped = it > cfg.qp_iters;
@@ -769,7 +764,6 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
             if (check) lds[L::vXx + xpos] = vx;
         }
         Q5B(4); __syncthreads(); Q5S(4);
-#ifndef Q5_NOTEST
         if (__builtin_expect(check, 0)) {
             int t = tid;
             asm volatile("" : "+v"(t));
@@ -779,7 +773,7 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
             const double ha = ldv(vcl + 3 * L::NVL);
             const double rcT = isDyn ? ldv(rcl + L::NRC) : 0.0, zgd = isDyn ? ldv(rcl) : 0.0;
             double sums[2] = {isDyn ? rcT * ygd : 0.0, ha * vx};
-            q5_reduce<L::NWV, 2, false>(sums, lds + L::oRedP, tid);      // (its barriers publish gpy)
+            __syncthreads();                                      // (gpy published)
             double mx[6] = {0, 0, 0, 0, 0, 0};
             if (isDyn) {
                 const double ax = row_dot_dyn(xx, ixc, L::oCD + 4 * ((prbc >> 17) & 3), rcT);
@@ -793,7 +787,6 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
             done = q5_check_tail<NSEG>(c, sums, mx);
             Q5S(5);
         }
-#endif
         if (done) break;
     }
     Q5_STAMP_DUMP(it > cfg.qp_iters ? cfg.qp_iters : it);

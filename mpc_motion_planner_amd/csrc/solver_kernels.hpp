@@ -44,7 +44,7 @@ struct WS {
     unsigned long long *dbg;  // [B][MPCMP_DBG_WORDS] phase cycle stamps (diagnostic builds with -DMPCMP_STAMPS only)
 };
 
-// ws.status[b] while a solve runs: bits 0..7 = status bits of mpcmp_info (include/mpcmp.h), bits 8..15 = number of QPs that ran out of
+// ws.status[b] while a solve runs: bits 0..7 = status bits of mpcmp_info (include/mpcmp.h), bits 8..30 = number of QPs that ran out of
 // iterations (every QP kernel adds MPCMP_ST_CAP_ONE then); k_step / k_step_m fold it into the record
 #define MPCMP_ST_CAP_ONE 0x100
 #define MPCMP_DBG_WORDS 160   /* 16 workgroup stamps + [16 waves][8] per-wave busy cycles of k_qp2 + 16 stamps of k_step */
@@ -88,7 +88,7 @@ __device__ __forceinline__ double clip(double v, double lo, double hi) { return 
 // status word and capped-QP count of the result record (include/mpcmp.h: MPCMP_STATUS_*; the oracle's orc_solve_multi does the same)
 __device__ __forceinline__ void report_status(const mpcmp_config &cfg, int st, int anybad, mpcmp_info &o) {
     int s = (st & 0xFF) | (anybad ? MPCMP_STATUS_NAN : 0);
-    o.qp_capped = (st >> 8) & 0xFF;
+    o.qp_capped = (st >> 8) & 0x7FFFFF;      // (23 bits: the count cannot wrap for any sqp_iters a solve can run)
     if (o.qp_capped) s |= MPCMP_STATUS_QP_CAPPED;
     if (o.defect_inf > cfg.eps_abs || o.path_viol_inf > cfg.eps_abs || o.term_err_inf > cfg.eps_target + cfg.eps_abs) s |= MPCMP_STATUS_OUTSIDE_TOL;
     if (!(o.T >= cfg.lbT - 1e-9 && o.T <= cfg.ubT + 1e-9)) s |= MPCMP_STATUS_T_OUT_OF_BOX;

@@ -157,7 +157,11 @@ static void work_free(work *w) {
 }
 
 /* structure probes against the reference's ONE stored solve; a bit mask in the environment, 0 = the specification */
+#ifdef ORC_PROBE_BUILD      /* hypothesis probes (tools/polympc_param_fit.py --probe): only in liboracle_probe.so (make -C oracle probe) */
 static int orc_probe(void) { const char *e = getenv("ORC_PROBE"); return e ? atoi(e) : 0; }
+#else                       /* liboracle.so, the specification every parity test and the CPU baseline use: the probes are compiled out */
+static int orc_probe(void) { return 0; }
+#endif
 
 static void set_boxes(work *w, const orc_config *c, const double *x0, const double *xf) {
     int N = w->N;

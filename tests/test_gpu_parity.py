@@ -120,8 +120,36 @@ def test_n13_e_free_kernels_vs_oracle(M, kern, monkeypatch):
 
 @pytest.mark.parametrize("nseg,B,iters", [(6, 2, 5), (6, 3, 700), (8, 2, 5), (8, 3, 700)])
 def test_qp3_vs_oracle(M, nseg, B, iters):
-    """k_qp3 (N = 19 as shipped, N = 25): T bordered out, E-free interior solve — one QP against the oracle's skyline Cholesky"""
+    """N = 19 as shipped (default kernel: k_qp3f<6, 1, 5> + k_qp5, factor resident on the CU) and N = 25 (k_qp3f + k_qp3): T bordered out —
+    one QP against the oracle's skyline Cholesky"""
     _qp_case(M, nseg, B, iters)
+
+
+def test_n19_both_loop_kernels_vs_oracle(M, monkeypatch):
+    """N = 19 through BOTH loop kernels (MPCMP_QP19 picks at mpcmp_create): 5 = k_qp5 (default: G, E, S^-1 blocks in registers, loaded once),
+    3 = k_qp3 (E-free, blocks re-read every test period).  One full QP and a 2-iteration solve each against the oracle, identical ADMM
+    iteration counts; the two kernels' results agree to round-off."""
+    from mpc_motion_planner_amd import scenarios
+    res = {}
+    for kern in ("5", "3"):
+        monkeypatch.setenv("MPCMP_QP19", kern)
+        _qp_case(M, 6, 3, 700)
+        cfg, ocfg = _cfgs(M, 6, 2)
+        B = 3
+        x0, xf = scenarios.make_batch(B, stream_offset=70)
+        s = M.Solver(cfg, B)
+        assert s.kernel_timing()[0] == ("k_qp5" if kern == "5" else "k_qp3")
+        wx = np.zeros((B, 19, 14)); wu = np.zeros((B, 19, 7)); wT = np.zeros(B)
+        for b in range(B):
+            wx[b], wu[b], wT[b] = o.warm_start(ocfg, x0[b], xf[b])
+        sx, su, sT, info = s.solve(x0, xf, (wx, wu, wT))
+        for b in range(B):
+            xs, us, T, oi = o.solve(ocfg, x0[b], xf[b], wx[b], wu[b], wT[b])
+            assert abs(sT[b] - T) <= 1e-6 * T and np.abs(sx[b] - xs).max() <= 1e-6
+            assert info["qp_iters_total"][b] == oi.qp_iters_total and info["status"][b] == oi.status
+        res[kern] = (sx, sT, info["qp_iters_total"].copy())
+    assert np.array_equal(res["5"][2], res["3"][2])
+    assert np.abs(res["5"][0] - res["3"][0]).max() <= 1e-7 and np.abs(res["5"][1] - res["3"][1]).max() <= 1e-8
 
 
 @pytest.mark.parametrize("nseg,sqp,B", [(4, 2, 4), (4, 20, 3), (6, 2, 3), (6, 20, 2), (8, 2, 3), (8, 20, 2), (2, 3, 2), (1, 3, 2)])

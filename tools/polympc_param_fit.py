@@ -57,6 +57,11 @@ def residuals(g, xs, us, T, nseg=6):
 
 
 def probe(g, x0, xf):
+    # the probes are compiled out of liboracle.so (the specification): this tool loads its own build, liboracle_probe.so
+    import subprocess
+    import oracle_py
+    subprocess.check_call(["make", "-C", os.path.join(oracle_py.ROOT, "oracle"), "-B", "liboracle_probe.so"], stdout=subprocess.DEVNULL)
+    oracle_py._SO = os.path.join(oracle_py.ROOT, "oracle", "liboracle_probe.so"); oracle_py._lib = None
     lim = o.default_limits(); m = g["margins"]
     xg, ug, Tg = o.warm_start_jerk(6, m[1] * lim["vmax"], m[2] * lim["amax"], m[4] * lim["jmax"], x0, xf)
     def run(mask, **kw):

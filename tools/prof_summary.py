@@ -6,14 +6,14 @@ import sys
 
 
 def short(name):
-    for k in ("k_qp3f", "k_qp3", "k_qp2", "k_qp4", "k_qp", "k_step_m", "k_step", "k_init_m", "k_init", "k_warm_jerk", "k_sample", "k_rnea_batch", "k_eval_constraints"):
+    for k in ("k_qp3f", "k_qp3", "k_qp2", "k_qp4", "k_qp5", "k_qp", "k_step_m", "k_step", "k_init_m", "k_init", "k_warm_jerk", "k_sample", "k_rnea_batch", "k_eval_constraints"):
         if k in name:
             i = name.find("ILi")
             return k + ("<%s>" % name[i + 3:name.find("E", i)] if i >= 0 else "")
     return name[:60]
 
 
-for path in sys.argv[1:]:
+for path in (sys.argv[1:] if __name__ == "__main__" else []):
     db = sqlite3.connect(path)
     cur = db.cursor()
     print("== %s" % path)

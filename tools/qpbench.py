@@ -14,6 +14,8 @@ nseg = int(os.environ.get("QPB_NSEG", "4"))
 for B in [int(a) for a in sys.argv[1:]] or [256, 512, 1024]:
     cfg = M.default_config(nseg, 1, margins=(0.9, 0.9, 0.5, 0.9))
     cfg.eps_abs = 0.0; cfg.eps_rel = 0.0
+    if os.environ.get("QPB_CE"):
+        cfg.check_every = int(os.environ["QPB_CE"])      # (e.g. 10000: no termination test at all)
     s = M.Solver(cfg, B)
     x0, xf = scenarios.make_batch(B)
     wx, wu, wT = s.warm_start(x0, xf)
