@@ -100,18 +100,29 @@ def status_fractions(st):
 
 
 def committed_counters(workload):
-    """FP64 VALU instruction counters of the dominant kernels from the committed rocprofv3 PMC pass (profiles/r03_fp64_counters.json, written
-    by tools/fp64_counters.py from `tools/profile_round.sh`): flops the ISA executed per ADMM iteration of one trajectory (factorisation
-    included in the ratio).  None if the profile is absent."""
+    """FP64 VALU instruction counters of the dominant kernels from the newest committed rocprofv3 PMC pass (profiles/r0N_fp64_counters.json, written
+    by tools/fp64_counters.py from `tools/profile_round.sh`): flops the ISA executed per ADMM iteration of one trajectory (factorisation included in
+    the ratio; wave-level counts x 64 lanes, inactive lanes included: an upper bound).  `stale` is True when the kernel sources of the working tree
+    (tools/src_hash.py) are not the ones the profile was measured on: the fraction is then withheld.  None if no profile has the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
-        cj = json.load(open(os.path.join(ROOT, "profiles", "r03_fp64_counters.json")))
-        e = cj["workloads"].get(workload)
-        if e is None:
-            return None
-        return {"flops_per_admm_iter": float(e["fp64_flops_per_traj_admm_iter"]), "source": "profiles/r03_fp64_counters.json", "build": cj.get("build"),
-                "counters": "64 x (2 SQ_INSTS_VALU_FMA_F64 + SQ_INSTS_VALU_ADD_F64 + SQ_INSTS_VALU_MUL_F64) + MFMA MOPS, of every QP kernel"}
+        from src_hash import csrc_sha16
+        now = csrc_sha16(ROOT)
     except Exception:
-        return None
+        now = None
+    for f in ("r04_fp64_counters.json", "r03_fp64_counters.json"):
+        try:
+            cj = json.load(open(os.path.join(ROOT, "profiles", f)))
+            e = cj["workloads"].get(workload)
+            if e is None:
+                continue
+            sha = e.get("csrc_sha16") or cj.get("csrc_sha16")
+            return {"flops_per_admm_iter": float(e["fp64_flops_per_traj_admm_iter"]), "source": "profiles/" + f, "csrc_sha16": sha, "tree_sha16": now,
+                    "stale": bool(sha is None or now is None or sha != now),
+                    "counters": "64 x (2 SQ_INSTS_VALU_FMA_F64 + SQ_INSTS_VALU_ADD_F64 + SQ_INSTS_VALU_MUL_F64) + MFMA MOPS, of every QP kernel; inactive lanes counted (upper bound)"}
+        except Exception:
+            pass
+    return None
 
 
 def cpu_baseline(nseg, sqp, x0, xf, warm, n_multi, n_single):
@@ -182,14 +193,16 @@ def bench_receding_horizon(args, M, scenarios, local):
     N = 3 * nseg + 1
     admm_per_resolve = float(info["qp_iters_total"].mean())           # of the last re-solve
     flops = canonical_flops(N, sqp, admm_per_resolve)
+    cc_rh = committed_counters("batch")
     line = {"metric": "re-solves/sec, receding-horizon MPC, 512 instances x 200 warm-started re-solves", "value": out["graph"],
             "unit": "re-solves/s", "n_gpus": 1, "steps": resolves, "warmup": 2, "ms_per_step": 1e3 * B / out["graph"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "eager_value": out["eager"], "dtype": "f64", "data": "synthetic",
             "config": {"workload": "512 Panda instances x 200 re-solves, N=13, 2 SQP iters/re-solve, dt=10 ms, hipGraph replay of the two-stream step "
                                    "(BASELINE.json configs[4])"},
             "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": out["graph"] * flops / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (out["graph"] * admm_per_resolve * committed_counters("batch")["flops_per_admm_iter"] / 1e12 / FP64_PEAK_TFLOPS) if committed_counters("batch") else None,
-                         "frac_def": "FP64 flops the QP kernel executed (instruction counters of the N = 13 kernel x 64 lanes) over the wall clock / peak",
+                         "frac": (out["graph"] * admm_per_resolve * cc_rh["flops_per_admm_iter"] / 1e12 / FP64_PEAK_TFLOPS) if (cc_rh and not cc_rh["stale"]) else None,
+                         "frac_def": "FP64 flops the QP kernel executed (instruction counters of the N = 13 kernel x 64 lanes, inactive lanes counted: an upper bound) over the wall clock / peak; null when the committed counter profile is stale (executed_source.stale)",
+                         "executed_source": cc_rh,
                          "canonical_frac": out["graph"] * flops / 1e12 / FP64_PEAK_TFLOPS, "traffic": None, "mfma_busy": 0.0,
                          "avg_launch_ms_eager": (k_ms / max(k_n, 1)) if k_n else None, "launches_eager": k_n,
                          "admm_iters_per_resolve": admm_per_resolve, "canonical_gflop_per_resolve": flops / 1e9,
@@ -421,7 +434,7 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
         cc = committed_counters(workload)
         ex = EXECUTED_FMA.get(nseg)
         if cc is not None:
-            executed = per_gpu * admm_mean * cc["flops_per_admm_iter"] / 1e12
+            executed = None if cc["stale"] else per_gpu * admm_mean * cc["flops_per_admm_iter"] / 1e12      # (a stale profile yields no fraction: frac null, executed_source.stale true)
         else:
             executed = per_gpu * 2.0 * (admm_mean * ex[0] + sqp * ex[1]) / 1e12 if ex else None
         feasible = (inf["status"] & (1 | 2 | 4 | 16 | 32)) == 0           # inside every tolerance and no hard failure (capped QPs allowed)
@@ -439,7 +452,7 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
             # the binding resource is FP64 vector issue + LDS + workgroup barriers: not HBM, not MFMA
             "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (executed / FP64_PEAK_TFLOPS) if executed is not None else None,
-                         "frac_def": "FP64 flops the QP kernels executed (instruction counters x 64 lanes) per GPU over the wall clock of the timed region / peak",
+                         "frac_def": "FP64 flops the QP kernels executed (instruction counters x 64 lanes, inactive lanes counted: an upper bound) per GPU over the wall clock of the timed region / peak; null when the committed counter profile was measured on other kernel sources (executed_source.stale)",
                          "executed_source": cc if cc is not None else "hand count (bench.py EXECUTED_FMA): no counter profile committed",
                          "canonical_frac": achieved / FP64_PEAK_TFLOPS,
                          "peak_measured": peak_meas, "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None,

@@ -99,7 +99,7 @@ def run(args, rank, world, local, dist, steps=None, warmup=None, batch=None):
     peak_meas = Bn.measured_fp64_peak()
     cc = Bn.committed_counters("dual14")
     if cc is not None:
-        executed = per_gpu * admm_mean * cc["flops_per_admm_iter"] / 1e12
+        executed = None if cc["stale"] else per_gpu * admm_mean * cc["flops_per_admm_iter"] / 1e12      # (stale counter profile: no fraction)
     else:
         executed = per_gpu * 2.0 * narm * (admm_mean * Bn.EXECUTED_FMA[nseg][0] + sqp * Bn.EXECUTED_FMA[nseg][1]) / 1e12
     out = {
@@ -112,8 +112,8 @@ def run(args, rank, world, local, dist, steps=None, warmup=None, batch=None):
                    "batch": batch, "problems_total": total, "problems_rank0": B, "rccl_world_size": world, "seed": scenarios.SEED,
                    "margins": list(margins), "n_variables": 42 * N + 1},
         "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": Bn.FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": executed / Bn.FP64_PEAK_TFLOPS,
-                     "frac_def": "FP64 flops the QP kernels executed (instruction counters x 64 lanes) per GPU over the wall clock of the timed region / peak",
+                     "frac": (executed / Bn.FP64_PEAK_TFLOPS) if executed is not None else None,
+                     "frac_def": "FP64 flops the QP kernels executed (instruction counters x 64 lanes, inactive lanes counted: an upper bound) per GPU over the wall clock of the timed region / peak; null when the committed counter profile was measured on other kernel sources (executed_source.stale)",
                      "executed_source": cc if cc is not None else "hand count (bench.py EXECUTED_FMA): no counter profile committed",
                      "canonical_frac": achieved / Bn.FP64_PEAK_TFLOPS,
                      "peak_measured": peak_meas,

@@ -5,7 +5,9 @@
     divided by (problems solved in the process x ADMM iterations per trajectory of the bench line).
 usage: fp64_counters.py <workload> <pmc results.db> <bench line of the same process (json file or log)> [<mfma results.db>]
 prints one JSON object (tools/profile_round.sh collects them into profiles/r03_fp64_counters.json)."""
-import json, re, sqlite3, sys
+import json, os, re, sqlite3, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from src_hash import csrc_sha16
 
 def is_qp(name):
     return "k_qp" in name          # k_qp, k_qp2, k_qp3f, k_qp3, k_qp4 (mangled or demangled)
@@ -44,7 +46,7 @@ def main():
                     tot[cn] += d[cn][1]
                     per_kernel.setdefault(kn[:60], {})[cn] = d[cn][1] / max(d[cn][0], 1)
     flops = 64.0 * (2.0 * tot["SQ_INSTS_VALU_FMA_F64"] + tot["SQ_INSTS_VALU_ADD_F64"] + tot["SQ_INSTS_VALU_MUL_F64"]) + 512.0 * tot["SQ_INSTS_VALU_MFMA_MOPS_F64"]
-    print(json.dumps({"workload": workload, "problems_solved_in_process": problems, "admm_iters_per_traj": admm, "counter_sums": tot,
+    print(json.dumps({"workload": workload, "csrc_sha16": csrc_sha16(), "problems_solved_in_process": problems, "admm_iters_per_traj": admm, "counter_sums": tot,
                       "per_dispatch_avg": per_kernel, "fp64_flops_total": flops,
                       "fp64_flops_per_traj_admm_iter": flops / max(problems * admm, 1.0)}))
 
