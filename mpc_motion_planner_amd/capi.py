@@ -64,7 +64,7 @@ def library_path():
 def build_library(force=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "qp_kernel_v2.hpp", "qp_kernel_v3.hpp", "structure3.hpp", "rbd_device.hpp", "structure.hpp", "multi_kernels.hpp",
+    deps = [os.path.join(src, f) for f in ("mpcmp.hip", "solver_kernels.hpp", "qp_kernel_v2.hpp", "qp_kernel_v3.hpp", "qp_kernel_v5.hpp", "structure3.hpp", "rbd_device.hpp", "structure.hpp", "multi_kernels.hpp",
                                            "kinematics_host.hpp", "jerk_device.hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "mpcmp.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
@@ -75,12 +75,29 @@ def build_library(force=False):
 _lib = None
 
 
+def _torch_runtime_first():
+    """torch bundles its own libamdhip64.so; libmpcmp.so links the system one (/opt/rocm), same soname.  Whichever is mapped first serves
+    both: with torch's first everything works (the order bench.py and the tests have); with the system runtime first, a LATER `import torch`
+    maps a second HIP runtime and reports "No HIP GPUs are available".  So: if torch is installed and not yet imported, import it before the
+    library is loaded (MPCMP_NO_TORCH_PRELOAD=1 skips this, e.g. for torch-free deployments that want the shorter start-up)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("MPCMP_NO_TORCH_PRELOAD"):
+        return
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
             raise MpcmpError(-2, "libmpcmp.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                                  "there is no CPU fallback" % _SO)
+        _torch_runtime_first()
         L = C.CDLL(_SO)
         L.mpcmp_version.restype = C.c_char_p
         L.mpcmp_last_error.restype = C.c_char_p

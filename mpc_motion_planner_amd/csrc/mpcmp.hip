@@ -19,7 +19,9 @@
 #include "solver_kernels.hpp"
 #include "qp_kernel_v2.hpp"
 #include "qp_kernel_v3.hpp"
+#ifdef MPCMP_WITH_QP4      /* the measured two-OCPs-per-CU alternative for N = 13 (does not pay): tools/experiments/, built only on request (-DMPCMP_WITH_QP4 -Itools/experiments) */
 #include "qp_kernel_v4.hpp"
+#endif
 #include "qp_kernel_v5.hpp"
 #include "multi_kernels.hpp"
 #include "kinematics_host.hpp"
@@ -694,6 +696,9 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
     if (cfg->num_seg == 4) {
         if (const char *e = std::getenv("MPCMP_QP13")) ctx->qp13 = std::atoi(e);
         if (ctx->qp13 != 2 && ctx->qp13 != 3 && ctx->qp13 != 4) { ctx->err = "MPCMP_QP13 must be 2 (k_qp2), 3 (k_qp3) or 4 (k_qp4, experimental: slower than k_qp2)"; return fail(MPCMP_EINVAL); }
+#ifndef MPCMP_WITH_QP4
+        if (ctx->qp13 == 4) { ctx->err = "MPCMP_QP13=4: this library was built without k_qp4 (experimental kernel: rebuild with -DMPCMP_WITH_QP4 -Itools/experiments)"; return fail(MPCMP_EINVAL); }
+#endif
         if (ctx->qp13 != 2 && std::getenv("MPCMP_FORCE_V1")) { ctx->err = "MPCMP_FORCE_V1 and MPCMP_QP13 != 2 exclude each other"; return fail(MPCMP_EINVAL); }
         if (ctx->qp13 != 2) {
             StructureTables t4;
@@ -708,10 +713,12 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
             TRY(dalloc(ctx, &ctx->d_fac, (size_t)max_batch * fac_doubles(4)));
             TRY(dalloc(ctx, &ctx->d_pat, 1));
             HIPTRY(hipMemcpy(ctx->d_pat, &pat, sizeof(Qp3Pat), hipMemcpyHostToDevice));
+#ifdef MPCMP_WITH_QP4
             std::vector<uint32_t> lane4((size_t)Qp4<4>::NF * Qp4<4>::NT);
             qp4_build_lanes<4>(pat, t4.ext_of_int.data(), lane4.data());
             TRY(dalloc(ctx, &ctx->d_lane4, lane4.size()));
             HIPTRY(hipMemcpy(ctx->d_lane4, lane4.data(), lane4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+#endif
         }
     }
 #undef TRY
@@ -775,6 +782,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         if (int rc = set_lds(ctx, k_qp5<6>, Qp5<6>::size5 * sizeof(double))) return rc;
         if (int rc = set_lds(ctx, k_qp3f<6, 1, 5>, Qp3<6>::sizeF * sizeof(double))) return rc;
     }
+#ifdef MPCMP_WITH_QP4
     const size_t l_qp4 = Qp4<4>::size * sizeof(double);
     if (V4) {
         if (int rc = set_lds(ctx, k_qp4<4>, l_qp4)) return rc;
@@ -786,6 +794,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
             std::fprintf(stderr, "k_qp4: %zu B of dynamic LDS, %d workgroups per CU\n", l_qp4, nb);
         }
     }
+#endif
     const size_t l_qp2 = Qp2<V2C ? NSEG : 4>::size * sizeof(double);
     if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
     else if (!V3C && !V4) { if (int rc = set_lds(ctx, k_qp<(NSEG >= 6) ? 1 : NSEG>, l_qp)) return rc; }
@@ -825,6 +834,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         for (int h = 0; h < nhalf; h++) {
             hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
             if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
+#ifdef MPCMP_WITH_QP4
             if (V4) {
                 WS w3 = wh[h];
                 w3.ext_of_int = ctx->d3_ext_of_int; w3.entry_ptr = ctx->d3_entry_ptr; w3.terms = ctx->d3_terms;
@@ -832,6 +842,9 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
                 hipLaunchKernelGGL((k_qp3f<4, 1, 4>), dim3(Bh[h]), dim3(1024), Qp3<4>::sizeF * sizeof(double), sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
                 hipLaunchKernelGGL((k_qp4<4>), dim3(Bh[h]), dim3(384), l_qp4, sh[h], ctx->cfg, w3, (const uint32_t *)ctx->d_lane4, Bh[h], (const double *)fh);
             }
+#else
+            if (V4) { ctx->err = "k_qp4 not built"; return MPCMP_EINVAL; }
+#endif
             else if (NSEG == 6 && ctx->qp19 == 5) {
                 double *fh = ctx->d_fac + (size_t)boff[h] * Qp5Fac<6>::FAC;
                 hipLaunchKernelGGL((k_qp3f<6, 1, 5>), dim3(Bh[h]), dim3(1024), Qp3<6>::sizeF * sizeof(double), sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);

@@ -212,6 +212,35 @@ __device__ __forceinline__ void block_reduce_dpp(double (&v)[K], double *red, in
     __syncthreads();
 }
 
+// Workgroup reduction (sum or max) of K values per thread for the termination tests, with a small register footprint (the lanes carry
+// their factor blocks; block_reduce_dpp's second stage reads NW x K partials per thread, which the compiler keeps all in flight): DPP inside the waves, one LDS slot per (wave, k), then the sixteen lanes of a DPP row combine the NW partials
+// of one k (k_qp2's scheme); the result is valid in every thread.  Two barriers; `red` (>= (NW + 1) K doubles) must not be shared
+// with a reduction issued right before or after.
+template <int NW, int K, int KM>
+__device__ __forceinline__ void block_reduce_lean(double (&v)[K], double *red, int tid) {      // values 0 .. KM - 1: maxima (of magnitudes), KM .. K - 1: sums
+    static_assert(NW <= 16 && 16 * K <= 64 * NW, "one DPP row per value");
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double x = v[k];
+        if (k < KM) {
+            x = fmax(x, dpp_mov<0xB1>(x)); x = fmax(x, dpp_mov<0x4E>(x)); x = fmax(x, dpp_mov<0x141>(x)); x = fmax(x, dpp_mov<0x140>(x));
+            x = fmax(fmax(x, read_lane(x, 16)), fmax(read_lane(x, 32), read_lane(x, 48)));
+        } else x = wave_sum(x);
+        if ((tid & 63) == 0) red[(tid >> 6) * K + k] = x;
+    }
+    __syncthreads();
+    if (tid < 16 * K) {
+        const int w = tid & 15, k = tid >> 4;
+        double a = w < NW ? red[w * K + k] : 0.0;             // (0: identity of both reductions)
+        if (k < KM) { a = fmax(a, dpp_mov<0xB1>(a)); a = fmax(a, dpp_mov<0x4E>(a)); a = fmax(a, dpp_mov<0x141>(a)); a = fmax(a, dpp_mov<0x140>(a)); }
+        else { a += dpp_mov<0xB1>(a); a += dpp_mov<0x4E>(a); a += dpp_mov<0x141>(a); a += dpp_mov<0x140>(a); }
+        if (w == 0) red[NW * K + k] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = red[NW * K + k];
+}
+
 // diagnostic builds (-DMPCMP_STAMPS, tools/stamps3.py): cycles per phase of the ADMM loop (QS: after a barrier) and the busy part of
 // each phase per wave (QB: in front of the barrier)
 #ifdef MPCMP_STAMPS
@@ -913,7 +942,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // termination test, common tail: combine the arms, add the row / column of T, decide
     const unsigned chk_base = 8 + cfg.qp_iters + 1;
     auto check_tail = [&](double (&sums)[2], double (&mx)[6], int nchk) -> int {
-        block_reduce_dpp<8, 6, true>(mx, redp, tid);
+        block_reduce_lean<8, 6, 6>(mx, redp + 32, tid);
         double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
         s1[arm] = sums[0]; s2[arm] = sums[1];
         if (NARM == 2) {
@@ -1417,7 +1446,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 }
             }
             if (sio < N) xt[NS * sio + 21] = misc[L::M_xT];
-            block_reduce_dpp<8, 2, false>(sums, redp, tid);      // (its barriers publish xt / ys)
+            block_reduce_lean<8, 2, 0>(sums, redp, tid);          // (its barriers publish xt / ys)
             double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
             const double xTc = xt[21];
 #pragma unroll

@@ -146,35 +146,6 @@ __device__ __forceinline__ double q5_sprod(const double (&m)[48], const double *
     return x + dpp_xor4(x);
 }
 
-// Workgroup reduction (sum or max) of K values per thread for the termination tests, with a small register footprint (the lanes carry
-// their factor blocks): DPP inside the waves, one LDS slot per (wave, k), then the sixteen lanes of a DPP row combine the NW partials
-// of one k (k_qp2's scheme); the result is valid in every thread.  Two barriers; `red` (>= (NW + 1) K doubles) must not be shared
-// with a reduction issued right before or after.
-template <int NW, int K, int KM>
-__device__ __forceinline__ void q5_reduce(double (&v)[K], double *red, int tid) {      // values 0 .. KM - 1: maxima (of magnitudes), KM .. K - 1: sums
-    static_assert(NW <= 16 && 16 * K <= 64 * NW, "one DPP row per value");
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        double x = v[k];
-        if (k < KM) {
-            x = fmax(x, dpp_mov<0xB1>(x)); x = fmax(x, dpp_mov<0x4E>(x)); x = fmax(x, dpp_mov<0x141>(x)); x = fmax(x, dpp_mov<0x140>(x));
-            x = fmax(fmax(x, read_lane(x, 16)), fmax(read_lane(x, 32), read_lane(x, 48)));
-        } else x = wave_sum(x);
-        if ((tid & 63) == 0) red[(tid >> 6) * K + k] = x;
-    }
-    __syncthreads();
-    if (tid < 16 * K) {
-        const int w = tid & 15, k = tid >> 4;
-        double a = w < NW ? red[w * K + k] : 0.0;             // (0: identity of both reductions)
-        if (k < KM) { a = fmax(a, dpp_mov<0xB1>(a)); a = fmax(a, dpp_mov<0x4E>(a)); a = fmax(a, dpp_mov<0x141>(a)); a = fmax(a, dpp_mov<0x140>(a)); }
-        else { a += dpp_mov<0xB1>(a); a += dpp_mov<0x4E>(a); a += dpp_mov<0x141>(a); a += dpp_mov<0x140>(a); }
-        if (w == 0) red[NW * K + k] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; k++) v[k] = red[NW * K + k];
-}
-
 // what-if profiling (tools/ablate5.py): -DQ5_ABL=n removes one piece of the ADMM iteration (results are then wrong); the change in run time at a
 // fixed iteration count is that piece's share of the critical path.  0 = product build.
 #ifndef Q5_ABL
@@ -374,7 +345,7 @@ __device__ __forceinline__ int q5_check_tail(const Qp5Ctx<NSEG> &c, const double
     using L = Qp5<NSEG>;
     const double *misc = c.lds + L::oMisc;
     double v[8] = {mxi[0], mxi[1], mxi[2], mxi[3], mxi[4], mxi[5], sums[0], sums[1]};
-    q5_reduce<L::NWV, 8, 6>(v, c.lds + L::oRedP, c.tid);
+    block_reduce_lean<L::NWV, 8, 6>(v, c.lds + L::oRedP, c.tid);
     const double xTv = misc[L::M_xT], zT = misc[L::M_zbT], yT = misc[L::M_ybT];
     const double hxT = misc[L::M_hdT] * xTv + v[7], atyT = v[6] + yT;
     const double m0 = fmax(v[0], fabs(xTv - zT)), m1 = fmax(v[1], fabs(xTv)), m2 = fmax(v[2], fabs(zT));

@@ -102,6 +102,12 @@ def test_n13_e_free_kernels_vs_oracle(M, kern, monkeypatch):
     384-thread / 80 KB loop sized for two OCPs per CU (it does not co-reside at its 168 VGPRs, kept as a measured
     alternative).  One full QP and a 3-iteration solve against the oracle, identical ADMM iteration counts."""
     monkeypatch.setenv("MPCMP_QP13", kern)
+    if kern == "4":     # k_qp4 is an experiment outside the product build (tools/experiments/qp_kernel_v4.hpp, -DMPCMP_WITH_QP4): the library must say so
+        try:
+            M.Solver(_cfgs(M, 4, 3)[0], 1)
+        except M.MpcmpError as e:
+            assert "k_qp4" in str(e)
+            pytest.skip("library built without k_qp4 (the product build)")
     _qp_case(M, 4, 3, 700)
     cfg, ocfg = _cfgs(M, 4, 3)
     from mpc_motion_planner_amd import scenarios
