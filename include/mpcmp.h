@@ -161,8 +161,9 @@ int mpcmp_sample_batch_device(mpcmp_ctx *ctx, int B, const double *d_sol_x, cons
                               const double *d_sol_T, int n_pts, double *d_out, void *hip_stream);
 
 /* ---- jerk-limited, time-synchronised warm start (stands in for Ruckig, mpc_solver/motionPlanner.cpp:146-175) ----
- * Per joint: S-curve velocity transition, cruise, S-curve transition (zero boundary accelerations as in
- * motionPlanner.cpp:27-54); minimum time of the slowest joint, every other joint re-planned to exactly that duration.
+ * Per joint: S-curve velocity transition, cruise, S-curve transition; minimum time of the slowest joint, every other joint
+ * re-planned to exactly that duration.  Boundary accelerations: zero in the plain entry points (every example of the reference),
+ * given in the *_acc_* ones (set_current_state / set_target_state forward them to Ruckig, motionPlanner.cpp:36-38,50-52).
  * Velocity / acceleration limits are the context's margin-applied bounds (mpcmp_set_margins), jmax[7] = margin_jerk *
  * max_jerk (motionPlanner.cpp:86-88).  Outputs in the layout mpcmp_solve_batch takes as warm start: warm_x [B][N][14],
  * warm_u [B][N][7], warm_T [B] (x_guess / u_guess / p_guess, motionPlanner.cpp:158-174). */
@@ -179,6 +180,16 @@ int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *x0, const d
  * its duration, with the RNEA torque: out [B][28] = q(7), qd(7), qdd(7), tau(7); T_out [B] (may be NULL) = the durations. */
 int mpcmp_jerk_point_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, const double *time,
                            double *out, double *T_out);
+/* The three entry points above with boundary accelerations acc0 / accT [B][7] (either may be NULL = zero; with both NULL the result is
+ * the plain entry point's bit for bit).  Single-arm contexts.  The acceleration limit yields to a given boundary acceleration above it. */
+int mpcmp_warm_start_jerk_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                    const double *jmax, double *warm_x, double *warm_u, double *warm_T);
+int mpcmp_warm_start_jerk_acc_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_acc0, const double *d_accT,
+                                           const double *jmax, double *d_warm_x, double *d_warm_u, double *d_warm_T, void *hip_stream);
+int mpcmp_jerk_trajectory_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                    const double *jmax, int n_pts, double *out, double *T_out);
+int mpcmp_jerk_point_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                               const double *jmax, const double *time, double *out, double *T_out);
 /* MotionPlanner::get_MPC_point (motionPlanner.hpp:118-128): the solution at ONE physical time per problem, including the
  * reference's clamp (time >= T: the normalised time becomes T, not 1), with the RNEA torque: out [B][28] as above. */
 int mpcmp_mpc_point_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double *sol_u, const double *sol_T, const double *time,

@@ -372,7 +372,9 @@ class MotionPlanner {
             guess_x_.assign((size_t)14 * N_, 0.0); guess_u_.assign((size_t)7 * N_, 0.0);
             double jm[7];
             jerk_limits(jm);
-            chk(mpcmp_warm_start_jerk_batch(ctx_, 1, current_state.data(), target_state.data(), jm, guess_x_.data(), guess_u_.data(), &guess_T_));
+            // (boundary accelerations as the reference forwards them to Ruckig: input.current_acceleration / target_acceleration, motionPlanner.cpp:36-38,50-52,149)
+            for (int j = 0; j < 7; j++) { guess_a0_[j] = input.current_acceleration[j]; guess_aT_[j] = input.target_acceleration[j]; }
+            chk(mpcmp_warm_start_jerk_acc_batch(ctx_, 1, current_state.data(), target_state.data(), guess_a0_, guess_aT_, jm, guess_x_.data(), guess_u_.data(), &guess_T_));
             guess_is_profile_ = true;
             for (int r = 0; r < 14; r++) { guess_x0_[r] = current_state(r); guess_xf_[r] = target_state(r); }
         } else { guess_x_ = warm_x_; guess_u_ = warm_u_; guess_T_ = warm_T_; guess_is_profile_ = false; }
@@ -404,7 +406,7 @@ class MotionPlanner {
             std::vector<double> tr((size_t)(NP + 1) * 22), q((size_t)(NP + 1) * 7), v(q.size()), a(q.size()), tau(q.size());
             double jm[7];
             jerk_limits(jm);
-            chk(mpcmp_jerk_trajectory_batch(ctx_, 1, guess_x0_, guess_xf_, jm, NP, tr.data(), nullptr));
+            chk(mpcmp_jerk_trajectory_acc_batch(ctx_, 1, guess_x0_, guess_xf_, guess_a0_, guess_aT_, jm, NP, tr.data(), nullptr));
             for (int i = 0; i <= NP; i++)
                 for (int j = 0; j < 7; j++) { q[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 1 + j]; v[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 8 + j]; a[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 15 + j]; }
             chk(mpcmp_rnea_batch(ctx_, NP + 1, q.data(), v.data(), a.data(), tau.data()));
@@ -431,7 +433,7 @@ class MotionPlanner {
     void get_RK_point(double time, Vec7 &position, Vec7 &velocity, Vec7 &acceleration, Vec7 &torque) {
         double o[28], jm[7];
         jerk_limits(jm);
-        chk(mpcmp_jerk_point_batch(ctx_, 1, guess_x0_, guess_xf_, jm, &time, o, nullptr));
+        chk(mpcmp_jerk_point_acc_batch(ctx_, 1, guess_x0_, guess_xf_, guess_a0_, guess_aT_, jm, &time, o, nullptr));
         for (int j = 0; j < 7; j++) { position(j) = o[j]; velocity(j) = o[7 + j]; acceleration(j) = o[14 + j]; torque(j) = o[21 + j]; }
     }
     double solution_T() const { return sol_T_; }
@@ -506,7 +508,7 @@ class MotionPlanner {
     std::vector<double> sol_x_, sol_u_, warm_x_, warm_u_, guess_x_, guess_u_;
     double sol_T_ = 0, warm_T_ = 0, guess_T_ = 0;
     bool guess_is_profile_ = false;                 // the last guess came from the jerk-limited generator
-    double guess_x0_[14] = {0}, guess_xf_[14] = {0};
+    double guess_x0_[14] = {0}, guess_xf_[14] = {0}, guess_a0_[7] = {0}, guess_aT_[7] = {0};      // states and boundary accelerations of the last jerk-limited guess
     void jerk_limits(double *jm) const { for (int j = 0; j < 7; j++) jm[j] = input.max_jerk[j]; }   // motionPlanner.cpp:86-88,149 (margin_jerk * max_jerk unless the caller wrote `input`)
     bool have_warm_ = false;
     uint64_t rng_ = 20240001ull;
@@ -641,7 +643,7 @@ inline void mpcmp_shim::Trajectory::at_time(double time, std::array<double, NDOF
         tmp.ubu[j] = in.max_acceleration[j]; tmp.lbu[j] = -in.max_acceleration[j];
     }
     if (differs) owner->chk(mpcmp_set_config(owner->ctx_, &tmp));
-    const int rc = mpcmp_jerk_point_batch(owner->ctx_, 1, x0, xf, in.max_jerk.data(), &time, o, &T);
+    const int rc = mpcmp_jerk_point_acc_batch(owner->ctx_, 1, x0, xf, in.current_acceleration.data(), in.target_acceleration.data(), in.max_jerk.data(), &time, o, &T);
     if (differs) owner->chk(mpcmp_set_config(owner->ctx_, &keep));
     owner->chk(rc);
     duration = T;

@@ -54,7 +54,8 @@ SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_models_from_ur
            "mpcmp_kernel_timing", "mpcmp_debug_stamps", "mpcmp_rh_init", "mpcmp_rh_run", "mpcmp_rh_get", "mpcmp_traj_stats_batch",
            "mpcmp_tool_jacobian", "mpcmp_forward_velocities", "mpcmp_inverse_velocities", "mpcmp_inverse_kinematics",
            "mpcmp_warm_start_jerk_batch", "mpcmp_warm_start_jerk_batch_device", "mpcmp_jerk_trajectory_batch",
-           "mpcmp_jerk_point_batch", "mpcmp_mpc_point_batch", "mpcmp_debug_fetch"]
+           "mpcmp_jerk_point_batch", "mpcmp_mpc_point_batch", "mpcmp_debug_fetch",
+           "mpcmp_warm_start_jerk_acc_batch", "mpcmp_warm_start_jerk_acc_batch_device", "mpcmp_jerk_trajectory_acc_batch", "mpcmp_jerk_point_acc_batch"]
 
 
 def library_path():

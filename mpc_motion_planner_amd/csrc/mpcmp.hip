@@ -1059,9 +1059,11 @@ static int jerk_limits(mpcmp_ctx *ctx, const double *jmax, JerkLimits &lim) {
     return MPCMP_OK;
 }
 
-extern "C" int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *jmax,
-                                                  double *d_wx, double *d_wu, double *d_wT, void *hip_stream) {
+// boundary accelerations d_acc0 / d_accT: device [B][7], either may be NULL (= zero); single-arm contexts only (a multi-arm warm start has none)
+extern "C" int mpcmp_warm_start_jerk_acc_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_acc0, const double *d_accT,
+                                                      const double *jmax, double *d_wx, double *d_wu, double *d_wT, void *hip_stream) {
     if (!ctx || !d_x0 || !d_xf || !jmax || !d_wx || !d_wu || !d_wT || B < 1) return MPCMP_EINVAL;
+    if ((d_acc0 || d_accT) && ctx->narm != 1) { ctx->err = "boundary accelerations: single-arm contexts only"; return MPCMP_EINVAL; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     JerkLimits lim;
     if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
@@ -1072,20 +1074,36 @@ extern "C" int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const d
         const int cnt = B * 2 * 14;
         hipLaunchKernelGGL((k_split_states<2>), dim3((cnt + 255) / 256), dim3(256), 0, s2, B, d_x0, ctx->d_ax0);
         hipLaunchKernelGGL((k_split_states<2>), dim3((cnt + 255) / 256), dim3(256), 0, s2, B, d_xf, ctx->d_axf);
-        hipLaunchKernelGGL(k_warm_jerk, dim3(B * 2), dim3(64), 0, s2, ctx->nseg, lim, ctx->d_ax0, ctx->d_axf, ctx->d_awx, ctx->d_awu, ctx->d_awT);
+        hipLaunchKernelGGL(k_warm_jerk, dim3(B * 2), dim3(64), 0, s2, ctx->nseg, lim, ctx->d_ax0, ctx->d_axf, (const double *)nullptr, (const double *)nullptr, ctx->d_awx, ctx->d_awu, ctx->d_awT);
         hipLaunchKernelGGL((k_warm_merge<2>), dim3(B), dim3(256), 0, s2, ctx->N, B, ctx->d_awx, ctx->d_awu, ctx->d_awT, d_x0, d_xf, d_wx, d_wu, d_wT);
         HIPCHK(ctx, hipGetLastError());
         return MPCMP_OK;
     }
     // the stream exactly as given (NULL = the legacy default stream), like the other *_device entry points: the solve that
     // consumes the warm start is enqueued on the same stream and is ordered behind this launch
-    hipLaunchKernelGGL(k_warm_jerk, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, ctx->nseg, lim, d_x0, d_xf, d_wx, d_wu, d_wT);
+    hipLaunchKernelGGL(k_warm_jerk, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, ctx->nseg, lim, d_x0, d_xf, d_acc0, d_accT, d_wx, d_wu, d_wT);
     HIPCHK(ctx, hipGetLastError());
     return MPCMP_OK;
 }
+extern "C" int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *jmax,
+                                                  double *d_wx, double *d_wu, double *d_wT, void *hip_stream) {
+    return mpcmp_warm_start_jerk_acc_batch_device(ctx, B, d_x0, d_xf, nullptr, nullptr, jmax, d_wx, d_wu, d_wT, hip_stream);
+}
 
-extern "C" int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax,
-                                           double *wx, double *wu, double *wT) {
+// host [B][7] boundary accelerations (either may be NULL) staged next to the states; returns the device pointers (or NULL)
+static int stage_acc(mpcmp_ctx *ctx, TmpBuf &tb, int B, const double *acc0, const double *accT, hipStream_t st, const double **d0, const double **dT) {
+    *d0 = *dT = nullptr;
+    if (!acc0 && !accT) return MPCMP_OK;
+    if (ctx->narm != 1) { ctx->err = "boundary accelerations: single-arm contexts only"; return MPCMP_EINVAL; }
+    double *buf = tb.get<double>(14 * (size_t)B);
+    if (!buf) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
+    if (acc0) { HIPCHK(ctx, hipMemcpyAsync(buf, acc0, sizeof(double) * 7 * B, hipMemcpyHostToDevice, st)); *d0 = buf; }
+    if (accT) { HIPCHK(ctx, hipMemcpyAsync(buf + 7 * (size_t)B, accT, sizeof(double) * 7 * B, hipMemcpyHostToDevice, st)); *dT = buf + 7 * (size_t)B; }
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_warm_start_jerk_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                               const double *jmax, double *wx, double *wu, double *wT) {
     if (!ctx || !x0 || !xf || !jmax || !wx || !wu || !wT || B < 1) return MPCMP_EINVAL;
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1093,7 +1111,10 @@ extern "C" int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * nx * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * nx * B, hipMemcpyHostToDevice, st));
-    if (int rc = mpcmp_warm_start_jerk_batch_device(ctx, B, ctx->d_x0, ctx->d_xf, jmax, ctx->d_wx, ctx->d_wu, ctx->d_wT, st)) return rc;
+    TmpBuf tb(ctx, (acc0 || accT) ? 14 * (size_t)B * sizeof(double) : 0);
+    const double *da0, *daT;
+    if (int rc = stage_acc(ctx, tb, B, acc0, accT, st, &da0, &daT)) return rc;
+    if (int rc = mpcmp_warm_start_jerk_acc_batch_device(ctx, B, ctx->d_x0, ctx->d_xf, da0, daT, jmax, ctx->d_wx, ctx->d_wu, ctx->d_wT, st)) return rc;
     HIPCHK(ctx, hipMemcpyAsync(wx, ctx->d_wx, sizeof(double) * nx * N * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(wu, ctx->d_wu, sizeof(double) * nu * N * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(wT, ctx->d_wT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
@@ -1101,8 +1122,13 @@ extern "C" int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *
     return MPCMP_OK;
 }
 
-extern "C" int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, int n_pts,
-                                           double *out, double *T_out) {
+extern "C" int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax,
+                                           double *wx, double *wu, double *wT) {
+    return mpcmp_warm_start_jerk_acc_batch(ctx, B, x0, xf, nullptr, nullptr, jmax, wx, wu, wT);
+}
+
+extern "C" int mpcmp_jerk_trajectory_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                               const double *jmax, int n_pts, double *out, double *T_out) {
     if (!ctx || !x0 || !xf || !jmax || !out || B < 1 || n_pts < 1) return MPCMP_EINVAL;
     SINGLE_ARM_ONLY(ctx);
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
@@ -1110,13 +1136,15 @@ extern "C" int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *
     JerkLimits lim;
     if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
     const size_t cnt = (size_t)B * (n_pts + 1) * 22;
-    TmpBuf tb(ctx, cnt * sizeof(double));
+    TmpBuf tb(ctx, (cnt + 14 * (size_t)B) * sizeof(double));
     double *dout = tb.get<double>(cnt);
     if (!dout) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_jerk_traj, dim3(B), dim3(64), 0, st, lim, ctx->d_x0, ctx->d_xf, n_pts, dout, ctx->d_wT);
+    const double *da0, *daT;
+    if (int rc = stage_acc(ctx, tb, B, acc0, accT, st, &da0, &daT)) return rc;
+    hipLaunchKernelGGL(k_jerk_traj, dim3(B), dim3(64), 0, st, lim, ctx->d_x0, ctx->d_xf, da0, daT, n_pts, dout, ctx->d_wT);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out, dout, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
     if (T_out) HIPCHK(ctx, hipMemcpyAsync(T_out, ctx->d_wT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
@@ -1124,28 +1152,40 @@ extern "C" int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *
     return MPCMP_OK;
 }
 
+extern "C" int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, int n_pts,
+                                           double *out, double *T_out) {
+    return mpcmp_jerk_trajectory_acc_batch(ctx, B, x0, xf, nullptr, nullptr, jmax, n_pts, out, T_out);
+}
+
 // MotionPlanner::get_RK_point (motionPlanner.hpp:130-142)
-extern "C" int mpcmp_jerk_point_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, const double *time,
-                                      double *out, double *T_out) {
+extern "C" int mpcmp_jerk_point_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                          const double *jmax, const double *time, double *out, double *T_out) {
     if (!ctx || !x0 || !xf || !jmax || !time || !out || B < 1) return MPCMP_EINVAL;
     SINGLE_ARM_ONLY(ctx);
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     JerkLimits lim;
     if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
-    TmpBuf tb(ctx, 29 * (size_t)B * sizeof(double));
+    TmpBuf tb(ctx, (29 + 14) * (size_t)B * sizeof(double));
     double *dt = tb.get<double>(B), *dout = tb.get<double>(28 * (size_t)B);
     if (!dt || !dout) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(dt, time, sizeof(double) * B, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_jerk_point, dim3(B), dim3(64), 0, st, ctx->d_model, lim, ctx->d_x0, ctx->d_xf, dt, dout, ctx->d_wT);
+    const double *da0, *daT;
+    if (int rc = stage_acc(ctx, tb, B, acc0, accT, st, &da0, &daT)) return rc;
+    hipLaunchKernelGGL(k_jerk_point, dim3(B), dim3(64), 0, st, ctx->d_model, lim, ctx->d_x0, ctx->d_xf, da0, daT, dt, dout, ctx->d_wT);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out, dout, sizeof(double) * 28 * B, hipMemcpyDeviceToHost, st));
     if (T_out) HIPCHK(ctx, hipMemcpyAsync(T_out, ctx->d_wT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return MPCMP_OK;
+}
+
+extern "C" int mpcmp_jerk_point_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, const double *time,
+                                      double *out, double *T_out) {
+    return mpcmp_jerk_point_acc_batch(ctx, B, x0, xf, nullptr, nullptr, jmax, time, out, T_out);
 }
 
 // MotionPlanner::get_MPC_point (motionPlanner.hpp:118-128)

@@ -117,6 +117,11 @@ void orc_warm_start_jerk(int num_seg, const double *vmax, const double *amax, co
 /* out (n_pts+1) x 22 = t, q(7), v(7), a(7): get_ruckig_trajectory (motionPlanner.hpp:73-96) */
 void orc_jerk_trajectory(const double *vmax, const double *amax, const double *jmax, const double *x0, const double *xf, int n_pts,
                          double *out, double *T_out);
+/* the same with boundary accelerations acc0 / accT [7] (NULL = zero), as the reference forwards them to Ruckig (motionPlanner.cpp:36-38,50-52) */
+void orc_warm_start_jerk_acc(int num_seg, const double *vmax, const double *amax, const double *jmax, const double *x0, const double *xf,
+                             const double *acc0, const double *accT, double *xg, double *ug, double *Tg);
+void orc_jerk_trajectory_acc(const double *vmax, const double *amax, const double *jmax, const double *x0, const double *xf,
+                             const double *acc0, const double *accT, int n_pts, double *out, double *T_out);
 
 /* ---- the hot path: one OCP ---- */
 /* z layout: xs[N][14], us[N][7], T.  lam (optional, size m_eq+m_in+n) receives final multipliers */

@@ -132,20 +132,24 @@ def warm_start(cfg, x0, xf, amax_used=None):
     return xg, ug, T.value
 
 
-def warm_start_jerk(num_seg, vmax, amax, jmax, x0, xf):
-    """jerk-limited time-synchronised warm start (oracle/jerk.c): node states, node controls, duration"""
+def warm_start_jerk(num_seg, vmax, amax, jmax, x0, xf, acc0=None, accT=None):
+    """jerk-limited time-synchronised warm start (oracle/jerk.c): node states, node controls, duration; acc0 / accT: boundary accelerations [7]"""
     N = 3 * num_seg + 1
     vmax, amax, jmax, x0, xf = f64(vmax), f64(amax), f64(jmax), f64(x0), f64(xf)
+    a0 = f64(acc0) if acc0 is not None else None; aT = f64(accT) if accT is not None else None
     xg, ug, T = np.zeros((N, 14)), np.zeros((N, 7)), C.c_double(0)
-    lib().orc_warm_start_jerk(int(num_seg), _p(vmax), _p(amax), _p(jmax), _p(x0), _p(xf), _p(xg), _p(ug), C.byref(T))
+    lib().orc_warm_start_jerk_acc(int(num_seg), _p(vmax), _p(amax), _p(jmax), _p(x0), _p(xf), _p(a0) if a0 is not None else None,
+                                  _p(aT) if aT is not None else None, _p(xg), _p(ug), C.byref(T))
     return xg, ug, T.value
 
 
-def jerk_trajectory(vmax, amax, jmax, x0, xf, n_pts=200):
+def jerk_trajectory(vmax, amax, jmax, x0, xf, n_pts=200, acc0=None, accT=None):
     """uniform samples (n_pts+1) x 22 = t, q, v, a of the same trajectory, and its duration"""
     vmax, amax, jmax, x0, xf = f64(vmax), f64(amax), f64(jmax), f64(x0), f64(xf)
+    a0 = f64(acc0) if acc0 is not None else None; aT = f64(accT) if accT is not None else None
     out, T = np.zeros((n_pts + 1, 22)), C.c_double(0)
-    lib().orc_jerk_trajectory(_p(vmax), _p(amax), _p(jmax), _p(x0), _p(xf), int(n_pts), _p(out), C.byref(T))
+    lib().orc_jerk_trajectory_acc(_p(vmax), _p(amax), _p(jmax), _p(x0), _p(xf), _p(a0) if a0 is not None else None,
+                                  _p(aT) if aT is not None else None, int(n_pts), _p(out), C.byref(T))
     return out, T.value
 
 

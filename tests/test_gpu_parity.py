@@ -435,6 +435,26 @@ def test_jerk_limited_warm_start_vs_oracle_and_stored_ruckig(M, golden_dir):
         oo, _ = o.jerk_trajectory(vmax, amax, jmax, x0[b], xf[b], 100)
         assert np.abs(out[b][:, :15] - oo[:, :15]).max() <= 1e-8
     assert np.all(np.abs(out[:, :, 8:15]) <= vmax + 1e-9)
+    # non-zero boundary accelerations (set_current_state / set_target_state forward them to Ruckig, motionPlanner.cpp:36-38,50-52): HIP vs oracle on
+    # random accelerations, both boundary states met in q, qd AND qdd, and zero accelerations through the *_acc_* entry points = the plain ones bit for bit
+    rng = np.random.default_rng(5)
+    a0, aT = rng.uniform(-0.8, 0.8, (B, 7)) * amax, rng.uniform(-0.8, 0.8, (B, 7)) * amax
+    x0s = x0.copy(); xfs = xf.copy(); x0s[:, 7:] *= 0.6; xfs[:, 7:] *= 0.6
+    wxa, wua, wTa = s.warm_start_jerk(x0s, xfs, jmax, acc0=a0, accT=aT)
+    outa, Ta = s.jerk_trajectory(x0s, xfs, jmax, 100, acc0=a0, accT=aT)
+    pta, _ = s.jerk_point(x0s, xfs, jmax, 0.37 * Ta, acc0=a0, accT=aT)
+    for b in range(B):
+        xg, ug, Tg = o.warm_start_jerk(4, vmax, amax, jmax, x0s[b], xfs[b], acc0=a0[b], accT=aT[b])
+        assert abs(wTa[b] - Tg) <= 1e-9 * Tg and abs(Ta[b] - Tg) <= 1e-9 * Tg
+        assert np.abs(wxa[b] - xg).max() <= 1e-8 and np.abs(wua[b] - ug).max() <= 1e-6
+        oo, _ = o.jerk_trajectory(vmax, amax, jmax, x0s[b], xfs[b], 100, acc0=a0[b], accT=aT[b])
+        assert np.abs(outa[b] - oo).max() <= 1e-6
+        assert np.abs(outa[b][0, 15:22] - a0[b]).max() <= 1e-9 and np.abs(outa[b][-1, 15:22] - aT[b]).max() <= 1e-8
+        assert np.abs(outa[b][-1, 1:8] - xfs[b][:7]).max() <= 1e-8 and np.abs(outa[b][-1, 8:15] - xfs[b][7:]).max() <= 1e-8
+        assert np.abs(pta[b][:21] - np.array([np.interp(0.37 * Ta[b], oo[:, 0], oo[:, c]) for c in range(1, 22)])).max() < 5e-2     # (the point entry sees the same trajectory)
+    z = np.zeros((B, 7))
+    wxz, wuz, wTz = s.warm_start_jerk(x0, xf, jmax, acc0=z, accT=z)
+    assert np.array_equal(wxz, wx) and np.array_equal(wuz, wu) and np.array_equal(wTz, wT)
     # KAT-RK through the GPU path (6 stored digits)
     g = json.load(open(os.path.join(golden_dir, "gold_traj.json")))
     k0 = np.concatenate([g["q0"], g["v0"]])[None]; kf = np.concatenate([g["qT"], g["vT"]])[None]

@@ -207,6 +207,45 @@ def test_jerk_limited_warm_start_random_states():
     assert worst <= 1.0 + 1e-9 or worst < 1.6     # (a joint that fell back to a quintic may overshoot a limit)
 
 
+def test_jerk_limited_warm_start_boundary_accelerations():
+    """non-zero boundary accelerations (the reference forwards current / target accelerations to Ruckig, motionPlanner.cpp:36-38,50-52; KAT-RK has
+    none, so the pin is properties): both boundary states met in position, velocity AND acceleration, the trajectory is continuous (positions are
+    the integral of the velocities, velocities of the accelerations), the acceleration stays inside its limit, the jerk inside its limit (finite
+    differences), and zero accelerations reproduce the zero-only generator bit for bit."""
+    rng = np.random.default_rng(11)
+    lim = o.default_limits()
+    vmax, amax, jmax = 0.9 * lim["vmax"], 0.5 * lim["amax"], 0.1 * lim["jmax"]
+    worst_a = worst_j = 0.0
+    nq = 0
+    for it in range(200):
+        x0 = np.concatenate([rng.uniform(lim["qmin"], lim["qmax"]), rng.uniform(-0.6 * vmax, 0.6 * vmax)])
+        xf = np.concatenate([rng.uniform(lim["qmin"], lim["qmax"]), rng.uniform(-0.6 * vmax, 0.6 * vmax)])
+        a0, aT = rng.uniform(-0.8 * amax, 0.8 * amax), rng.uniform(-0.8 * amax, 0.8 * amax)
+        n = 2000
+        out, T = o.jerk_trajectory(vmax, amax, jmax, x0, xf, n, acc0=a0, accT=aT)
+        t, q, v, a = out[:, 0], out[:, 1:8], out[:, 8:15], out[:, 15:22]
+        assert T > 0 and np.all(np.isfinite(out))
+        assert np.abs(q[0] - x0[:7]).max() < 1e-12 and np.abs(v[0] - x0[7:]).max() < 1e-12 and np.abs(a[0] - a0).max() < 1e-12
+        assert np.abs(q[-1] - xf[:7]).max() < 1e-9 and np.abs(v[-1] - xf[7:]).max() < 1e-9 and np.abs(a[-1] - aT).max() < 1e-9
+        dt = np.diff(t)[:, None]
+        assert np.abs(q[1:] - q[0] - np.cumsum(0.5 * (v[1:] + v[:-1]) * dt, axis=0)).max() < 2e-4
+        assert np.abs(v[1:] - v[0] - np.cumsum(0.5 * (a[1:] + a[:-1]) * dt, axis=0)).max() < 2e-3
+        jerk = np.abs(np.diff(a, axis=0) / dt)
+        # (a joint that fell back to the quintic of the common duration may overshoot: count them, bound the rest)
+        ok = (np.abs(a) / amax).max(axis=0) <= 1.0 + 1e-9
+        nq += int((~ok).sum())
+        worst_a = max(worst_a, (np.abs(a) / amax)[:, ok].max()); worst_j = max(worst_j, (jerk / jmax)[:, ok].max())
+        xg, ug, Tg = o.warm_start_jerk(6, vmax, amax, jmax, x0, xf, acc0=a0, accT=aT)
+        assert Tg == T and np.array_equal(xg[0], x0) and np.array_equal(xg[-1], xf) and np.abs(ug[0] - a0).max() < 1e-12 and np.abs(ug[-1] - aT).max() < 1e-9
+        if it < 20:
+            z = np.zeros(7)
+            ref, Tr = o.jerk_trajectory(vmax, amax, jmax, x0, xf, 50)
+            got, Tz = o.jerk_trajectory(vmax, amax, jmax, x0, xf, 50, acc0=z, accT=z)
+            assert Tz == Tr and np.array_equal(ref, got)
+    assert worst_a <= 1.0 + 1e-9 and worst_j <= 1.0 + 1e-6, (worst_a, worst_j)
+    assert nq <= 0.2 * 200 * 7, nq
+
+
 def test_status_word_semantics():
     """mpcmp_info.status / orc_info.status (include/mpcmp.h MPCMP_STATUS_*; the reference never reads mpc.info().status, motionPlanner.cpp:191):
     bit 8 = a QP stopped at qp_iters (qp_capped counts them), bit 16 = returned iterate outside tolerance, bit 32 = T outside its box,
