@@ -69,6 +69,12 @@ typedef struct {
     double lbu[7], ubu[7];   /* mpc.control_bounds,     motionPlanner.cpp:73    */
     double lbg[8], ubg[8];   /* mpc.constraints_bounds, motionPlanner.cpp:92-98 */
     double lbT, ubT;         /* mpc.parameters_bounds,  motionPlanner.cpp:76-79 */
+    /* QP start of the SQP iterations after the first (the build's choice: polympc is absent).  0 (default) = every QP starts cold,
+     * x = z = y = 0; 1 = warm duals: y_0 = the NLP multipliers lambda_k, x_0 = 0, z_0 = clip(0, l, u).  On the headline batch the warm start
+     * nearly halves the ADMM iterations per trajectory with better feasibility; the stored reference solve is ONE SQP iteration
+     * and cannot tell the two apart. */
+    int    qp_warm_start;
+    int    reserved_;
 } mpcmp_config;
 
 /* Per-problem result record; replaces mpc.info() (never read by the reference, motionPlanner.cpp:191). */

@@ -28,7 +28,8 @@ class Config(C.Structure):
                 ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("rho_eq_scale", C.c_double),
                 ("ls_eta", C.c_double), ("ls_tau", C.c_double), ("hess_reg", C.c_double), ("eps_target", C.c_double),
                 ("lbx", C.c_double * 14), ("ubx", C.c_double * 14), ("lbu", C.c_double * 7), ("ubu", C.c_double * 7),
-                ("lbg", C.c_double * 8), ("ubg", C.c_double * 8), ("lbT", C.c_double), ("ubT", C.c_double)]
+                ("lbg", C.c_double * 8), ("ubg", C.c_double * 8), ("lbT", C.c_double), ("ubT", C.c_double),
+                ("qp_warm_start", C.c_int), ("reserved_", C.c_int)]
 
 
 class Info(C.Structure):

@@ -309,6 +309,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     const double *xa = part == 0 ? xn0 : part == 1 ? xn0 + 8 : part == 2 ? xn1 + 2 : xn1 + 10;
     const double *xc3 = part == 3 ? xn1 + 20 : xa + 4;
     const double *xb = part == 0 ? xn0 + 6 : part == 1 ? xn1 : part == 2 ? xn1 + 8 : xn1 + 20;
+    if (cfg.qp_warm_start) __syncthreads();          // (warm duals: roles A2 and B publish w_0 = rho z_0 - y_0)
     int it = 0, done = 0, until_check = cfg.check_every;
     BUSY_DECL;
     STAMP2(12);                 // role prologue: register blocks fetched from the factor scratch, constants published
@@ -510,6 +511,18 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
     __syncthreads();          // constants published (matches the barrier of the other roles)
     const double alpha = c.alpha;
     const double *bj = rhsJ + 56 * seg + 14 * part;
+    if (cfg.qp_warm_start) {     // warm duals (mpcmp_config.qp_warm_start): y_0 = lambda_k, z_0 = clip(0, l, u); the node's path-row part of A^T w_0
+        if (ownsRow) { yg = c.ws.lam[(size_t)b * D::mn + myrow]; zg = clip(0.0, pcl[0], pcl[L::NA2]); }
+        if (isPath) {
+            D2 q0[3], q1[3];
+            const double *g0 = gkl + groff + (pq & 1) * GS, *g1 = gkl + groff + (1 - (pq & 1)) * GS;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { q0[j] = lds2(g0 + 2 * j); q1[j] = lds2(g1 + 2 * j); }
+            const double w0_ = ownsRow ? pcl[2 * L::NA2] * zg - yg : 0.0;
+            path_rows(q0, q1, xn, lds + L::oGp, [&](double) -> double { return w0_; });
+        }
+        __syncthreads();
+    }
     int it = 0, done = 0, until_check = cfg.check_every;
     BUSY_DECL;
     for (it = 1; it <= cfg.qp_iters; it++) {
@@ -736,6 +749,12 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     };
     const double alpha = c.alpha, sigma = c.sigma, rho_eq = c.rho_eq;
     double x = 0, zb = 0, yb = 0;
+    if (cfg.qp_warm_start) {     // warm duals: y_0 = lambda_k, x_0 = 0, z_0 = clip(0, l, u); w_0 of the dynamics rows
+        const double *lamb = c.ws.lam + (size_t)b * D::mn;
+        if (isVar) { yb = lamb[m + u]; zb = clip(0.0, vcl[10 * L::NB], vcl[11 * L::NB]); }
+        if (isDyn) { ygd = lamb[u]; zgd = lgd; const double w = rho_eq * lgd - ygd; wg[u] = w; tpl[u] = rcT * w; }
+        __syncthreads();
+    }
     int it = 0, done = 0, until_check = cfg.check_every;
     BUSY_DECL;
     for (it = 1; it <= cfg.qp_iters; it++) {

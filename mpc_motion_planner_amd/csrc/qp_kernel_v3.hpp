@@ -1305,6 +1305,37 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     for (int k = 0; k < 8; k++) st_acc[k] = st_busy[k] = 0;
     QS(6);
 #endif
+    if (cfg.qp_warm_start) {     // warm duals (mpcmp_config.qp_warm_start): y_0 = lambda_k, x_0 = 0, z_0 = clip(0, l, u); w_0 = rho z_0 - y_0 published
+        const double *lam_vars = ws.lam + (size_t)b * mn_tot + NARM * ma + arm * na;
+        double tp = 0.0;
+#pragma unroll
+        for (int h = 0; h < NR; h++) {
+            if (tid + 512 * h < ma) {
+                const int r = row_of(tid + 512 * h);
+                const double rr = (dr[h] >> 21) & 1u ? rho_eq : rho_in, yg = lam_rows[r], zg = clip(0.0, lds[L::oLg + r], lds[L::oUg + r]);
+                const double w = rr * zg - yg;
+                wg[w_slot(dr[h], r)] = w;
+                tp += lds[L::oCf + r] * w;
+                if (h) { s1zg[tid] = zg; s1yg[tid] = yg; } else if (L::STL) { stg[tid] = zg; sth[tid] = yg; } else { zg0 = zg; yg0 = yg; }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NV; h++) {
+            const int v = tid + 512 * h;
+            if (v < na) {
+                const double yb = lam_vars[v], zb = clip(0.0, lds[L::oLb + v], lds[L::oUb + v]);
+                if (h) { s1z[tid] = zb; s1y[tid] = yb; } else if (L::STL) { stz[tid] = zb; sty[tid] = yb; } else { zb0 = zb; yb0 = yb; }
+            }
+        }
+        if (L::P8) { tp = sum8(tp); redT[8 * wave + (lane >> 3)] = tp; }
+        else { tp = wave_sum(tp); if (lane == 0) redT[wave] = tp; }
+        if (tid == 511) {       // the shared variable T (replicated in the arm workgroups of the OCP, identical arithmetic)
+            const double yT = ws.lam[(size_t)b * mn_tot + mn_tot - 1], zT = clip(0.0, misc[L::M_lbT], misc[L::M_ubT]);
+            misc[L::M_zbT] = zT; misc[L::M_ybT] = yT;
+            misc[L::M_baseT] = -1.0 + (misc[L::M_rbT] * zT - yT);
+        }
+        __syncthreads();
+    }
     // The hot loop is the INNER loop (one termination-test period): it contains nothing but the five phases; the test itself
     // sits in the outer loop.
     int it = 0, done = 0, nchk = 0;

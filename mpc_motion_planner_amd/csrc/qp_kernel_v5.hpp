@@ -478,6 +478,38 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
         asm volatile("" : "+v"(t));
         pxr = q5_l5<NSEG>(c, t & 63, 0); prf = q5_l5<NSEG>(c, t & 63, 1); prb = q5_l5<NSEG>(c, t & 63, 2);
     }
+    const bool warm = cfg.qp_warm_start != 0;
+    if (warm) {     // warm duals (mpcmp_config.qp_warm_start): y_0 = lambda_k, x_0 = 0, z_0 = clip(0, l, u); w_0 = rho z_0 - y_0 published
+        const double *lamb = c.ws.lam + (size_t)c.b * (D::ma + na + 1);
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        if (isPath) {
+            const int gro = q5_lc<NSEG>(c, t, 4), xno = q5_lc<NSEG>(c, t, 5);
+            if (ownsRow) yg = lamb[D::meq + 8 * (tid >> 4) + 2 * ((tid & 15) >> 2) + (tid & 3)];
+            q5_path_rows<NSEG>(lds, gro, xno, t, lds + L::vXn, lds + L::vGp, [&](double, const PathOp5 &po) -> double {
+                if (ownsRow) zg = clip(0.0, po.lgp, po.ugp);
+                return ownsRow ? po.rr * zg - yg : 0.0;
+            });
+        }
+        if (laneD) {
+            const int r = L::DR0 + (t - L::tV5);
+            const double lgd = lds[L::vRc + r], rcT = lds[L::vRc + L::NRC + r];
+            yg = lamb[r];
+            const double w = rho_eq * lgd - yg;
+            lds[L::vWg + r] = w;
+            const double tp = sum8(rcT * w);
+            lds[L::vRedT + (r >> 3)] = tp;
+        }
+        if (laneV) {
+            const int vi = L::NG + (t - L::tV5);
+            double *vst = lds + L::vVst + (t - L::tV5);
+            const double *vcl = lds + L::vVc + vi;
+            const double vzb = clip(0.0, vcl[1 * L::NVL], vcl[2 * L::NVL]), vyb = lamb[D::ma + vi], rb = vcl[4 * L::NVL];
+            vst[16] = vzb; vst[32] = vyb;
+            if (vi == na) { misc[L::M_zbT] = vzb; misc[L::M_ybT] = vyb; misc[L::M_baseT] = -1.0 + (rb * vzb - vyb); }
+        }
+        __syncthreads();
+    }
     for (it = 1; it <= cfg.qp_iters; it++) {
         int sio = tid;
         asm volatile("" : "+v"(sio));
@@ -524,7 +556,7 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
                 const double *rcl = lds + L::vRc + r;
                 const double lgd = ldv(rcl), rcT = ldv(rcl + L::NRC);
                 const double zt = row_dot_dyn(lds + L::vXn, q5_l5<NSEG>(c, sio & 63, 3), L::oCD + 4 * ((prb >> 17) & 3), rcT);
-                const double zr = alpha * zt + c.oma * (it > 1 ? lgd : 0.0);
+                const double zr = alpha * zt + c.oma * ((it > 1 || warm) ? lgd : 0.0);
                 yg += rho_eq * (zr - lgd);                  // the row is an equality: the projection of anything onto [l, l] is l
                 const double w = rho_eq * lgd - yg;
                 lds[L::vWg + r] = w;
@@ -682,6 +714,21 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
         asm volatile("" : "+v"(t));
         apx = q5_lc<NSEG>(c, t, 2); apf = q5_lc<NSEG>(c, t, 3); apb = q5_lc<NSEG>(c, t, 4);
     }
+    const bool warm = cfg.qp_warm_start != 0;
+    if (warm) {     // warm duals (mpcmp_config.qp_warm_start): y_0 = lambda_k, x_0 = 0, z_0 = clip(0, l, u); w_0 of the dynamics rows published
+        const double *lamb = c.ws.lam + (size_t)c.b * (D::ma + D::na + 1);
+        const double *vcl = lds + L::vVc + vi0;
+        vyb = lamb[D::ma + vi0]; vzb = clip(0.0, vcl[1 * L::NVL], vcl[2 * L::NVL]);
+        if (isDyn) {
+            const double lgd = lds[L::vRc + vi0], rcT = lds[L::vRc + L::NRC + vi0];
+            ygd = lamb[vi0];
+            const double w = rho_eq * lgd - ygd;
+            lds[L::vWg + vi0] = w;
+            const double tp = sum8(rcT * w);
+            lds[L::vRedT + (vi0 >> 3)] = tp;
+        }
+        __syncthreads();
+    }
     for (it = 1; it <= cfg.qp_iters; it++) {
         int sio = tid;
         asm volatile("" : "+v"(sio));
@@ -719,7 +766,7 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
             if (isDyn) {
                 const double lgd = ldv(rcl), rcT = ldv(rcl + L::NRC);
                 const double zt = row_dot_dyn(lds + L::vXn, eix, L::oCD + 4 * ((epb >> 17) & 3), rcT);
-                const double zr = alpha * zt + c.oma * (it > 1 ? lgd : 0.0);
+                const double zr = alpha * zt + c.oma * ((it > 1 || warm) ? lgd : 0.0);
                 ygd += rho_eq * (zr - lgd);                 // the row is an equality: the projection of anything onto [l, l] is l
                 const double w = rho_eq * lgd - ygd;
                 lds[L::vWg + vi] = w;

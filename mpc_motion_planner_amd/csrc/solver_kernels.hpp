@@ -559,6 +559,17 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
     const int ext_my = (tid < nJ) ? ws.ext_of_int[tid] : 0;                       // P3 role
     const int ext_if = ((tid >> 2) < nI) ? ws.ext_of_int[nJ + (tid >> 2)] : 0;    // P2 role
     if (isRow) wg[tid] = 0.0;
+    if (cfg.qp_warm_start) {     // warm duals (mpcmp_config.qp_warm_start): y_0 = lambda_k, x_0 = 0, z_0 = clip(0, l, u); w_0 = rho z_0 - y_0
+        const double *lamb = ws.lam + (size_t)b * D::mn;
+        double tp0 = 0.0;
+        if (isRow) { yg = lamb[tid]; zg = clip(0.0, lg, ug); const double w = rr_ * zg - yg; wg[tid] = w; tp0 = coefT * w; }
+        if (isVar) { yb = lamb[m + tid]; zb = clip(0.0, lb, ub); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tp0 += __shfl_xor(tp0, o);
+        if ((tid & 63) == 0) red[tid >> 6] = tp0;
+        __syncthreads();
+        if (isT) { double sT0 = 0.0; for (int w = 0; w < D::NW; w++) sT0 += red[w]; tsum = sT0; }
+    }
     __syncthreads();
     int it = 0, done = 0;
     for (it = 1; it <= cfg.qp_iters; it++) {

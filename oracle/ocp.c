@@ -369,13 +369,16 @@ static void H_mul(const work *w, const double *x, double *out) {
 static double inf_norm(const double *v, int n) { double s = 0; for (int i = 0; i < n; i++) { double a = fabs(v[i]); if (a > s) s = a; } return s; }
 
 /* box-ADMM in OSQP form on the stacked constraint [A; I], reduced KKT. cold start. */
-static int admm(const orc_config *c, work *w, double *x, double *y, int *status) {
+/* lam0: the NLP multipliers (rows, then variables) the QP's duals start from when c->qp_warm_start is set; NULL or flag 0: cold start */
+static int admm(const orc_config *c, work *w, double *x, double *y, int *status, const double *lam0) {
     int n = w->n, m = w->m, mn = m + n;
     double *zz = (double *)calloc(mn, sizeof(double)), *xt = (double *)calloc(n, sizeof(double));
     double *rhs = (double *)calloc(n, sizeof(double)), *zt = (double *)calloc(mn, sizeof(double));
     double *tmp = (double *)calloc(n, sizeof(double)), *wv = (double *)calloc(mn, sizeof(double));
     double *t1 = (double *)calloc(mn, sizeof(double)), *t2 = (double *)calloc(n, sizeof(double));
     memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * mn);
+    if (lam0 && c->qp_warm_start)         /* warm duals: y_0 = lambda_k, x_0 = 0, z_0 = clip([A; I] x_0, l, u) */
+        for (int i = 0; i < mn; i++) { y[i] = lam0[i]; zz[i] = 0.0 < w->l[i] ? w->l[i] : (0.0 > w->u[i] ? w->u[i] : 0.0); }
     const double sigma = c->sigma, alpha = c->alpha;
     int it = 0;
     double rho_cur = c->rho;
@@ -461,7 +464,7 @@ void orc_solve_multi(const orc_model *mdl, int narm, const orc_config *c, const 
     linearise(mdl, c, w, z, lam);
     for (int it = 0; it < c->sqp_iters; it++) {
         int st;
-        inf.qp_iters_total += admm(c, w, p, y, &st);
+        inf.qp_iters_total += admm(c, w, p, y, &st, lam);
         if (st) inf.status |= st;
         if (st & 8) inf.qp_capped++;
         /* l1 merit line search, polympc_redef.hpp:73-121 */
@@ -531,7 +534,7 @@ int orc_debug_qp_multi(const orc_model *mdl, int narm, const orc_config *c, cons
     pack(w, xs, us, T, z);
     set_boxes(w, c, x0, xf);
     linearise(mdl, c, w, z, lam ? lam : l0);
-    int st, it = admm(c, w, p, y, &st);
+    int st, it = admm(c, w, p, y, &st, lam);
     free(z); free(l0); work_free(w);
     return (st & ~8) ? -it : it;        /* (bit 3: the QP hit qp_iters — not an error of the leaf call) */
 }

@@ -65,6 +65,8 @@ typedef struct {
     double lbu[ORC_NU], ubu[ORC_NU]; /* control box    motionPlanner.cpp:73    */
     double lbg[ORC_NG], ubg[ORC_NG]; /* path bounds    motionPlanner.cpp:92-98 */
     double lbT, ubT;                 /* motionPlanner.cpp:76-79                */
+    int    qp_warm_start;            /* 0: every QP starts cold; 1: y_0 = lambda_k, x_0 = 0, z_0 = clip(0, l, u) (include/mpcmp.h) */
+    int    reserved_;
 } orc_config;
 
 typedef struct {

@@ -49,11 +49,11 @@ def test_dual_warm_start_vs_oracle(M):
         assert abs(wT[b] - Tg) <= 1e-9 * Tg and np.abs(wx[b] - xg).max() <= 1e-8 and np.abs(wu[b] - ug).max() <= 1e-6
 
 
-@pytest.mark.parametrize("nseg,sqp,B", [(6, 1, 2), (6, 3, 3), (8, 2, 2), (8, 20, 2)])
-def test_dual_arm_solve_vs_oracle(M, nseg, sqp, B):
+@pytest.mark.parametrize("nseg,sqp,B,warm", [(6, 1, 2, 0), (6, 3, 3, 0), (8, 2, 2, 0), (8, 20, 2, 0), (6, 3, 2, 1), (8, 3, 2, 1)])
+def test_dual_arm_solve_vs_oracle(M, nseg, sqp, B, warm):
     """two arm workgroups per OCP, one scalar exchanged per ADMM iteration: |dT| <= 1e-6 T, states <= 1e-6, identical ADMM
-    iteration counts and step lengths against orc_solve_multi"""
-    cfg = M.default_config(nseg, sqp, margins=MARGINS); ocfg = o.default_config(nseg, sqp, margins=MARGINS)
+    iteration counts and step lengths against orc_solve_multi (warm = 1: mpcmp_config.qp_warm_start, the QPs start from the NLP multipliers)"""
+    cfg = M.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=warm); ocfg = o.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=warm)
     x0, xf = dual_states(B, off=50)
     s = M.Solver(cfg, B, models=M.arm_models(M.DUAL_BASES))
     N = 3 * nseg + 1

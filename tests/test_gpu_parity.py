@@ -158,6 +158,32 @@ def test_n19_both_loop_kernels_vs_oracle(M, monkeypatch):
     assert np.abs(res["5"][0] - res["3"][0]).max() <= 1e-7 and np.abs(res["5"][1] - res["3"][1]).max() <= 1e-8
 
 
+@pytest.mark.parametrize("nseg,sqp,B,kern", [(4, 6, 3, ""), (4, 20, 2, ""), (6, 4, 3, ""), (6, 4, 3, "qp19=3"), (8, 4, 2, ""), (2, 4, 2, ""), (1, 4, 2, ""), (4, 4, 2, "qp13=3")])
+def test_solve_vs_oracle_qp_warm_start(M, nseg, sqp, B, kern, monkeypatch):
+    """mpcmp_config.qp_warm_start = 1 (opt-in: the QPs after the first start from the NLP multipliers, y_0 = lambda_k, x_0 = 0, z_0 = clip(0, l, u))
+    through every loop kernel — k_qp2 (N = 7, 13), k_qp5 and k_qp3 (N = 19), k_qp3 (N = 25, and N = 13 on request), the generic k_qp (N = 4) —
+    against the oracle with the same flag: identical ADMM iteration counts, step lengths and status words; and the flag does change the run."""
+    if kern:
+        monkeypatch.setenv("MPCMP_" + kern.split("=")[0].upper(), kern.split("=")[1])
+    cfg, ocfg = _cfgs(M, nseg, sqp, qp_warm_start=1)
+    from mpc_motion_planner_amd import scenarios
+    x0, xf = scenarios.make_batch(B, stream_offset=300)
+    N = 3 * nseg + 1
+    wx = np.zeros((B, N, 14)); wu = np.zeros((B, N, 7)); wT = np.zeros(B)
+    for b in range(B):
+        wx[b], wu[b], wT[b] = o.warm_start(ocfg, x0[b], xf[b])
+    s = M.Solver(cfg, B)
+    sx, su, sT, info = s.solve(x0, xf, (wx, wu, wT))
+    cold = 0
+    for b in range(B):
+        xs, us, T, oi = o.solve(ocfg, x0[b], xf[b], wx[b], wu[b], wT[b])
+        assert abs(sT[b] - T) <= 1e-6 * abs(T) and np.abs(sx[b] - xs).max() <= 1e-6 and np.abs(su[b] - us).max() <= 1e-5
+        assert info["qp_iters_total"][b] == oi.qp_iters_total and info["last_alpha"][b] == oi.last_alpha and info["status"][b] == oi.status
+        cold += o.solve(_cfgs(M, nseg, sqp)[1], x0[b], xf[b], wx[b], wu[b], wT[b])[3].qp_iters_total
+    if (nseg, sqp) == (4, 6):       # (the flag changes the run: checked where not every later QP runs into the cap both ways)
+        assert cold != int(info["qp_iters_total"].sum())
+
+
 @pytest.mark.parametrize("nseg,sqp,B", [(4, 2, 4), (4, 20, 3), (6, 2, 3), (6, 20, 2), (8, 2, 3), (8, 20, 2), (2, 3, 2), (1, 3, 2)])
 def test_solve_vs_oracle(M, nseg, sqp, B):
     cfg, ocfg = _cfgs(M, nseg, sqp)
