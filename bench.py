@@ -125,13 +125,13 @@ def committed_counters(workload):
     return None
 
 
-def cpu_baseline(nseg, sqp, x0, xf, warm, n_multi, n_single):
+def cpu_baseline(nseg, sqp, x0, xf, warm, n_multi, n_single, qp_warm_start=0):
     """Time the CPU oracle (same algorithm, same warm start; oracle/liboracle.so, C -O3) on a bounded sample of the same
     workload: (i) one thread = the reference's execution model (examples/benchmark.cpp:16), (ii) a pthread pool over
     problems on the host cores this process may use.  Checker/baseline only — never the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py as o
-    cfg = o.default_config(nseg, sqp, margins=MARGINS)
+    cfg = o.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=int(qp_warm_start))
     N = 3 * nseg + 1
     nproc = os.cpu_count() or 1
     try:
@@ -298,6 +298,7 @@ def main():
     ap.add_argument("--workload", choices=["batch", "rh", "shipped", "dual14"], default="batch",
                     help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon; shipped: the reference-as-shipped "
                          "solver depth (N=19, 2 SQP iterations; SURVEY.md 8d); dual14: configs[3], 14-DoF dual-Panda, N=25")
+    ap.add_argument("--qp-warm-start", action="store_true", help="mpcmp_config.qp_warm_start = 1 (opt-in: QPs start from the NLP multipliers); the contract line keeps the default 0")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the brief runs of the three other workloads")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # launcher self-test on a CPU-only box (gloo, no solve)
     args = ap.parse_args()
@@ -336,7 +337,8 @@ def main():
         # the other three workloads, briefly, inside the ONE contract line: value, ms_per_step, roofline fractions, CPU baseline
         import bench_dual14
         sec = {}
-        for name, fn in (("shipped", lambda: run_batch_workload(args, "shipped", 5, 1, 0, 1, local, None, 128, 1024, host_to_host=False)),
+        for name, fn in (("batch_qp_warm_start", lambda: run_batch_workload(args, "batch", 5, 1, 0, 1, local, None, 128, 1024, host_to_host=False, qp_warm_start=1)),
+                         ("shipped", lambda: run_batch_workload(args, "shipped", 5, 1, 0, 1, local, None, 128, 1024, host_to_host=False)),
                          ("rh", lambda: bench_receding_horizon(args, M, scenarios, local)),
                          ("dual14", lambda: bench_dual14.run(args, 0, 1, local, None, steps=2, warmup=1, batch=4096))):
             t0 = time.perf_counter()
@@ -356,7 +358,7 @@ def main():
         dist.destroy_process_group()
 
 
-def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, cpu_sample, batch, host_to_host=True):
+def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, cpu_sample, batch, host_to_host=True, qp_warm_start=None):
     """one batch workload (`batch` = BASELINE.json configs[1], `shipped` = the reference-as-shipped depth) on this rank; rank 0 returns the line"""
     import torch
     import mpc_motion_planner_amd as M
@@ -367,7 +369,8 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
     dev = torch.device("cuda", local)
     sb = sharding.ShardedBatch(total, rank, world, N, dev, dist)        # this rank's slice [lo, hi) of the global seeded batch
     B = sb.count
-    cfg = M.default_config(nseg, sqp, margins=MARGINS)
+    qws = int(args.qp_warm_start if qp_warm_start is None else qp_warm_start)
+    cfg = M.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws)
     solver = M.Solver(cfg, max(B, 1), device=local)
     x0_h, xf_h = scenarios.make_batch(B, MARGINS, stream_offset=sb.lo)
     x0 = torch.from_numpy(x0_h).to(dev); xf = torch.from_numpy(xf_h).to(dev)
@@ -447,7 +450,7 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
                                    % (batch, "per GPU" if args.scaling == "weak" else "in the whole job, sliced [r*B/G,(r+1)*B/G)", N, nseg, sqp,
                                       "jerk-limited (Ruckig-equivalent)" if args.warm == "jerk" else "quintic",
                                       "BASELINE.json configs[1]" if workload == "batch" else "reference as shipped: robot_ocp.hpp:32, motionPlanner.cpp:15"),
-                       "batch": batch, "problems_total": total, "problems_rank0": B, "rccl_world_size": world,
+                       "batch": batch, "problems_total": total, "problems_rank0": B, "rccl_world_size": world, "qp_warm_start": qws,
                        "seed": scenarios.SEED, "margins": list(MARGINS), "timed": "device-resident inputs and outputs (value); host_to_host beside it"},
             # the binding resource is FP64 vector issue + LDS + workgroup barriers: not HBM, not MFMA
             "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -488,7 +491,7 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
             out["host_to_host"] = {"trajectories_per_s": B / ts[len(ts) // 2], "repeats": len(ts), "min_ms": 1e3 * ts[0], "max_ms": 1e3 * ts[-1],
                                    "note": "SURVEY.md 8(d) defines the metric host->host; `value` is the device-resident rate the bench contract asks for"}
         if world == 1 and not args.no_cpu_baseline:
-            cb, T_cpu = cpu_baseline(nseg, sqp, x0_h, xf_h, args.warm, cpu_sample, max(16, cpu_sample // 4))
+            cb, T_cpu = cpu_baseline(nseg, sqp, x0_h, xf_h, args.warm, cpu_sample, max(16, cpu_sample // 4), qp_warm_start=qws)
             out["cpu_baseline"] = cb
             out["quality"]["max_rel_dT_vs_cpu_sample"] = float(np.max(np.abs(inf["T"][:len(T_cpu)] - T_cpu) / np.abs(T_cpu)))
         return out
