@@ -942,7 +942,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // termination test, common tail: combine the arms, add the row / column of T, decide
     const unsigned chk_base = 8 + cfg.qp_iters + 1;
     auto check_tail = [&](double (&sums)[2], double (&mx)[6], int nchk) -> int {
-        block_reduce_lean<8, 6, 6>(mx, redp + 32, tid);
+        block_reduce_dpp<8, 6, true>(mx, redp, tid);
         double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
         s1[arm] = sums[0]; s2[arm] = sums[1];
         if (NARM == 2) {
@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 }
             }
             if (sio < N) xt[NS * sio + 21] = misc[L::M_xT];
-            block_reduce_lean<8, 2, 0>(sums, redp, tid);          // (its barriers publish xt / ys)
+            block_reduce_dpp<8, 2, false>(sums, redp, tid);      // (its barriers publish xt / ys)
             double mx[6] = {0, 0, 0, 0, 0, 0};                   // rp, |Ax|, |z|, rd, |Hx|, |A^T y|
             const double xTc = xt[21];
 #pragma unroll
