@@ -90,6 +90,24 @@ int main() {
             mpcmp_shim::Trajectory tr2;
             planner.otg.calculate(slow, tr2);
             std::printf("\"rk_duration_slow\": %.17g, ", tr2.get_duration());
+            // an invalid input record is the RETURN VALUE (ruckig::Result::Error*), not an exception; at_time without a trajectory throws
+            mpcmp_shim::InputParameter bad = planner.input;
+            bad.max_acceleration[3] = 0.0;
+            mpcmp_shim::Trajectory tr3;
+            const int res_bad = (int)planner.otg.calculate(bad, tr3);
+            bool threw = false;
+            try { tr3.at_time(0.1, p7, v7, a7); } catch (const std::logic_error &) { threw = true; }
+            std::printf("\"otg_result_bad\": %d, \"at_time_threw\": %d, ", res_bad, threw ? 1 : 0);
+            // solve_trajectory(true) warm-starts from ALL of `input` (motionPlanner.cpp:146-149): a caller-written boundary acceleration and a tighter
+            // velocity limit change the guess's duration exactly as they change otg.calculate's
+            mpcmp_shim::InputParameter keep = planner.input;
+            for (int j = 0; j < 7; j++) { planner.input.current_acceleration[j] = 0.3 * planner.input.max_acceleration[j]; planner.input.max_velocity[j] *= 0.8; }
+            mpcmp_shim::Trajectory tr4;
+            planner.otg.calculate(planner.input, tr4);
+            planner.solve_trajectory(true);
+            planner.get_RK_point(0.0, q, v, a, tau);
+            std::printf("\"rk_duration_input\": %.17g, \"guess_T_input\": %.17g, \"rk_a0_ratio\": %.17g, ", tr4.get_duration(), planner.guess_T(), a(2) / planner.input.max_acceleration[2]);
+            planner.input = keep;
         }
         // robot.data look-alike (examples/benchmark.cpp:108-110)
         pinocchio::forwardKinematics(planner.robot.model, planner.robot.data, qT);

@@ -196,6 +196,15 @@ int mpcmp_jerk_trajectory_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, con
                                     const double *jmax, int n_pts, double *out, double *T_out);
 int mpcmp_jerk_point_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
                                const double *jmax, const double *time, double *out, double *T_out);
+/* The same three with the generator's velocity / acceleration limits given by the caller, vmax / amax [7] (either may be NULL = the context's
+ * margin-applied bounds): what ruckig::InputParameter::max_velocity / max_acceleration are to otg.calculate (motionPlanner.cpp:149).  The
+ * context's configuration is neither read for these limits nor changed. */
+int mpcmp_warm_start_jerk_lim_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                    const double *vmax, const double *amax, const double *jmax, double *warm_x, double *warm_u, double *warm_T);
+int mpcmp_jerk_trajectory_lim_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                    const double *vmax, const double *amax, const double *jmax, int n_pts, double *out, double *T_out);
+int mpcmp_jerk_point_lim_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                               const double *vmax, const double *amax, const double *jmax, const double *time, double *out, double *T_out);
 /* MotionPlanner::get_MPC_point (motionPlanner.hpp:118-128): the solution at ONE physical time per problem, including the
  * reference's clamp (time >= T: the normalised time becomes T, not 1), with the RNEA torque: out [B][28] as above. */
 int mpcmp_mpc_point_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const double *sol_u, const double *sol_T, const double *time,

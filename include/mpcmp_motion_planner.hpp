@@ -212,8 +212,7 @@ struct MpcView {
 
 // Look-alikes of the three Ruckig members (motionPlanner.hpp:34-37) for callers that touch them directly: the input record
 // (ruckig::InputParameter's field names), the trajectory (get_duration / at_time) and `otg.calculate(input, trajectory)`.
-// Behind them is the library's jerk-limited, time-synchronised generator (mpcmp_jerk_point_batch); target / current
-// accelerations other than zero are not supported by it and are ignored.
+// Behind them is the library's jerk-limited, time-synchronised generator (mpcmp_jerk_point_lim_batch); every field of the input record is used.
 enum Result { Working = 0, Finished = 1, Error = -1 };     // ruckig::Result, the values motionPlanner.cpp:149 can see
 struct InputParameter {
     std::array<double, NDOF> current_position{}, current_velocity{}, current_acceleration{};
@@ -228,7 +227,7 @@ struct Trajectory {
     friend struct Otg;
     MotionPlanner *owner = nullptr;
     InputParameter in;
-    mutable double duration = 0.0;
+    double duration = -1.0;
 };
 struct Otg {
     explicit Otg(MotionPlanner *o) : owner(o) {}
@@ -370,13 +369,15 @@ class MotionPlanner {
         const bool use_guess = !use_ruckig_as_warm_start && have_warm_;
         if (!use_guess) {
             guess_x_.assign((size_t)14 * N_, 0.0); guess_u_.assign((size_t)7 * N_, 0.0);
-            double jm[7];
-            jerk_limits(jm);
-            // (boundary accelerations as the reference forwards them to Ruckig: input.current_acceleration / target_acceleration, motionPlanner.cpp:36-38,50-52,149)
+            // the whole of `input`, as warm_start_RK hands it to otg.calculate (motionPlanner.cpp:146-149): states and boundary accelerations
+            // (written by set_current_state / set_target_state, motionPlanner.cpp:36-38,50-52, or by the caller), velocity / acceleration / jerk limits
+            // (set_constraint_margins, motionPlanner.cpp:86-88, or the caller)
+            input_states(guess_x0_, guess_xf_);
             for (int j = 0; j < 7; j++) { guess_a0_[j] = input.current_acceleration[j]; guess_aT_[j] = input.target_acceleration[j]; }
-            chk(mpcmp_warm_start_jerk_acc_batch(ctx_, 1, current_state.data(), target_state.data(), guess_a0_, guess_aT_, jm, guess_x_.data(), guess_u_.data(), &guess_T_));
+            guess_in_ = input;
+            chk(mpcmp_warm_start_jerk_lim_batch(ctx_, 1, guess_x0_, guess_xf_, guess_a0_, guess_aT_, input.max_velocity.data(), input.max_acceleration.data(),
+                                                input.max_jerk.data(), guess_x_.data(), guess_u_.data(), &guess_T_));
             guess_is_profile_ = true;
-            for (int r = 0; r < 14; r++) { guess_x0_[r] = current_state(r); guess_xf_[r] = target_state(r); }
         } else { guess_x_ = warm_x_; guess_u_ = warm_u_; guess_T_ = warm_T_; guess_is_profile_ = false; }
         solve_from_guess();
     }
@@ -404,9 +405,8 @@ class MotionPlanner {
         std::vector<double> out((size_t)(NP + 1) * 29);
         if (guess_is_profile_) {
             std::vector<double> tr((size_t)(NP + 1) * 22), q((size_t)(NP + 1) * 7), v(q.size()), a(q.size()), tau(q.size());
-            double jm[7];
-            jerk_limits(jm);
-            chk(mpcmp_jerk_trajectory_acc_batch(ctx_, 1, guess_x0_, guess_xf_, guess_a0_, guess_aT_, jm, NP, tr.data(), nullptr));
+            chk(mpcmp_jerk_trajectory_lim_batch(ctx_, 1, guess_x0_, guess_xf_, guess_a0_, guess_aT_, guess_in_.max_velocity.data(), guess_in_.max_acceleration.data(),
+                                                guess_in_.max_jerk.data(), NP, tr.data(), nullptr));
             for (int i = 0; i <= NP; i++)
                 for (int j = 0; j < 7; j++) { q[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 1 + j]; v[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 8 + j]; a[(size_t)i * 7 + j] = tr[(size_t)i * 22 + 15 + j]; }
             chk(mpcmp_rnea_batch(ctx_, NP + 1, q.data(), v.data(), a.data(), tau.data()));
@@ -431,12 +431,13 @@ class MotionPlanner {
     // motionPlanner.hpp:130-142: the jerk-limited (Ruckig stand-in) trajectory of the last solve_trajectory(true) at
     // min(time, duration), torque by RNEA
     void get_RK_point(double time, Vec7 &position, Vec7 &velocity, Vec7 &acceleration, Vec7 &torque) {
-        double o[28], jm[7];
-        jerk_limits(jm);
-        chk(mpcmp_jerk_point_acc_batch(ctx_, 1, guess_x0_, guess_xf_, guess_a0_, guess_aT_, jm, &time, o, nullptr));
+        double o[28];
+        chk(mpcmp_jerk_point_lim_batch(ctx_, 1, guess_x0_, guess_xf_, guess_a0_, guess_aT_, guess_in_.max_velocity.data(), guess_in_.max_acceleration.data(),
+                                       guess_in_.max_jerk.data(), &time, o, nullptr));
         for (int j = 0; j < 7; j++) { position(j) = o[j]; velocity(j) = o[7 + j]; acceleration(j) = o[14 + j]; torque(j) = o[21 + j]; }
     }
     double solution_T() const { return sol_T_; }
+    double guess_T() const { return guess_T_; }      // duration of the guess the last solve started from (p_guess, motionPlanner.cpp:173)
     const std::vector<double> &solution_x() const { return sol_x_; }
     const std::vector<double> &solution_u() const { return sol_u_; }
     int num_nodes() const { return N_; }
@@ -478,9 +479,8 @@ class MotionPlanner {
         std::vector<double> sg((size_t)B * 74), sm((size_t)B * 74);
         std::vector<mpcmp_info> info(B);
         for (int b = 0; b < B; b++) for (int r = 0; r < 14; r++) x0[(size_t)b * 14 + r] = current_state(r);
-        double jm[7];
-        jerk_limits(jm);
-        chk(mpcmp_warm_start_jerk_batch(ctx_, B, x0.data(), xf, jm, gx.data(), gu.data(), gT.data()));     // benchmark.cpp:46-47
+        chk(mpcmp_warm_start_jerk_lim_batch(ctx_, B, x0.data(), xf, nullptr, nullptr, input.max_velocity.data(), input.max_acceleration.data(), input.max_jerk.data(),
+                                            gx.data(), gu.data(), gT.data()));     // benchmark.cpp:46-47
         chk(mpcmp_solve_batch(ctx_, B, x0.data(), xf, gx.data(), gu.data(), gT.data(), sx.data(), su.data(), sT.data(), info.data()));
         chk(mpcmp_traj_stats_batch(ctx_, B, gx.data(), gu.data(), gT.data(), xf, n_pts, sg.data()));
         chk(mpcmp_traj_stats_batch(ctx_, B, sx.data(), su.data(), sT.data(), xf, n_pts, sm.data()));
@@ -509,7 +509,10 @@ class MotionPlanner {
     double sol_T_ = 0, warm_T_ = 0, guess_T_ = 0;
     bool guess_is_profile_ = false;                 // the last guess came from the jerk-limited generator
     double guess_x0_[14] = {0}, guess_xf_[14] = {0}, guess_a0_[7] = {0}, guess_aT_[7] = {0};      // states and boundary accelerations of the last jerk-limited guess
-    void jerk_limits(double *jm) const { for (int j = 0; j < 7; j++) jm[j] = input.max_jerk[j]; }   // motionPlanner.cpp:86-88,149 (margin_jerk * max_jerk unless the caller wrote `input`)
+    mpcmp_shim::InputParameter guess_in_;          // `input` as it was when that guess was made (limits of get_ruckig_trajectory / get_RK_point)
+    void input_states(double *x0, double *xf) const {
+        for (int j = 0; j < 7; j++) { x0[j] = input.current_position[j]; x0[7 + j] = input.current_velocity[j]; xf[j] = input.target_position[j]; xf[7 + j] = input.target_velocity[j]; }
+    }
     bool have_warm_ = false;
     uint64_t rng_ = 20240001ull;
 
@@ -620,32 +623,26 @@ inline void mpcmp_shim::MpcView::solve() {
     owner->solve_from_guess();
 }
 
-// Ruckig look-alikes.  The generator takes its velocity / acceleration limits from the context's bounds: a caller-written
-// input.max_velocity / max_acceleration is applied for the duration of the call and the planner's own bounds are restored.
+// Ruckig look-alikes.  All of `input` is honoured (states, boundary accelerations, the three limit vectors); the limits travel as arguments
+// (mpcmp_jerk_point_lim_batch), the planner's configuration is neither read nor touched.
 inline mpcmp_shim::Result mpcmp_shim::Otg::calculate(const InputParameter &input, Trajectory &trajectory) {
     trajectory.owner = owner; trajectory.in = input;
-    std::array<double, NDOF> p, v, a;
     trajectory.duration = -1.0;
-    trajectory.at_time(0.0, p, v, a);                       // (fills the duration)
-    return trajectory.duration >= 0.0 ? Working : Error;    // ruckig's offline calculate() returns Working on success
+    double x0[14], xf[14], o[28], T = 0.0, t0 = 0.0;
+    for (int j = 0; j < 7; j++) { x0[j] = input.current_position[j]; x0[7 + j] = input.current_velocity[j]; xf[j] = input.target_position[j]; xf[7 + j] = input.target_velocity[j]; }
+    // a failure (e.g. a limit that is not positive: ruckig::Result::ErrorInvalidInput) is the return value, not an exception
+    const int rc = mpcmp_jerk_point_lim_batch(owner->ctx_, 1, x0, xf, input.current_acceleration.data(), input.target_acceleration.data(), input.max_velocity.data(),
+                                              input.max_acceleration.data(), input.max_jerk.data(), &t0, o, &T);
+    if (rc != MPCMP_OK || !(T >= 0.0)) return Error;
+    trajectory.duration = T;
+    return Working;                                         // ruckig's offline calculate() returns Working on success
 }
 inline void mpcmp_shim::Trajectory::at_time(double time, std::array<double, NDOF> &position, std::array<double, NDOF> &velocity,
                                             std::array<double, NDOF> &acceleration) const {
-    if (!owner) throw std::logic_error("Trajectory::at_time before otg.calculate");
+    if (!owner || duration < 0.0) throw std::logic_error("Trajectory::at_time without a successful otg.calculate");
     double x0[14], xf[14], o[28], T = 0.0;
     for (int j = 0; j < 7; j++) { x0[j] = in.current_position[j]; x0[7 + j] = in.current_velocity[j]; xf[j] = in.target_position[j]; xf[7 + j] = in.target_velocity[j]; }
-    const mpcmp_config keep = owner->config;
-    mpcmp_config tmp = keep;
-    bool differs = false;
-    for (int j = 0; j < 7; j++) {
-        differs |= tmp.ubx[7 + j] != in.max_velocity[j] || tmp.ubu[j] != in.max_acceleration[j];
-        tmp.ubx[7 + j] = in.max_velocity[j]; tmp.lbx[7 + j] = -in.max_velocity[j];
-        tmp.ubu[j] = in.max_acceleration[j]; tmp.lbu[j] = -in.max_acceleration[j];
-    }
-    if (differs) owner->chk(mpcmp_set_config(owner->ctx_, &tmp));
-    const int rc = mpcmp_jerk_point_acc_batch(owner->ctx_, 1, x0, xf, in.current_acceleration.data(), in.target_acceleration.data(), in.max_jerk.data(), &time, o, &T);
-    if (differs) owner->chk(mpcmp_set_config(owner->ctx_, &keep));
-    owner->chk(rc);
-    duration = T;
+    owner->chk(mpcmp_jerk_point_lim_batch(owner->ctx_, 1, x0, xf, in.current_acceleration.data(), in.target_acceleration.data(), in.max_velocity.data(),
+                                          in.max_acceleration.data(), in.max_jerk.data(), &time, o, &T));
     for (int j = 0; j < 7; j++) { position[j] = o[j]; velocity[j] = o[7 + j]; acceleration[j] = o[14 + j]; }
 }

@@ -56,7 +56,8 @@ SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_models_from_ur
            "mpcmp_tool_jacobian", "mpcmp_forward_velocities", "mpcmp_inverse_velocities", "mpcmp_inverse_kinematics",
            "mpcmp_warm_start_jerk_batch", "mpcmp_warm_start_jerk_batch_device", "mpcmp_jerk_trajectory_batch",
            "mpcmp_jerk_point_batch", "mpcmp_mpc_point_batch", "mpcmp_debug_fetch",
-           "mpcmp_warm_start_jerk_acc_batch", "mpcmp_warm_start_jerk_acc_batch_device", "mpcmp_jerk_trajectory_acc_batch", "mpcmp_jerk_point_acc_batch"]
+           "mpcmp_warm_start_jerk_acc_batch", "mpcmp_warm_start_jerk_acc_batch_device", "mpcmp_jerk_trajectory_acc_batch", "mpcmp_jerk_point_acc_batch",
+           "mpcmp_warm_start_jerk_lim_batch", "mpcmp_jerk_trajectory_lim_batch", "mpcmp_jerk_point_lim_batch"]
 
 
 def library_path():

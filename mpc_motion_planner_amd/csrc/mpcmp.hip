@@ -1051,22 +1051,23 @@ struct TmpBuf {
 };
 
 // ---- jerk-limited, time-synchronised warm start / comparison trajectory (stands in for Ruckig) ----
-static int jerk_limits(mpcmp_ctx *ctx, const double *jmax, JerkLimits &lim) {
+// vmax / amax: NULL = the context's margin-applied bounds (the *_lim_* entry points pass a caller's own: ruckig::InputParameter::max_velocity / max_acceleration)
+static int jerk_limits(mpcmp_ctx *ctx, const double *vmax, const double *amax, const double *jmax, JerkLimits &lim) {
     for (int j = 0; j < 7; j++) {
-        lim.v[j] = ctx->cfg.ubx[7 + j]; lim.a[j] = ctx->cfg.ubu[j]; lim.j[j] = jmax[j];
+        lim.v[j] = vmax ? vmax[j] : ctx->cfg.ubx[7 + j]; lim.a[j] = amax ? amax[j] : ctx->cfg.ubu[j]; lim.j[j] = jmax[j];
         if (!(lim.v[j] > 0.0) || !(lim.a[j] > 0.0) || !(lim.j[j] > 0.0)) { ctx->err = "velocity, acceleration and jerk limits must be positive"; return MPCMP_EINVAL; }
     }
     return MPCMP_OK;
 }
 
 // boundary accelerations d_acc0 / d_accT: device [B][7], either may be NULL (= zero); single-arm contexts only (a multi-arm warm start has none)
-extern "C" int mpcmp_warm_start_jerk_acc_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_acc0, const double *d_accT,
-                                                      const double *jmax, double *d_wx, double *d_wu, double *d_wT, void *hip_stream) {
+static int warm_start_jerk_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_acc0, const double *d_accT,
+                                  const double *vmax, const double *amax, const double *jmax, double *d_wx, double *d_wu, double *d_wT, void *hip_stream) {
     if (!ctx || !d_x0 || !d_xf || !jmax || !d_wx || !d_wu || !d_wT || B < 1) return MPCMP_EINVAL;
     if ((d_acc0 || d_accT) && ctx->narm != 1) { ctx->err = "boundary accelerations: single-arm contexts only"; return MPCMP_EINVAL; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     JerkLimits lim;
-    if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
+    if (int rc = jerk_limits(ctx, vmax, amax, jmax, lim)) return rc;
     if (ctx->narm == 2) {
         // per-arm generator on B * narm arm problems, then the merge to the common (slowest arm's) duration: multi_kernels.hpp
         if (B > ctx->max_batch) return MPCMP_ETOOBIG;
@@ -1085,6 +1086,10 @@ extern "C" int mpcmp_warm_start_jerk_acc_batch_device(mpcmp_ctx *ctx, int B, con
     HIPCHK(ctx, hipGetLastError());
     return MPCMP_OK;
 }
+extern "C" int mpcmp_warm_start_jerk_acc_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_acc0, const double *d_accT,
+                                                      const double *jmax, double *d_wx, double *d_wu, double *d_wT, void *hip_stream) {
+    return warm_start_jerk_device(ctx, B, d_x0, d_xf, d_acc0, d_accT, nullptr, nullptr, jmax, d_wx, d_wu, d_wT, hip_stream);
+}
 extern "C" int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *jmax,
                                                   double *d_wx, double *d_wu, double *d_wT, void *hip_stream) {
     return mpcmp_warm_start_jerk_acc_batch_device(ctx, B, d_x0, d_xf, nullptr, nullptr, jmax, d_wx, d_wu, d_wT, hip_stream);
@@ -1102,8 +1107,8 @@ static int stage_acc(mpcmp_ctx *ctx, TmpBuf &tb, int B, const double *acc0, cons
     return MPCMP_OK;
 }
 
-extern "C" int mpcmp_warm_start_jerk_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
-                                               const double *jmax, double *wx, double *wu, double *wT) {
+extern "C" int mpcmp_warm_start_jerk_lim_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                               const double *vmax, const double *amax, const double *jmax, double *wx, double *wu, double *wT) {
     if (!ctx || !x0 || !xf || !jmax || !wx || !wu || !wT || B < 1) return MPCMP_EINVAL;
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1114,7 +1119,7 @@ extern "C" int mpcmp_warm_start_jerk_acc_batch(mpcmp_ctx *ctx, int B, const doub
     TmpBuf tb(ctx, (acc0 || accT) ? 14 * (size_t)B * sizeof(double) : 0);
     const double *da0, *daT;
     if (int rc = stage_acc(ctx, tb, B, acc0, accT, st, &da0, &daT)) return rc;
-    if (int rc = mpcmp_warm_start_jerk_acc_batch_device(ctx, B, ctx->d_x0, ctx->d_xf, da0, daT, jmax, ctx->d_wx, ctx->d_wu, ctx->d_wT, st)) return rc;
+    if (int rc = warm_start_jerk_device(ctx, B, ctx->d_x0, ctx->d_xf, da0, daT, vmax, amax, jmax, ctx->d_wx, ctx->d_wu, ctx->d_wT, st)) return rc;
     HIPCHK(ctx, hipMemcpyAsync(wx, ctx->d_wx, sizeof(double) * nx * N * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(wu, ctx->d_wu, sizeof(double) * nu * N * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(wT, ctx->d_wT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
@@ -1122,19 +1127,23 @@ extern "C" int mpcmp_warm_start_jerk_acc_batch(mpcmp_ctx *ctx, int B, const doub
     return MPCMP_OK;
 }
 
+extern "C" int mpcmp_warm_start_jerk_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                               const double *jmax, double *wx, double *wu, double *wT) {
+    return mpcmp_warm_start_jerk_lim_batch(ctx, B, x0, xf, acc0, accT, nullptr, nullptr, jmax, wx, wu, wT);
+}
 extern "C" int mpcmp_warm_start_jerk_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax,
                                            double *wx, double *wu, double *wT) {
     return mpcmp_warm_start_jerk_acc_batch(ctx, B, x0, xf, nullptr, nullptr, jmax, wx, wu, wT);
 }
 
-extern "C" int mpcmp_jerk_trajectory_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
-                                               const double *jmax, int n_pts, double *out, double *T_out) {
+extern "C" int mpcmp_jerk_trajectory_lim_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                               const double *vmax, const double *amax, const double *jmax, int n_pts, double *out, double *T_out) {
     if (!ctx || !x0 || !xf || !jmax || !out || B < 1 || n_pts < 1) return MPCMP_EINVAL;
     SINGLE_ARM_ONLY(ctx);
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     JerkLimits lim;
-    if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
+    if (int rc = jerk_limits(ctx, vmax, amax, jmax, lim)) return rc;
     const size_t cnt = (size_t)B * (n_pts + 1) * 22;
     TmpBuf tb(ctx, (cnt + 14 * (size_t)B) * sizeof(double));
     double *dout = tb.get<double>(cnt);
@@ -1152,20 +1161,24 @@ extern "C" int mpcmp_jerk_trajectory_acc_batch(mpcmp_ctx *ctx, int B, const doub
     return MPCMP_OK;
 }
 
+extern "C" int mpcmp_jerk_trajectory_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                               const double *jmax, int n_pts, double *out, double *T_out) {
+    return mpcmp_jerk_trajectory_lim_batch(ctx, B, x0, xf, acc0, accT, nullptr, nullptr, jmax, n_pts, out, T_out);
+}
 extern "C" int mpcmp_jerk_trajectory_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, int n_pts,
                                            double *out, double *T_out) {
     return mpcmp_jerk_trajectory_acc_batch(ctx, B, x0, xf, nullptr, nullptr, jmax, n_pts, out, T_out);
 }
 
 // MotionPlanner::get_RK_point (motionPlanner.hpp:130-142)
-extern "C" int mpcmp_jerk_point_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
-                                          const double *jmax, const double *time, double *out, double *T_out) {
+extern "C" int mpcmp_jerk_point_lim_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                          const double *vmax, const double *amax, const double *jmax, const double *time, double *out, double *T_out) {
     if (!ctx || !x0 || !xf || !jmax || !time || !out || B < 1) return MPCMP_EINVAL;
     SINGLE_ARM_ONLY(ctx);
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     JerkLimits lim;
-    if (int rc = jerk_limits(ctx, jmax, lim)) return rc;
+    if (int rc = jerk_limits(ctx, vmax, amax, jmax, lim)) return rc;
     TmpBuf tb(ctx, (29 + 14) * (size_t)B * sizeof(double));
     double *dt = tb.get<double>(B), *dout = tb.get<double>(28 * (size_t)B);
     if (!dt || !dout) { ctx->err = "hipMalloc failed"; return MPCMP_ERUNTIME; }
@@ -1183,6 +1196,10 @@ extern "C" int mpcmp_jerk_point_acc_batch(mpcmp_ctx *ctx, int B, const double *x
     return MPCMP_OK;
 }
 
+extern "C" int mpcmp_jerk_point_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                                          const double *jmax, const double *time, double *out, double *T_out) {
+    return mpcmp_jerk_point_lim_batch(ctx, B, x0, xf, acc0, accT, nullptr, nullptr, jmax, time, out, T_out);
+}
 extern "C" int mpcmp_jerk_point_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *jmax, const double *time,
                                       double *out, double *T_out) {
     return mpcmp_jerk_point_acc_batch(ctx, B, x0, xf, nullptr, nullptr, jmax, time, out, T_out);

@@ -151,7 +151,9 @@ __device__ __forceinline__ double q5_sprod(const double (&m)[48], const double *
 #ifndef Q5_ABL
 #define Q5_ABL 0
 #endif
-#define Q5_ON(n) (Q5_ABL != (n) && Q5_ABL != 10)      /* 10: every piece off (the bare loop: barriers and lane-constant fetches) */
+#define Q5_ON(n) (Q5_ABL != (n) && Q5_ABL < 10)        /* 10: every piece off (the bare loop: barriers, lane-constant fetches, the border's x~_T chain) */
+#define Q5_XT (Q5_ABL < 11)                            /* 11: 10 and no x~_T chain;  12: 11 and no lane-constant fetches;  13: 12 with three barriers instead of five */
+#define Q5_BAR(k) do { if (!(Q5_ABL == 13 && ((k) == 2 || (k) == 3))) __syncthreads(); } while (0)
 template <int NSEG>
 struct Qp5Ctx {
     const mpcmp_config *cfg;
@@ -203,12 +205,14 @@ template <int NSEG>
 __device__ __forceinline__ int q5_lc(const Qp5Ctx<NSEG> &c, int t, int f) {
     using L = Qp5<NSEG>;
     const int *lct = reinterpret_cast<const int *>(c.lds + L::vLCT);
+    if (Q5_ABL >= 12) return 0;
     return *(const volatile __attribute__((address_space(3))) int *)(lct + f * L::NT + t);
 }
 template <int NSEG>
 __device__ __forceinline__ int q5_l5(const Qp5Ctx<NSEG> &c, int lane, int f) {       // last G wave: 0 pxr, 1 prf, 2 prb, 3 ixr of the lane's variable / dynamics row
     using L = Qp5<NSEG>;
     const int *t5 = reinterpret_cast<const int *>(c.lds + L::vL5);
+    if (Q5_ABL >= 12) return 0;
     return *(const volatile __attribute__((address_space(3))) int *)(t5 + f * 64 + lane);
 }
 __device__ __forceinline__ int lo16(int w) { return w & 0xFFFF; }
@@ -525,14 +529,14 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
             const double bp = sum8(wb * r);
             lds[L::vRedB + (vi >> 3)] = bp;
         }
-        Q5B(0); __syncthreads(); Q5S(0);
+        Q5B(0); Q5_BAR(0); Q5S(0);
         if (Q5_ON(2)) q5_p1<NSEG>(c, fm, sio, k0, k1, k2, k3);
-        Q5B(1); __syncthreads(); Q5S(1);
+        Q5B(1); Q5_BAR(1); Q5S(1);
         // ---- P2 (role S); this role is idle: the lane constants of phase E ----
         const int gro = q5_lc<NSEG>(c, sio, 4), xno = q5_lc<NSEG>(c, sio, 5);
-        Q5B(2); __syncthreads(); Q5S(2);
+        Q5B(2); Q5_BAR(2); Q5S(2);
         // ---- P3 (role E) ----
-        Q5B(3); __syncthreads(); Q5S(3);
+        Q5B(3); Q5_BAR(3); Q5S(3);
         // ---- E: the path rows; the last G wave's variables ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
@@ -586,7 +590,7 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
             }
         }
         pxr = q5_l5<NSEG>(c, sio & 63, 0); prf = q5_l5<NSEG>(c, sio & 63, 1); prb = q5_l5<NSEG>(c, sio & 63, 2);
-        Q5B(4); __syncthreads(); Q5S(4);
+        Q5B(4); Q5_BAR(4); Q5S(4);
         if (__builtin_expect(check, 0)) {
             int t = tid;
             asm volatile("" : "+v"(t));
@@ -743,17 +747,17 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
             const double bp = sum8(wb * r);
             lds[L::vRedB + (vi >> 3)] = bp;               // (all eight lanes of a group hold the sum and store it)
         }
-        Q5B(0); __syncthreads(); Q5S(0);
+        Q5B(0); Q5_BAR(0); Q5S(0);
         // ---- P1 (role G); the last wave sums the border's partial sums ----
-        if (waveX) q5_p1_xT<NSEG>(c, sio);
+        if (waveX && Q5_XT) q5_p1_xT<NSEG>(c, sio);
         const int k0 = q5_lc<NSEG>(c, sio, 0), k1 = q5_lc<NSEG>(c, sio, 1);
-        Q5B(1); __syncthreads(); Q5S(1);
+        Q5B(1); Q5_BAR(1); Q5S(1);
         if (waveS && Q5_ON(3)) q5_p2<NSEG>(c, fs, sio, k0, k1, laneS, true);
-        Q5B(2); __syncthreads(); Q5S(2);
+        Q5B(2); Q5_BAR(2); Q5S(2);
         const int epx = q5_lc<NSEG>(c, sio, 2), epb = isDyn ? q5_lc<NSEG>(c, sio, 4) : 0, eix = isDyn ? q5_lc<NSEG>(c, sio, 5) : 0;      // (constants of phase E: in flight during the product)
         if (EP && Q5_ON(4)) q5_p3<NSEG>(c, reinterpret_cast<const double (&)[52]>(fm), sio, k0, k1, laneE, true);
-        else if (waveX) q5_p3_xT<NSEG>(c, sio, true);
-        Q5B(3); __syncthreads(); Q5S(3);
+        else if (waveX && Q5_XT) q5_p3_xT<NSEG>(c, sio, true);
+        Q5B(3); Q5_BAR(3); Q5S(3);
         // ---- E: the variable and the dynamics row of the lane ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
@@ -781,7 +785,7 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
             vzb = znv;
             if (check) lds[L::vXx + xpos] = vx;
         }
-        Q5B(4); __syncthreads(); Q5S(4);
+        Q5B(4); Q5_BAR(4); Q5S(4);
         if (__builtin_expect(check, 0)) {
             int t = tid;
             asm volatile("" : "+v"(t));

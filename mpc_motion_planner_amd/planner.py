@@ -89,13 +89,19 @@ class Solver:
     def _acc(self, a, B):
         return None if a is None else f64(np.broadcast_to(np.asarray(a, dtype=np.float64), (B, 7)))
 
-    def warm_start_jerk(self, x0, xf, jmax, acc0=None, accT=None):
+    @staticmethod
+    def _lim(v):
+        return None if v is None else f64(v).reshape(7)
+
+    def warm_start_jerk(self, x0, xf, jmax, acc0=None, accT=None, vmax=None, amax=None):
         """Jerk-limited, time-synchronised warm start (stands in for Ruckig): (warm_x [B][N][14], warm_u [B][N][7], warm_T [B]).
-        acc0 / accT: boundary accelerations [B][7] (None = zero), as set_current_state / set_target_state forward them (motionPlanner.cpp:36-38,50-52)."""
+        acc0 / accT: boundary accelerations [B][7] (None = zero), as set_current_state / set_target_state forward them (motionPlanner.cpp:36-38,50-52).
+        vmax / amax [7]: the generator's velocity / acceleration limits (None = the context's margin-applied bounds): ruckig's input.max_velocity / max_acceleration."""
         (x0, xf), jmax = self._states(x0, xf), f64(jmax).reshape(7); B = x0.shape[0]
         wx, wu, wT = np.zeros((B, self.N, self.nx)), np.zeros((B, self.N, self.nu)), np.zeros(B)
         a0, aT = self._acc(acc0, B), self._acc(accT, B)
-        check(lib().mpcmp_warm_start_jerk_acc_batch(self._ctx, B, dp(x0), dp(xf), dp(a0), dp(aT), dp(jmax), dp(wx), dp(wu), dp(wT)), self._ctx)
+        check(lib().mpcmp_warm_start_jerk_lim_batch(self._ctx, B, dp(x0), dp(xf), dp(a0), dp(aT), dp(self._lim(vmax)), dp(self._lim(amax)), dp(jmax),
+                                                    dp(wx), dp(wu), dp(wT)), self._ctx)
         return wx, wu, wT
 
     def warm_start_jerk_device(self, B, x0, xf, jmax, warm_x, warm_u, warm_T, stream=0):
@@ -105,21 +111,23 @@ class Solver:
         check(lib().mpcmp_warm_start_jerk_batch_device(self._ctx, int(B), vp(x0), vp(xf), dp(jmax), vp(warm_x), vp(warm_u), vp(warm_T),
                                                        vp(stream or None)), self._ctx)
 
-    def jerk_trajectory(self, x0, xf, jmax, n_pts=200, acc0=None, accT=None):
+    def jerk_trajectory(self, x0, xf, jmax, n_pts=200, acc0=None, accT=None, vmax=None, amax=None):
         """The same trajectory sampled uniformly: out [B][n_pts+1][22] = t, q, qd, qdd, and the durations [B]."""
         (x0, xf), jmax = self._states(x0, xf), f64(jmax).reshape(7); B = x0.shape[0]
         out, T = np.zeros((B, n_pts + 1, 22)), np.zeros(B)
         a0, aT = self._acc(acc0, B), self._acc(accT, B)
-        check(lib().mpcmp_jerk_trajectory_acc_batch(self._ctx, B, dp(x0), dp(xf), dp(a0), dp(aT), dp(jmax), int(n_pts), dp(out), dp(T)), self._ctx)
+        check(lib().mpcmp_jerk_trajectory_lim_batch(self._ctx, B, dp(x0), dp(xf), dp(a0), dp(aT), dp(self._lim(vmax)), dp(self._lim(amax)), dp(jmax),
+                                                    int(n_pts), dp(out), dp(T)), self._ctx)
         return out, T
 
-    def jerk_point(self, x0, xf, jmax, time, acc0=None, accT=None):
+    def jerk_point(self, x0, xf, jmax, time, acc0=None, accT=None, vmax=None, amax=None):
         """MotionPlanner::get_RK_point: [B][28] = q, qd, qdd, tau of the jerk-limited trajectory at min(time, duration), durations [B]."""
         (x0, xf), jmax = self._states(x0, xf), f64(jmax).reshape(7); B = x0.shape[0]
         time = f64(np.broadcast_to(np.asarray(time, dtype=np.float64), (B,)))
         out, T = np.zeros((B, 28)), np.zeros(B)
         a0, aT = self._acc(acc0, B), self._acc(accT, B)
-        check(lib().mpcmp_jerk_point_acc_batch(self._ctx, B, dp(x0), dp(xf), dp(a0), dp(aT), dp(jmax), dp(time), dp(out), dp(T)), self._ctx)
+        check(lib().mpcmp_jerk_point_lim_batch(self._ctx, B, dp(x0), dp(xf), dp(a0), dp(aT), dp(self._lim(vmax)), dp(self._lim(amax)), dp(jmax),
+                                               dp(time), dp(out), dp(T)), self._ctx)
         return out, T
 
     def mpc_point(self, sx, su, sT, time):

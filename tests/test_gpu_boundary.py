@@ -92,6 +92,10 @@ def test_cpp_shim_warm_start_solve_points_vs_oracle(M, tmp_path):
     assert np.abs(np.array(r["rk_at_time"]) - pin[:21]).max() == 0.0
     _, Tslow = o.jerk_trajectory(0.8 * vmax, amax, 0.5 * jmax, x0, xf, 10)
     assert abs(r["rk_duration_slow"] - Tslow) <= 1e-9 * Tslow and Tslow > Trk
+    # a non-positive limit: calculate() returns Error (-1) and leaves no trajectory behind; `input` is honoured in full by solve_trajectory(true)
+    assert r["otg_result_bad"] == -1 and r["at_time_threw"] == 1
+    _, Tin = o.jerk_trajectory(0.8 * vmax, amax, jmax, x0, xf, 10, acc0=0.3 * amax, accT=np.zeros(7))
+    assert abs(r["rk_duration_input"] - Tin) <= 1e-9 * Tin and r["guess_T_input"] == r["rk_duration_input"] and abs(r["rk_a0_ratio"] - 0.3) <= 1e-12
 
 
 def test_python_batch_motion_planner_vs_oracle(M):

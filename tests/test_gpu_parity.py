@@ -481,6 +481,18 @@ def test_jerk_limited_warm_start_vs_oracle_and_stored_ruckig(M, golden_dir):
     z = np.zeros((B, 7))
     wxz, wuz, wTz = s.warm_start_jerk(x0, xf, jmax, acc0=z, accT=z)
     assert np.array_equal(wxz, wx) and np.array_equal(wuz, wu) and np.array_equal(wTz, wT)
+    # limits given by the caller (ruckig's input.max_velocity / max_acceleration, motionPlanner.cpp:86-88,149) instead of the context's bounds:
+    # HIP vs oracle with tighter limits; the context's own limits passed explicitly = the plain entry point bit for bit; a limit <= 0 is EINVAL
+    wxl, wul, wTl = s.warm_start_jerk(x0s, xfs, jmax, acc0=a0, accT=aT, vmax=0.8 * vmax, amax=0.9 * amax)
+    ptl, Tl = s.jerk_point(x0s, xfs, jmax, 0.4 * wTl, acc0=a0, accT=aT, vmax=0.8 * vmax, amax=0.9 * amax)
+    for b in range(B):
+        xg, ug, Tg = o.warm_start_jerk(4, 0.8 * vmax, 0.9 * amax, jmax, x0s[b], xfs[b], acc0=a0[b], accT=aT[b])
+        assert abs(wTl[b] - Tg) <= 1e-9 * Tg and abs(Tl[b] - Tg) <= 1e-9 * Tg
+        assert np.abs(wxl[b] - xg).max() <= 1e-8 and np.abs(wul[b] - ug).max() <= 1e-6
+    wxe, wue, wTe = s.warm_start_jerk(x0, xf, jmax, vmax=vmax, amax=amax)
+    assert np.array_equal(wxe, wx) and np.array_equal(wue, wu) and np.array_equal(wTe, wT)
+    with pytest.raises(Exception):
+        s.warm_start_jerk(x0, xf, jmax, vmax=0.0 * vmax)
     # KAT-RK through the GPU path (6 stored digits)
     g = json.load(open(os.path.join(golden_dir, "gold_traj.json")))
     k0 = np.concatenate([g["q0"], g["v0"]])[None]; kf = np.concatenate([g["qT"], g["vT"]])[None]

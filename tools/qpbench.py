@@ -16,6 +16,8 @@ for B in [int(a) for a in sys.argv[1:]] or [256, 512, 1024]:
     cfg.eps_abs = 0.0; cfg.eps_rel = 0.0
     if os.environ.get("QPB_CE"):
         cfg.check_every = int(os.environ["QPB_CE"])      # (e.g. 10000: no termination test at all)
+    if os.environ.get("QPB_ITERS"):
+        cfg.qp_iters = int(os.environ["QPB_ITERS"])      # (two settings give the per-iteration cost without the kernel's prologue)
     s = M.Solver(cfg, B)
     x0, xf = scenarios.make_batch(B)
     wx, wu, wT = s.warm_start(x0, xf)
