@@ -63,21 +63,54 @@ def measured_fp64_peak():
         return None
 
 
-def committed_traffic(kname, problems_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json)"""
+def _tree_sha():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from src_hash import csrc_sha16
+        return csrc_sha16(ROOT)
+    except Exception:
+        return None
+
+
+def committed_traffic(kname, problems_per_launch, workload=None):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes: (bytes, MFMA busy cycles, source record).
+    Round 4's file (profiles/r04_traffic.json, tools/traffic_from_summary.py) is keyed by workload and kernel and names the kernel sources it was
+    measured on; the figure is withheld (None) when the tree differs.  Older files (one kernel each, no hash) are used for an unchanged kernel only."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+        rec = tj["workloads"].get(workload or "", {})
+        e = rec.get("kernels", {}).get(kname)
+        if e is not None and rec.get("problems_per_launch") == problems_per_launch and "traffic_bytes_per_launch" in e:
+            stale = tj.get("csrc_sha16") != _tree_sha()
+            src = {"file": "profiles/r04_traffic.json", "csrc_sha16": tj.get("csrc_sha16"), "stale": stale,
+                   "what": "FETCH_SIZE x 2 + WRITE_SIZE of the dominant kernel, per launch (committed profile, not this run)"}
+            return (None if stale else e["traffic_bytes_per_launch"]), e.get("SQ_VALU_MFMA_BUSY_CYCLES"), src
+    except Exception:
+        pass
     for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", f)))
             if tj.get("kernel") == kname and tj.get("problems_per_launch") == problems_per_launch:
-                return tj["traffic_bytes_per_launch"], tj.get("mfma_busy_cycles_per_launch")
+                return tj["traffic_bytes_per_launch"], tj.get("mfma_busy_cycles_per_launch"), {"file": "profiles/" + f, "stale": None,
+                        "what": "FETCH_SIZE x 2 + WRITE_SIZE of the dominant kernel, per launch (committed profile of an earlier round, no source hash)"}
         except Exception:
             pass
-    return None, None
+    return None, None, None
 
 
 def committed_mfma(workload):
     """MFMA counters of the factorisation kernel k_qp3f (its Schur complement products run on the matrix cores) from the committed
-    rocprofv3 PMC pass (profiles/r02_mfma.json); None for the N = 13 path, whose kernel k_qp2 issues no MFMA"""
+    rocprofv3 PMC pass (profiles/r04_traffic.json, else r03_mfma.json); None for the N = 13 path, whose kernel k_qp2 issues no MFMA"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+        rec = tj["workloads"].get(workload, {})
+        e = rec.get("kernels", {}).get("k_qp3f")
+        if e is not None and "SQ_INSTS_MFMA" in e:
+            return {"kernel": "k_qp3f", "insts_mfma_per_launch": e["SQ_INSTS_MFMA"], "mfma_busy_cycles_per_launch": e.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                    "mops_f64_per_launch": e.get("SQ_INSTS_VALU_MFMA_MOPS_F64"), "problems_per_launch": rec.get("problems_per_launch"),
+                    "source": "committed_profile: profiles/r04_traffic.json", "stale": tj.get("csrc_sha16") != _tree_sha()}
+    except Exception:
+        pass
     try:
         mj = json.load(open(os.path.join(ROOT, "profiles", "r03_mfma.json")))
         e = mj.get(workload)
@@ -104,12 +137,7 @@ def committed_counters(workload):
     by tools/fp64_counters.py from `tools/profile_round.sh`): flops the ISA executed per ADMM iteration of one trajectory (factorisation included in
     the ratio; wave-level counts x 64 lanes, inactive lanes included: an upper bound).  `stale` is True when the kernel sources of the working tree
     (tools/src_hash.py) are not the ones the profile was measured on: the fraction is then withheld.  None if no profile has the workload."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    try:
-        from src_hash import csrc_sha16
-        now = csrc_sha16(ROOT)
-    except Exception:
-        now = None
+    now = _tree_sha()
     for f in ("r04_fp64_counters.json", "r03_fp64_counters.json"):
         try:
             cj = json.load(open(os.path.join(ROOT, "profiles", f)))
@@ -173,7 +201,8 @@ def bench_receding_horizon(args, M, scenarios, local):
     (reference-as-shipped solver depth: 2 SQP iterations per re-solve, motionPlanner.cpp:15; N = 13; dt = 10 ms)"""
     nseg, sqp = 4, 2
     B, resolves, dt = 512, 200, 0.01
-    cfg = M.default_config(nseg, sqp, margins=MARGINS)
+    qws = int(getattr(args, "qp_warm_start", False))
+    cfg = M.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws)
     s = M.Solver(cfg, B, device=local)
     x0, xf = scenarios.make_batch(B, MARGINS)
     out, admm = {}, {}
@@ -212,7 +241,7 @@ def bench_receding_horizon(args, M, scenarios, local):
         # CPU baseline: the oracle's re-solve (2 SQP iterations from the previous solution) on a sample of the instances
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_py as o
-        ocfg = o.default_config(nseg, sqp, margins=MARGINS)
+        ocfg = o.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws)
         ns, reps = 16, 8
         t0 = time.perf_counter()
         for b in range(ns):
@@ -430,7 +459,7 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
         per_gpu = value / world
         achieved = per_gpu * flops_qp_traj / 1e12                           # on the wall clock of the timed region (includes the other kernels)
         alg_bytes_launch = problems_per_launch * bytes_per_traj / sqp
-        traffic, mfma_busy = committed_traffic(kname, problems_per_launch)
+        traffic, mfma_busy, traffic_src = committed_traffic(kname, problems_per_launch, workload)
         peak_meas = measured_fp64_peak()
         # executed FP64 flops: from the committed counter pass (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 of the QP kernels), per ADMM iteration actually run;
         # the round-1/2 hand count (EXECUTED_FMA) only if no counter profile is committed
@@ -459,7 +488,7 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
                          "executed_source": cc if cc is not None else "hand count (bench.py EXECUTED_FMA): no counter profile committed",
                          "canonical_frac": achieved / FP64_PEAK_TFLOPS,
                          "peak_measured": peak_meas, "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None,
-                         "traffic": traffic, "traffic_source": "committed_profile: profiles/r03_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE of the dominant kernel, per launch)",
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "mfma_busy": 0.0 if mfma_busy is None else mfma_busy,
                          "mfma_factor_kernel": committed_mfma(workload),
                          "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts, "problems_per_launch": problems_per_launch,

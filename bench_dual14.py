@@ -102,6 +102,7 @@ def run(args, rank, world, local, dist, steps=None, warmup=None, batch=None):
         executed = None if cc["stale"] else per_gpu * admm_mean * cc["flops_per_admm_iter"] / 1e12      # (stale counter profile: no fraction)
     else:
         executed = per_gpu * 2.0 * narm * (admm_mean * Bn.EXECUTED_FMA[nseg][0] + sqp * Bn.EXECUTED_FMA[nseg][1]) / 1e12
+    traffic, _, traffic_src = Bn.committed_traffic(kname, B / parts, "dual14")
     out = {
         "metric": metric, "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -117,7 +118,7 @@ def run(args, rank, world, local, dist, steps=None, warmup=None, batch=None):
                      "executed_source": cc if cc is not None else "hand count (bench.py EXECUTED_FMA): no counter profile committed",
                      "canonical_frac": achieved / Bn.FP64_PEAK_TFLOPS,
                      "peak_measured": peak_meas,
-                     "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None, "traffic": None, "mfma_busy": 0.0,
+                     "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None, "traffic": traffic, "traffic_source": traffic_src, "mfma_busy": 0.0,
                      "mfma_factor_kernel": Bn.committed_mfma("dual14"),
                      "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts,
                      "problems_per_launch": B / parts, "workgroups_per_problem": 2,
