@@ -31,9 +31,18 @@ def test_library_exports_every_declared_symbol(M):
     assert M.lib().mpcmp_version().startswith(b"mpcmp")
 
 
-def test_struct_layouts_match_header(M):
+def test_struct_layouts_match_header(M, tmp_path):
     assert C.sizeof(M.Info) == 64 and M.INFO_DTYPE.itemsize == 64
     assert C.sizeof(M.Config) == C.sizeof(o.Config) and C.sizeof(M.Model) == C.sizeof(o.Model)
+    # the header itself, through a C compiler: sizes and the offsets of the fields appended last
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mpcmp.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(mpcmp_config), '
+                   'sizeof(mpcmp_model), sizeof(mpcmp_info), offsetof(mpcmp_config, qp_warm_start), offsetof(mpcmp_config, lbT)); return 0; }\n')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    sz = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sz == [C.sizeof(M.Config), C.sizeof(M.Model), C.sizeof(M.Info), M.Config.qp_warm_start.offset, M.Config.lbT.offset], sz
 
 
 def test_config_and_limits_match_oracle(M):
