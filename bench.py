@@ -374,7 +374,7 @@ def main():
             try:
                 d = fn()
                 sec[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"],
-                             "roofline": {k: d["roofline"].get(k) for k in ("kernel", "frac", "canonical_frac", "avg_launch_ms", "admm_iters_per_traj", "admm_iters_per_resolve")
+                             "roofline": {k: d["roofline"].get(k) for k in ("kernel", "frac", "canonical_frac", "avg_launch_ms", "admm_iters_per_traj", "admm_iters_per_resolve", "traffic", "problems_per_launch")
                                           if k in d["roofline"]},
                              "cpu_baseline": {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "single_thread")} if "cpu_baseline" in d else None,
                              "quality": d.get("quality"), "config": d["config"]["workload"], "wall_s": time.perf_counter() - t0}
