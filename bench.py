@@ -122,6 +122,19 @@ def committed_mfma(workload):
         return None
 
 
+def _finite(x):
+    """the line must be strict JSON: a non-finite number (e.g. the mean final time of a batch with a failed instance) becomes null"""
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, float) and not np.isfinite(x):
+        return None
+    if isinstance(x, np.generic):
+        return _finite(x.item())
+    return x
+
+
 def status_fractions(st):
     """what the per-problem status words (include/mpcmp.h MPCMP_STATUS_*) say about a batch"""
     st = np.asarray(st)
@@ -196,13 +209,14 @@ def cpu_baseline(nseg, sqp, x0, xf, warm, n_multi, n_single, qp_warm_start=0):
                       % (n_multi, threads, dt_multi, n_single, dt_single, nproc)}, T
 
 
-def bench_receding_horizon(args, M, scenarios, local):
+def bench_receding_horizon(args, M, scenarios, local, qp_warm_start=None, carry_multipliers=None):
     """BASELINE.json configs[4]: 512 parallel Panda instances x 200 warm-started re-solves, hipGraph-captured step.
     (reference-as-shipped solver depth: 2 SQP iterations per re-solve, motionPlanner.cpp:15; N = 13; dt = 10 ms)"""
     nseg, sqp = 4, 2
     B, resolves, dt = 512, 200, 0.01
-    qws = int(getattr(args, "qp_warm_start", False))
-    cfg = M.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws)
+    qws = int(getattr(args, "qp_warm_start", False)) if qp_warm_start is None else int(qp_warm_start)
+    carry = int(getattr(args, "carry_multipliers", False)) if carry_multipliers is None else int(carry_multipliers)
+    cfg = M.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws, carry_multipliers=carry)
     s = M.Solver(cfg, B, device=local)
     x0, xf = scenarios.make_batch(B, MARGINS)
     out, admm = {}, {}
@@ -236,21 +250,24 @@ def bench_receding_horizon(args, M, scenarios, local):
                          "avg_launch_ms_eager": (k_ms / max(k_n, 1)) if k_n else None, "launches_eager": k_n,
                          "admm_iters_per_resolve": admm_per_resolve, "canonical_gflop_per_resolve": flops / 1e9,
                          "note": "whole re-solve on the wall clock (canonical dense-equivalent flops, SURVEY.md 8d); the kernel uses no MFMA"},
-            "quality": dict(status_fractions(info["status"]), T_mean_remaining=float(sT.mean()))}
+            "quality": dict(status_fractions(info["status"]), T_mean_remaining=float(np.nanmean(sT)), T_nan_frac=float(np.isnan(sT).mean()))}
     if not args.no_cpu_baseline:
         # CPU baseline: the oracle's re-solve (2 SQP iterations from the previous solution) on a sample of the instances
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_py as o
-        ocfg = o.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws)
+        ocfg = o.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws, carry_multipliers=carry)
         ns, reps = 16, 8
         t0 = time.perf_counter()
         for b in range(ns):
-            wx, wu, wT = o.warm_start(ocfg, x0[b], xf[b]); xc = x0[b].copy()
+            wx, wu, wT = o.warm_start(ocfg, x0[b], xf[b]); xc = x0[b].copy(); lam = None
             for r in range(reps):
-                xs, us, T, _ = o.solve(ocfg, xc, xf[b], wx, wu, wT)
-                xc = o.mpc_point(nseg, xs, us, T, dt)[:14]
-                wx, wu, wT = xs.copy(), us, T
-                wx[0] = xc; wx[-1] = xf[b]
+                xs, us, T, oi, lam = o.solve_carry(ocfg, xc, xf[b], wx, wu, wT, lam=lam)
+                if oi.status & (1 | 2 | 4 | 32):                  # a failed solve is neither a trajectory to follow nor a guess (k_advance, k_init)
+                    wx, wu, wT = o.warm_start(ocfg, xc, xf[b])
+                else:
+                    xc = o.mpc_point(nseg, xs, us, T, dt)[:14]
+                    wx, wu, wT = xs.copy(), us, T
+                    wx[0] = xc; wx[-1] = xf[b]
         el = time.perf_counter() - t0
         line["cpu_baseline"] = {"value": ns * reps / el, "unit": "re-solves/s", "cores": 1, "kind": "port", "single_thread": ns * reps / el,
                                 "nproc": os.cpu_count(), "sample": "oracle, %d instances x %d re-solves, 1 thread, %.1f s" % (ns, reps, el)}
@@ -327,6 +344,7 @@ def main():
     ap.add_argument("--workload", choices=["batch", "rh", "shipped", "dual14"], default="batch",
                     help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon; shipped: the reference-as-shipped "
                          "solver depth (N=19, 2 SQP iterations; SURVEY.md 8d); dual14: configs[3], 14-DoF dual-Panda, N=25")
+    ap.add_argument("--carry-multipliers", action="store_true", help="rh workload: mpcmp_config.carry_multipliers = 1 (a re-solve starts from the multipliers of the one before; opt-in)")
     ap.add_argument("--qp-warm-start", action="store_true", help="mpcmp_config.qp_warm_start = 1 (opt-in: QPs start from the NLP multipliers); the contract line keeps the default 0")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the brief runs of the three other workloads")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # launcher self-test on a CPU-only box (gloo, no solve)
@@ -369,6 +387,7 @@ def main():
         for name, fn in (("batch_qp_warm_start", lambda: run_batch_workload(args, "batch", 5, 1, 0, 1, local, None, 128, 1024, host_to_host=False, qp_warm_start=1)),
                          ("shipped", lambda: run_batch_workload(args, "shipped", 5, 1, 0, 1, local, None, 128, 1024, host_to_host=False)),
                          ("rh", lambda: bench_receding_horizon(args, M, scenarios, local)),
+                         ("rh_carry_multipliers", lambda: bench_receding_horizon(args, M, scenarios, local, qp_warm_start=1, carry_multipliers=1)),
                          ("dual14", lambda: bench_dual14.run(args, 0, 1, local, None, steps=2, warmup=1, batch=4096))):
             t0 = time.perf_counter()
             try:
@@ -382,7 +401,7 @@ def main():
                 sec[name] = {"error": repr(e)}
         line["secondary"] = sec
     if line is not None:
-        print(json.dumps(line))
+        print(json.dumps(_finite(line), allow_nan=False))
     if world > 1:
         dist.destroy_process_group()
 

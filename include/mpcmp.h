@@ -74,8 +74,15 @@ typedef struct {
      * nearly halves the ADMM iterations per trajectory with better feasibility; the stored reference solve is ONE SQP iteration
      * and cannot tell the two apart. */
     int    qp_warm_start;
-    int    reserved_;
+    /* Multipliers at the start of a solve.  0 (default) = lambda_0 = 0 for every problem of every call (independent problems: the batch semantics).
+     * 1 = the multipliers a problem slot was left with by the context's previous solve are the start of the next one (zero in a fresh context and
+     * after mpcmp_reset_multipliers / mpcmp_rh_init): what a re-solve on ONE MotionPlanner object most plausibly does upstream (polympc keeps its
+     * dual iterate until lam_guess is called: SURVEY.md 3.2, unverified) and what a receding-horizon loop wants.  Slot b of a call = problem b. */
+    int    carry_multipliers;
 } mpcmp_config;
+
+/* zero the carried multipliers of every problem slot (mpcmp_config.carry_multipliers) */
+int mpcmp_reset_multipliers(mpcmp_ctx *ctx);
 
 /* Per-problem result record; replaces mpc.info() (never read by the reference, motionPlanner.cpp:191). */
 typedef struct {

@@ -29,7 +29,7 @@ class Config(C.Structure):
                 ("ls_eta", C.c_double), ("ls_tau", C.c_double), ("hess_reg", C.c_double), ("eps_target", C.c_double),
                 ("lbx", C.c_double * 14), ("ubx", C.c_double * 14), ("lbu", C.c_double * 7), ("ubu", C.c_double * 7),
                 ("lbg", C.c_double * 8), ("ubg", C.c_double * 8), ("lbT", C.c_double), ("ubT", C.c_double),
-                ("qp_warm_start", C.c_int), ("reserved_", C.c_int)]
+                ("qp_warm_start", C.c_int), ("carry_multipliers", C.c_int)]
 
 
 class Info(C.Structure):
@@ -57,7 +57,7 @@ SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_models_from_ur
            "mpcmp_warm_start_jerk_batch", "mpcmp_warm_start_jerk_batch_device", "mpcmp_jerk_trajectory_batch",
            "mpcmp_jerk_point_batch", "mpcmp_mpc_point_batch", "mpcmp_debug_fetch",
            "mpcmp_warm_start_jerk_acc_batch", "mpcmp_warm_start_jerk_acc_batch_device", "mpcmp_jerk_trajectory_acc_batch", "mpcmp_jerk_point_acc_batch",
-           "mpcmp_warm_start_jerk_lim_batch", "mpcmp_jerk_trajectory_lim_batch", "mpcmp_jerk_point_lim_batch"]
+           "mpcmp_warm_start_jerk_lim_batch", "mpcmp_jerk_trajectory_lim_batch", "mpcmp_jerk_point_lim_batch", "mpcmp_reset_multipliers"]
 
 
 def library_path():

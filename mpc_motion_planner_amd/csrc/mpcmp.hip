@@ -85,6 +85,7 @@ struct mpcmp_ctx {
     bool capturing = false;
     // receding-horizon state (mpcmp_rh_*)
     int rh_B = 0;
+    size_t lam_count = 0;          // doubles in ws.lam (max_batch x (m + n))
     bool rh_first = true;
     hipGraph_t rh_graph = nullptr;
     hipGraphExec_t rh_exec = nullptr;
@@ -544,6 +545,7 @@ static int validate(const mpcmp_config *c, std::string &err) {
     if (c->sqp_iters < 1 || c->qp_iters < 1 || c->check_every < 1) { err = "iteration counts must be >= 1"; return MPCMP_EINVAL; }
     if (c->ls_iters < 2 || c->ls_iters > 10) { err = "ls_iters must be in [2,10]"; return MPCMP_EINVAL; }
     if (!(c->rho > 0) || !(c->sigma > 0) || !(c->alpha > 0 && c->alpha < 2)) { err = "rho, sigma > 0 and 0 < alpha < 2 required"; return MPCMP_EINVAL; }
+    if ((c->qp_warm_start != 0 && c->qp_warm_start != 1) || (c->carry_multipliers != 0 && c->carry_multipliers != 1)) { err = "qp_warm_start and carry_multipliers are 0 or 1"; return MPCMP_EINVAL; }
     return MPCMP_OK;
 }
 
@@ -668,10 +670,12 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
     WS &w = ctx->ws;
     w.model = ctx->d_model; w.ext_of_int = ctx->d_ext_of_int; w.entry_ptr = ctx->d_entry_ptr; w.terms = ctx->d_terms;
     TRY(dalloc(ctx, &w.z, B * n)); TRY(dalloc(ctx, &w.lam, B * mn)); TRY(dalloc(ctx, &w.ceq, B * ctx->meq));
+    HIPTRY(hipMemset(w.lam, 0, sizeof(double) * B * mn));        // (mpcmp_config.carry_multipliers: a fresh context starts every slot from lambda = 0)
+    ctx->lam_count = B * mn;
     TRY(dalloc(ctx, &w.g, B * 8 * N * narm)); TRY(dalloc(ctx, &w.Gk, B * N * 176 * narm)); TRY(dalloc(ctx, &w.p, B * n));
     TRY(dalloc(ctx, &w.y, B * mn)); TRY(dalloc(ctx, &w.qpit, B)); TRY(dalloc(ctx, &w.perm, B)); TRY(dalloc(ctx, &w.okey, B)); TRY(dalloc(ctx, &w.done, 4));
     HIPTRY(hipMemset(w.done, 0, 4 * sizeof(int))); TRY(dalloc(ctx, &w.qp_total, B));
-    TRY(dalloc(ctx, &w.status, B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, (size_t)B * MPCMP_DBG_WORDS));
+    TRY(dalloc(ctx, &w.status, B)); HIPTRY(hipMemset(w.status, 0, sizeof(*w.status) * B)); TRY(dalloc(ctx, &w.alpha, B)); TRY(dalloc(ctx, &w.dbg, (size_t)B * MPCMP_DBG_WORDS));
     const size_t nx = ctx->nx, nu = ctx->nu;
     TRY(dalloc(ctx, &ctx->d_x0, B * nx)); TRY(dalloc(ctx, &ctx->d_xf, B * nx));
     TRY(dalloc(ctx, &ctx->d_wx, B * nx * N)); TRY(dalloc(ctx, &ctx->d_wu, B * nu * N)); TRY(dalloc(ctx, &ctx->d_wT, B));
@@ -1356,11 +1360,22 @@ extern "C" int mpcmp_traj_stats_batch(mpcmp_ctx *ctx, int B, const double *sx, c
 // receding-horizon driver (BASELINE config #5): B instances, every step = warm-started re-solve from the previous
 // solution (re-guess rule of motionPlanner.cpp:199-207) + state advance along the new solution
 // (get_MPC_point, motionPlanner.hpp:118-128).  The fixed launch sequence of one step is captured in a hipGraph.
+extern "C" int mpcmp_reset_multipliers(mpcmp_ctx *ctx) {
+    if (!ctx) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws.lam, 0, sizeof(double) * ctx->lam_count, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws.status, 0, sizeof(*ctx->ws.status) * ctx->max_batch, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCMP_OK;
+}
+
 extern "C" int mpcmp_rh_init(mpcmp_ctx *ctx, int B, const double *x0, const double *xf) {
     if (!ctx || !x0 || !xf || B < 1) return MPCMP_EINVAL;
     if (B > ctx->max_batch) return MPCMP_ETOOBIG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws.lam, 0, sizeof(double) * ctx->lam_count, st));       // new instances: no multipliers to carry, no failed solve behind them
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws.status, 0, sizeof(*ctx->ws.status) * ctx->max_batch, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * ctx->nx * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * ctx->nx * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
@@ -1376,7 +1391,7 @@ static int rh_enqueue_step(mpcmp_ctx *ctx, double dt, bool first, hipStream_t st
     if (int rc = solve_dispatch(ctx, B, ctx->d_x0, ctx->d_xf, wx, wu, wT, ctx->d_sx, ctx->d_su, ctx->d_sT, ctx->d_info, st, 0,
                                 first ? 0 : 1))
         return rc;
-    hipLaunchKernelGGL(k_advance, dim3((B * ctx->nx + 255) / 256), dim3(256), 0, st, ctx->nseg, ctx->nx, B, dt, ctx->d_sx, ctx->d_sT, ctx->d_x0);
+    hipLaunchKernelGGL(k_advance, dim3((B * ctx->nx + 255) / 256), dim3(256), 0, st, ctx->nseg, ctx->nx, B, dt, ctx->d_sx, ctx->d_sT, ctx->ws.status, ctx->d_x0);
     HIPCHK(ctx, hipGetLastError());
     return MPCMP_OK;
 }

@@ -127,9 +127,12 @@ __global__ __launch_bounds__(512) void k_init_m(mpcmp_config cfg, const mpcmp_mo
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *zl = lds + D::oZ, *scr = lds + D::oScr;
     const int tid = threadIdx.x, b = blockIdx.x;
+    // (the slot's previous solve, as in k_init: a failed solve leaves neither a re-guess nor multipliers behind)
+    const bool prev_bad = (ws.status[b] & (MPCMP_STATUS_NAN | MPCMP_STATUS_NOT_PD | MPCMP_STATUS_XCH_DEAD | MPCMP_STATUS_T_OUT_OF_BOX)) != 0;
+    __syncthreads();
     if (tid == 0) { ws.perm[b] = b; ws.okey[b] = 0; if (b == 0) *ws.done = 0; ws.qp_total[b] = 0; ws.status[b] = 0; ws.alpha[b] = 0.0; }
     const double *x0 = ws.x0 + (size_t)b * 14 * NARM, *xf = ws.xf + (size_t)b * 14 * NARM;
-    if (warm_x) {
+    if (warm_x && !(reguess && prev_bad)) {
         for (int v = tid; v < n - 1; v += NT) {
             const int a = v / na, w = v % na;
             double val;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(512) void k_init_m(mpcmp_config cfg, const mpcmp_mo
     }
     __syncthreads();
     for (int v = tid; v < n; v += NT) ws.z[(size_t)b * n + v] = zl[v];
-    for (int i = tid; i < D::mn; i += NT) ws.lam[(size_t)b * D::mn + i] = 0.0;
+    if (!cfg.carry_multipliers || prev_bad) for (int i = tid; i < D::mn; i += NT) ws.lam[(size_t)b * D::mn + i] = 0.0;
     if (NARM == 2) for (int i = tid; i < 2 * MPCMP_XCH_STRIDE; i += NT) xch.buf[(size_t)b * 2 * MPCMP_XCH_STRIDE + i] = MPCMP_XCH_EMPTY;
     const double T = zl[n - 1];
 #pragma nounroll

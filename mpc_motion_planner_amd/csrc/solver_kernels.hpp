@@ -210,7 +210,11 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, mpcmp_
     const int tid = threadIdx.x, b = blockIdx.x;
     if (tid == 0) { ws.perm[b] = b; ws.okey[b] = 0; if (b == 0) *ws.done = 0; }     // no history yet: problems are solved in batch order
     const double *x0 = ws.x0 + 14 * b, *xf = ws.xf + 14 * b;
-    if (warm_x) {
+    // the slot's previous solve (0 in a fresh context): after a hard failure or a final time outside its box neither its iterate (re-guess of the
+    // receding-horizon loop) nor its multipliers (mpcmp_config.carry_multipliers) are a start: built-in initialiser, lambda_0 = 0
+    const bool prev_bad = (ws.status[b] & (MPCMP_STATUS_NAN | MPCMP_STATUS_NOT_PD | MPCMP_STATUS_XCH_DEAD | MPCMP_STATUS_T_OUT_OF_BOX)) != 0;
+    __syncthreads();                                      // (thread 0 resets the status word below)
+    if (warm_x && !(reguess && prev_bad)) {
         for (int v = tid; v < n; v += D::NT) {
             double val;
             if (v < 14 * N) val = warm_x[(size_t)b * 14 * N + v];
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, mpcmp_
     }
     __syncthreads();
     for (int v = tid; v < n; v += D::NT) ws.z[(size_t)b * n + v] = zl[v];
-    for (int i = tid; i < D::mn; i += D::NT) ws.lam[(size_t)b * D::mn + i] = 0.0;
+    if (!cfg.carry_multipliers || prev_bad) for (int i = tid; i < D::mn; i += D::NT) ws.lam[(size_t)b * D::mn + i] = 0.0;      // (carried: the slot's multipliers of the previous solve stay)
     if (tid == 0) { ws.qp_total[b] = 0; ws.status[b] = 0; ws.alpha[b] = 0.0; }
     linearise_block<NSEG>(cfg, &mdl, zl, scr, ws.g + (size_t)b * 8 * N, ws.Gk + (size_t)b * N * 176,
                           ws.ceq + (size_t)b * D::meq, tid);
@@ -1053,10 +1057,12 @@ __global__ __launch_bounds__(64) void k_mpc_point(const mpcmp_model *mdl, int ns
 
 // Receding horizon: x0 <- MPC solution evaluated at physical time dt (MotionPlanner::get_MPC_point, motionPlanner.hpp:118-128,
 // including its clamp: for dt >= T the normalised time is set to T, not 1).  One thread per (problem, state component).
-__global__ __launch_bounds__(256) void k_advance(int nseg, int nx, int B, double dt, const double *sx, const double *sT, double *x0) {
+// An instance whose solve failed hard or left the box of T keeps its state: there is no trajectory to follow (the next re-solve starts afresh, k_init).
+__global__ __launch_bounds__(256) void k_advance(int nseg, int nx, int B, double dt, const double *sx, const double *sT, const int *status, double *x0) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= B * nx) return;
     const int b = gid / nx, r = gid % nx, N = 3 * nseg + 1;
+    if (status[b] & (MPCMP_STATUS_NAN | MPCMP_STATUS_NOT_PD | MPCMP_STATUS_XCH_DEAD | MPCMP_STATUS_T_OUT_OF_BOX)) return;
     const double T = sT[b];
     const double t = (dt < T) ? dt / T : T;
     const double xi[4] = {-1.0, -0.5, 0.5, 1.0};

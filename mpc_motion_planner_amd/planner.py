@@ -178,6 +178,10 @@ class Solver:
         check(lib().mpcmp_traj_stats_batch(self._ctx, B, dp(sx), dp(su), dp(sT), dp(xf), int(n_pts), dp(out)), self._ctx)
         return out
 
+    def reset_multipliers(self):
+        """zero the multipliers every problem slot carries to its next solve (mpcmp_config.carry_multipliers)"""
+        check(lib().mpcmp_reset_multipliers(self._ctx), self._ctx)
+
     # -- receding horizon (BASELINE config #5)
     def rh_init(self, x0, xf):
         x0, xf = self._states(x0, xf)

@@ -449,11 +449,14 @@ static void pack(const work *w, const double *xs, const double *us, double T, do
 
 /* one OCP for narm arms (narm consecutive orc_model): x0, xf [14 narm] = [q(7 narm); qd(7 narm)], xg/xs [N][14 narm],
    ug/us [N][7 narm] */
-void orc_solve_multi(const orc_model *mdl, int narm, const orc_config *c, const double *x0, const double *xf,
-                     const double *xg, const double *ug, double Tg, double *xs, double *us, double *Tout, orc_info *info) {
+/* lam_io [m + n] (rows, then variables), may be NULL: with c->carry_multipliers the SQP starts from it instead of lambda_0 = 0 (mpcmp_config.carry_multipliers:
+   the multipliers the previous solve of the same planner left behind); the final multipliers are written back whatever the flag says */
+static void solve_core(const orc_model *mdl, int narm, const orc_config *c, const double *x0, const double *xf,
+                       const double *xg, const double *ug, double Tg, double *lam_io, double *xs, double *us, double *Tout, orc_info *info) {
     work *w = work_new(c, narm);
     int n = w->n, m = w->m, mn = m + n;
     double *z = (double *)calloc(n, sizeof(double)), *lam = (double *)calloc(mn, sizeof(double));
+    if (lam_io && c->carry_multipliers) memcpy(lam, lam_io, sizeof(double) * mn);
     double *p = (double *)calloc(n, sizeof(double)), *y = (double *)calloc(mn, sizeof(double));
     double *zs = (double *)calloc(n, sizeof(double)), *ce = (double *)calloc(w->meq, sizeof(double));
     double *gg = (double *)calloc(w->min, sizeof(double));
@@ -498,8 +501,30 @@ void orc_solve_multi(const orc_model *mdl, int narm, const orc_config *c, const 
     if (!(inf.T >= c->lbT - 1e-9 && inf.T <= c->ubT + 1e-9)) inf.status |= 32;
     memcpy(xs, z, sizeof(double) * w->nx * w->N); memcpy(us, z + w->nx * w->N, sizeof(double) * w->nu * w->N); *Tout = z[n - 1];
     if (info) *info = inf;
+    /* what the next solve of this planner may start from: nothing after a hard failure or a final time outside its box (the multipliers of a solve
+       that left the feasible region of T are not a start; mpcmp.h, carry_multipliers) */
+    if (lam_io) {
+        if (inf.status & (1 | 2 | 4 | 32)) memset(lam_io, 0, sizeof(double) * mn);
+        else memcpy(lam_io, lam, sizeof(double) * mn);
+    }
     free(z); free(lam); free(p); free(y); free(zs); free(ce); free(gg);
     work_free(w);
+}
+
+void orc_solve_multi(const orc_model *mdl, int narm, const orc_config *c, const double *x0, const double *xf,
+                     const double *xg, const double *ug, double Tg, double *xs, double *us, double *Tout, orc_info *info) {
+    solve_core(mdl, narm, c, x0, xf, xg, ug, Tg, NULL, xs, us, Tout, info);
+}
+/* a re-solve on one planner object: lam_io [m + n] in / out (m + n = orc_num_multipliers) */
+void orc_solve_carry(const orc_model *mdl, int narm, const orc_config *c, const double *x0, const double *xf,
+                     const double *xg, const double *ug, double Tg, double *lam_io, double *xs, double *us, double *Tout, orc_info *info) {
+    solve_core(mdl, narm, c, x0, xf, xg, ug, Tg, lam_io, xs, us, Tout, info);
+}
+int orc_num_multipliers(const orc_config *c, int narm) {
+    work *w = work_new(c, narm);
+    const int mn = w->m + w->n;
+    work_free(w);
+    return mn;
 }
 
 void orc_solve(const orc_model *mdl, const orc_config *c, const double *x0, const double *xf,

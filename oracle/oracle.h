@@ -66,7 +66,7 @@ typedef struct {
     double lbg[ORC_NG], ubg[ORC_NG]; /* path bounds    motionPlanner.cpp:92-98 */
     double lbT, ubT;                 /* motionPlanner.cpp:76-79                */
     int    qp_warm_start;            /* 0: every QP starts cold; 1: y_0 = lambda_k, x_0 = 0, z_0 = clip(0, l, u) (include/mpcmp.h) */
-    int    reserved_;
+    int    carry_multipliers;   /* 1: orc_solve_carry starts from the multipliers handed in (mpcmp_config.carry_multipliers) */
 } orc_config;
 
 typedef struct {
@@ -137,6 +137,10 @@ void orc_solve(const orc_model *m, const orc_config *c, const double *x0, const 
 void orc_solve_multi(const orc_model *m, int narm, const orc_config *c, const double *x0, const double *xf,
                      const double *xg, const double *ug, double Tg,
                      double *xs, double *us, double *T, orc_info *info);
+/* a re-solve on one planner object (mpcmp_config.carry_multipliers): lam_io [orc_num_multipliers] in / out; the start only with c->carry_multipliers */
+void orc_solve_carry(const orc_model *m, int narm, const orc_config *c, const double *x0, const double *xf,
+                     const double *xg, const double *ug, double Tg, double *lam_io, double *xs, double *us, double *T, orc_info *info);
+int orc_num_multipliers(const orc_config *c, int narm);
 void orc_solve_batch_multi(const orc_model *m, int narm, const orc_config *c, int B, const double *x0, const double *xf,
                            const double *xg, const double *ug, const double *Tg,
                            double *xs, double *us, double *T, orc_info *info, int threads);

@@ -25,7 +25,7 @@ class Config(C.Structure):
                 ("ls_eta", C.c_double), ("ls_tau", C.c_double), ("hess_reg", C.c_double), ("eps_target", C.c_double),
                 ("lbx", C.c_double * NX), ("ubx", C.c_double * NX), ("lbu", C.c_double * NU), ("ubu", C.c_double * NU),
                 ("lbg", C.c_double * NG), ("ubg", C.c_double * NG), ("lbT", C.c_double), ("ubT", C.c_double),
-                ("qp_warm_start", C.c_int), ("reserved_", C.c_int)]
+                ("qp_warm_start", C.c_int), ("carry_multipliers", C.c_int)]
 
 
 class Info(C.Structure):
@@ -161,6 +161,19 @@ def solve(cfg, x0, xf, xg, ug, Tg, model=None):
     lib().orc_solve(C.byref(model), C.byref(cfg), _p(x0), _p(xf), _p(xg), _p(ug), C.c_double(Tg),
                     _p(xs), _p(us), C.byref(T), C.byref(info))
     return xs, us, T.value, info
+
+
+def solve_carry(cfg, x0, xf, xg, ug, Tg, lam=None, model=None):
+    """a re-solve on one planner object: lam [m + n] in / out (None: zeros); the start only when cfg.carry_multipliers is set.  Returns xs, us, T, info, lam"""
+    model = model or default_model(); N = 3 * cfg.num_seg + 1
+    lib().orc_num_multipliers.restype = C.c_int
+    mn = lib().orc_num_multipliers(C.byref(cfg), 1)
+    lam = np.zeros(mn) if lam is None else f64(lam).copy()
+    assert lam.shape == (mn,)
+    x0, xf, xg, ug = f64(x0), f64(xf), f64(xg), f64(ug)
+    xs, us, T, info = np.zeros((N, 14)), np.zeros((N, 7)), C.c_double(0), Info()
+    lib().orc_solve_carry(C.byref(model), 1, C.byref(cfg), _p(x0), _p(xf), _p(xg), _p(ug), C.c_double(Tg), _p(lam), _p(xs), _p(us), C.byref(T), C.byref(info))
+    return xs, us, T.value, info, lam
 
 
 def solve_batch(cfg, x0, xf, xg, ug, Tg, threads=1, model=None):

@@ -310,6 +310,75 @@ def test_receding_horizon_vs_oracle(M):
     assert np.array_equal(s.rh_get()[0], xg)
 
 
+@pytest.mark.parametrize("nseg", [4, 6])
+def test_carried_multipliers_vs_oracle(M, nseg):
+    """mpcmp_config.carry_multipliers (+ qp_warm_start): (i) the receding-horizon loop, every re-solve starting from the multipliers of the one before
+    (k_qp2), eager and graph replay; (ii) re-solves through the plain solve call on one context (N = 13: k_qp2, N = 19: k_qp3f + k_qp5), reset in between;
+    against the oracle's chain with the multipliers handed from solve to solve: identical ADMM iteration counts"""
+    cfg, ocfg = _cfgs(M, nseg, 2, carry_multipliers=1, qp_warm_start=1)
+    from mpc_motion_planner_amd import scenarios
+    B, steps, dt = 4, 4, 0.02
+    x0, xf = scenarios.make_batch(B, stream_offset=900)
+    if nseg == 4:
+        xc = x0.copy(); prev = [None] * B; lam = [None] * B; its = np.zeros(B, dtype=int)
+        for st in range(steps):
+            for b in range(B):
+                if prev[b] is None or (prev[b][3] & (1 | 2 | 4 | 32)):      # (a failed solve is not a guess: built-in initialiser, as k_init does)
+                    wx, wu, wT = o.warm_start(ocfg, xc[b], xf[b])
+                else:
+                    wx, wu, wT = prev[b][0].copy(), prev[b][1], prev[b][2]
+                    wx[0] = xc[b]; wx[-1] = xf[b]
+                xs, us, T, oi, lam[b] = o.solve_carry(ocfg, xc[b], xf[b], wx, wu, wT, lam=lam[b])
+                prev[b] = (xs, us, T, oi.status); its[b] = oi.qp_iters_total
+                if not oi.status & (1 | 2 | 4 | 32):                        # (k_advance: no trajectory to follow after a failed solve)
+                    xc[b] = o.mpc_point(4, xs, us, T, dt)[:14]
+        for use_graph in (False, True):
+            s = M.Solver(cfg, B)
+            s.rh_init(x0, xf)
+            s.rh_run(steps, dt, use_graph=use_graph)
+            xg, sx, su, sT, info = s.rh_get()
+            assert np.array_equal(info["qp_iters_total"], its), (use_graph, info["qp_iters_total"], its)
+            assert np.abs(xg - xc).max() < 1e-6 and np.abs(sT - np.array([p[2] for p in prev])).max() < 1e-6
+            s.rh_init(x0, xf)                                 # (a new set of instances: nothing carried over)
+            s.rh_run(steps, dt, use_graph=use_graph)
+            assert np.array_equal(s.rh_get()[0], xg)
+    # plain solves on one context: solve, re-solve from the solution (motionPlanner.cpp:199-207), reset, solve again
+    s = M.Solver(cfg, B)
+    wx, wu, wT = s.warm_start(x0, xf)
+    sx1, su1, sT1, i1 = s.solve(x0, xf, (wx, wu, wT))
+    gx = sx1.copy(); gx[:, 0] = x0; gx[:, -1] = xf
+    sx2, su2, sT2, i2 = s.solve(x0, xf, (gx, su1, sT1))
+    s.reset_multipliers()
+    sx3, su3, sT3, i3 = s.solve(x0, xf, (wx, wu, wT))
+    assert np.array_equal(sx3, sx1) and np.array_equal(i3["qp_iters_total"], i1["qp_iters_total"])
+    for b in range(B):
+        xs, us, T, oi, lam = o.solve_carry(ocfg, x0[b], xf[b], wx[b], wu[b], wT[b])
+        assert oi.qp_iters_total == i1["qp_iters_total"][b] and abs(sT1[b] - T) <= 1e-6 * T
+        g = xs.copy(); g[0] = x0[b]; g[-1] = xf[b]
+        xs2, us2, T2, oi2, _ = o.solve_carry(ocfg, x0[b], xf[b], g, us, T, lam=lam)
+        assert oi2.qp_iters_total == i2["qp_iters_total"][b], (b, oi2.qp_iters_total, i2["qp_iters_total"][b])
+        assert abs(sT2[b] - T2) <= 1e-6 * T2 and np.abs(sx2[b] - xs2).max() <= 1e-5 and oi2.status == i2["status"][b]
+
+
+def test_receding_horizon_with_carried_multipliers_survives_the_degenerate_tail(M):
+    """configs[4] in full length (200 re-solves of 10 ms: most instances arrive, T -> 0 and the OCP degenerates) with carried multipliers: an instance whose
+    solve leaves the box of T or fails hard holds its state and restarts from the built-in guess with lambda = 0 (k_advance, k_init), so nothing is lost
+    for good: every state stays finite, no instance ends in a hard failure, and the run is bitwise repeatable"""
+    cfg, _ = _cfgs(M, 4, 2, carry_multipliers=1, qp_warm_start=1)
+    from mpc_motion_planner_amd import scenarios
+    B = 128
+    x0, xf = scenarios.make_batch(B, MARGINS)
+    s = M.Solver(cfg, B)
+    outs = []
+    for rep in range(2):
+        s.rh_init(x0, xf)
+        s.rh_run(200, 0.01, use_graph=True)
+        xg, sx, su, sT, info = s.rh_get()
+        outs.append((xg.copy(), info["status"].copy()))
+        assert np.all(np.isfinite(xg)), np.argwhere(~np.isfinite(xg))[:4]
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_traj_stats_vs_oracle(M):
     """examples/benchmark.cpp:58-160: extrema, terminal error and the four pass flags of a resampled trajectory"""
     cfg, ocfg = _cfgs(M, 4, 3)

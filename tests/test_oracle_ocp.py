@@ -1,6 +1,7 @@
 """Oracle NLP/SQP layer: discretisation facts and the one stored solve of the reference (GOLD-TRAJ)."""
 import json
 import os
+import sys
 
 import numpy as np
 
@@ -244,6 +245,37 @@ def test_jerk_limited_warm_start_boundary_accelerations():
             assert Tz == Tr and np.array_equal(ref, got)
     assert worst_a <= 1.0 + 1e-9 and worst_j <= 1.0 + 1e-6, (worst_a, worst_j)
     assert nq <= 0.2 * 200 * 7, nq
+
+
+def scenarios_pair(k):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mpc_motion_planner_amd import scenarios
+    x0, xf = scenarios.make_batch(k + 1, (0.9, 0.9, 0.5, 0.9), stream_offset=900)
+    return x0[k], xf[k]
+
+
+def test_carried_multipliers_semantics():
+    """mpcmp_config.carry_multipliers (what a re-solve on one MotionPlanner object most plausibly does upstream: polympc keeps its dual iterate until
+    lam_guess is called): flag 0 = lambda_0 = 0 whatever is handed in; flag 1 with zeros = the plain solve bit for bit; flag 1 with the
+    previous solve's multipliers = another start, and with qp_warm_start a cheaper re-solve of the same problem"""
+    x0, xf = scenarios_pair(3)
+    cfg0 = o.default_config(4, 2, margins=(0.9, 0.9, 0.5, 0.9))
+    wx, wu, wT = o.warm_start(cfg0, x0, xf)
+    xs, us, T, info = o.solve(cfg0, x0, xf, wx, wu, wT)
+    rng = np.random.default_rng(0)
+    xa, ua, Ta, ia, lam = o.solve_carry(cfg0, x0, xf, wx, wu, wT, lam=rng.normal(size=o.solve_carry(cfg0, x0, xf, wx, wu, wT)[4].shape))
+    assert np.array_equal(xa, xs) and Ta == T and ia.qp_iters_total == info.qp_iters_total and np.abs(lam).max() > 0
+    cfg1 = o.default_config(4, 2, margins=(0.9, 0.9, 0.5, 0.9), carry_multipliers=1, qp_warm_start=1)
+    cfgw = o.default_config(4, 2, margins=(0.9, 0.9, 0.5, 0.9), qp_warm_start=1)
+    xw, uw, Tw, iw = o.solve(cfgw, x0, xf, wx, wu, wT)
+    xb, ub, Tb, ib, lam1 = o.solve_carry(cfg1, x0, xf, wx, wu, wT)                 # zeros in: the plain (QP-warm-started) solve
+    assert np.array_equal(xb, xw) and Tb == Tw and ib.qp_iters_total == iw.qp_iters_total
+    # the re-solve of motionPlanner.cpp:199-207 (previous solution as the guess, end states re-pinned), with and without the carried multipliers
+    gx = xb.copy(); gx[0] = x0; gx[-1] = xf
+    xc, uc, Tc, ic, lam2 = o.solve_carry(cfg1, x0, xf, gx, ub, Tb, lam=lam1)
+    xd, ud, Td, idd = o.solve(cfgw, x0, xf, gx, ub, Tb)
+    assert not np.array_equal(xc, xd) and np.all(np.isfinite(xc)) and abs(Tc - Td) < 0.05 * Td
+    assert ic.qp_iters_total <= idd.qp_iters_total, (ic.qp_iters_total, idd.qp_iters_total)
 
 
 def test_status_word_semantics():
