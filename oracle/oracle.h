@@ -95,6 +95,10 @@ void orc_rnea(const orc_model *m, const double *q, const double *v, const double
 /* JVP-based analytic derivatives: dq,dv,M are 7x7 row-major (row = torque index) */
 void orc_rnea_derivatives(const orc_model *m, const double *q, const double *v, const double *a,
                           double *tau, double *dtau_dq, double *dtau_dv, double *M);
+/* the same partial derivatives and mass matrix in closed form (world-frame spatial algebra: the formulation of pinocchio::computeRNEADerivatives /
+   crba, robot_ocp.hpp:118-122): an independent second implementation, checked against the directional one to round-off */
+void orc_rnea_derivatives_analytic(const orc_model *m, const double *q, const double *v, const double *a,
+                                   double *tau, double *dtau_dq, double *dtau_dv, double *M);
 void orc_fk(const orc_model *m, const double *q, double *p_joint7, double *R_joint7 /*9*/,
             double *p_link8, double *p_tool);
 /* world-aligned 6x7 Jacobian of a point rigidly attached to joint 7 at local offset `off` */

@@ -262,6 +262,118 @@ void orc_rnea_derivatives(const orc_model *m, const double *q, const double *v, 
     }
 }
 
+static void fk_all(const orc_model *m, const double *q, double Rw[ORC_NJ][9], double pw[ORC_NJ][3]);
+
+/* ---------- analytic partial derivatives of RNEA (pinocchio::computeRNEADerivatives, robot_ocp.hpp:118) and the mass matrix (pinocchio::crba,
+   robot_ocp.hpp:121-122) in closed form: 6-D spatial algebra in the WORLD frame, as the published algorithm is formulated (Carpentier & Mansard,
+   "Analytical derivatives of rigid body dynamics algorithms", RSS 2018; the identities below are those of Singh, Russell & Wensing, "Efficient
+   analytical derivatives of rigid-body dynamics using spatial vector algebra", RA-L 2022).  An independent second implementation: the solver's
+   linearisation uses the directional derivatives above (rnea_jvp); tests/test_oracle_rigid_body.py checks that the two agree to round-off.
+
+   Spatial vectors at the world origin: motion [omega; v_O], force [n_O; f].  Joint i: S_i = [z_i; p_i x z_i].  With v_k = sum_{l<=k} S_l qd_l,
+   a_k = a_0 + sum_{l<=k} (S_l qdd_l + v_l x S_l qd_l), f_k = I_k a_k + v_k x* I_k v_k, tau_i = S_i^T sum_{k>=i} f_k (serial chain):
+     d v_k / d qd_j = S_j                          d a_k / d qd_j = (2 v_j - v_k) x S_j                                   (j <= k)
+     d S_l / d q_j  = S_j x S_l  (j < l)           d I_k / d q_j  = S_j x* I_k - I_k S_j x                                 (j <= k)
+     d v_k / d q_j  = S_j x (v_k - v_j)            d a_k / d q_j  = sum_{j<l<=k} [(S_j x S_l) qdd_l + (S_j x (v_l - v_j)) x S_l qd_l + v_l x (S_j x S_l) qd_l] */
+typedef struct { double w[3], v[3]; } sv6;   /* motion: (omega, v_O);  force: (n_O, f) */
+static inline sv6 sv_zero(void) { sv6 r = {{0, 0, 0}, {0, 0, 0}}; return r; }
+static inline sv6 sv_add(sv6 a, sv6 b) { for (int d = 0; d < 3; d++) { a.w[d] += b.w[d]; a.v[d] += b.v[d]; } return a; }
+static inline sv6 sv_sub(sv6 a, sv6 b) { for (int d = 0; d < 3; d++) { a.w[d] -= b.w[d]; a.v[d] -= b.v[d]; } return a; }
+static inline sv6 sv_scale(sv6 a, double s) { for (int d = 0; d < 3; d++) { a.w[d] *= s; a.v[d] *= s; } return a; }
+static inline double sv_dot(sv6 m, sv6 f) { double r = 0; for (int d = 0; d < 3; d++) r += m.w[d] * f.w[d] + m.v[d] * f.v[d]; return r; }
+static inline sv6 crm(sv6 a, sv6 m) {        /* a x m (motion) = [w x m_w; w x m_v + v x m_w] */
+    sv6 r; double t[3];
+    cross(a.w, m.w, r.w); cross(a.w, m.v, r.v); cross(a.v, m.w, t); add3(r.v, t); return r;
+}
+static inline sv6 crf(sv6 a, sv6 f) {        /* a x* f (force) = [w x n + v x f; w x f] */
+    sv6 r; double t[3];
+    cross(a.w, f.w, r.w); cross(a.v, f.v, t); add3(r.w, t); cross(a.w, f.v, r.v); return r;
+}
+typedef struct { double m, c[3], Ic[9]; } si6;   /* spatial inertia: mass, com (world, from the origin), rotational inertia about the com (world axes) */
+static inline sv6 si_mul(const si6 *I, sv6 a) {  /* I a: f = m (v + w x c);  n_O = Ic w + c x f */
+    sv6 r; double t[3];
+    cross(a.w, I->c, t);
+    for (int d = 0; d < 3; d++) r.v[d] = I->m * (a.v[d] + t[d]);
+    matvec(I->Ic, a.w, r.w); cross(I->c, r.v, t); add3(r.w, t);
+    return r;
+}
+
+void orc_rnea_derivatives_analytic(const orc_model *m, const double *q, const double *v, const double *a,
+                                   double *tau, double *dtau_dq, double *dtau_dv, double *M) {
+    const int n = ORC_NJ;
+    double Rw[ORC_NJ][9], pw[ORC_NJ][3];
+    fk_all(m, q, Rw, pw);
+    sv6 S[ORC_NJ], vel[ORC_NJ], acc[ORC_NJ], f[ORC_NJ], fC[ORC_NJ];
+    si6 I[ORC_NJ];
+    sv6 a0 = sv_zero();
+    for (int d = 0; d < 3; d++) a0.v[d] = -m->gravity[d];
+    for (int i = 0; i < n; i++) {
+        for (int d = 0; d < 3; d++) S[i].w[d] = Rw[i][3 * d + 2];
+        cross(pw[i], S[i].w, S[i].v);
+        /* inertia of body i in world axes, com from the world origin */
+        double t[3], RI[9];
+        matvec(Rw[i], m->com[i], t);
+        for (int d = 0; d < 3; d++) I[i].c[d] = pw[i][d] + t[d];
+        I[i].m = m->mass[i];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+            RI[3 * r + c] = Rw[i][3 * r + 0] * m->I[i][0 + c] + Rw[i][3 * r + 1] * m->I[i][3 + c] + Rw[i][3 * r + 2] * m->I[i][6 + c];
+        }
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+            I[i].Ic[3 * r + c] = RI[3 * r + 0] * Rw[i][3 * c + 0] + RI[3 * r + 1] * Rw[i][3 * c + 1] + RI[3 * r + 2] * Rw[i][3 * c + 2];
+        const sv6 vp = i ? vel[i - 1] : sv_zero(), ap = i ? acc[i - 1] : a0;
+        vel[i] = sv_add(vp, sv_scale(S[i], v[i]));
+        acc[i] = sv_add(ap, sv_add(sv_scale(S[i], a[i]), sv_scale(crm(vel[i], S[i]), v[i])));
+        f[i] = sv_add(si_mul(&I[i], acc[i]), crf(vel[i], si_mul(&I[i], vel[i])));
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        fC[i] = f[i];
+        if (i + 1 < n) fC[i] = sv_add(fC[i], fC[i + 1]);
+        tau[i] = sv_dot(S[i], fC[i]);
+    }
+    /* d f_k / d qd_j and d f_k / d q_j for j <= k */
+    for (int j = 0; j < n; j++) {
+        sv6 dfv_sum[ORC_NJ], dfq_sum[ORC_NJ];      /* suffix sums over k >= i of the partials of f_k */
+        sv6 dfv[ORC_NJ], dfq[ORC_NJ];
+        sv6 daq = sv_zero();                      /* running d a_k / d q_j */
+        for (int k = 0; k < n; k++) { dfv[k] = sv_zero(); dfq[k] = sv_zero(); }
+        for (int k = j; k < n; k++) {
+            const si6 *Ik = &I[k];
+            /* velocity partials */
+            const sv6 dv_v = S[j];
+            const sv6 da_v = crm(sv_sub(sv_scale(vel[j], 2.0), vel[k]), S[j]);
+            dfv[k] = sv_add(si_mul(Ik, da_v), sv_add(crf(dv_v, si_mul(Ik, vel[k])), crf(vel[k], si_mul(Ik, dv_v))));
+            /* configuration partials */
+            if (k > j) {
+                const sv6 dS = crm(S[j], S[k]);
+                const sv6 dvl = crm(S[j], sv_sub(vel[k], vel[j]));
+                daq = sv_add(daq, sv_add(sv_scale(dS, a[k]), sv_add(sv_scale(crm(dvl, S[k]), v[k]), sv_scale(crm(vel[k], dS), v[k]))));
+            }
+            const sv6 dv_q = crm(S[j], sv_sub(vel[k], vel[j]));
+            /* (dI) x = S_j x* (I x) - I (S_j x x) */
+            const sv6 dI_a = sv_sub(crf(S[j], si_mul(Ik, acc[k])), si_mul(Ik, crm(S[j], acc[k])));
+            const sv6 dI_v = sv_sub(crf(S[j], si_mul(Ik, vel[k])), si_mul(Ik, crm(S[j], vel[k])));
+            dfq[k] = sv_add(dI_a, sv_add(si_mul(Ik, daq), sv_add(crf(dv_q, si_mul(Ik, vel[k])), sv_add(crf(vel[k], dI_v), crf(vel[k], si_mul(Ik, dv_q))))));
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            dfv_sum[i] = dfv[i]; dfq_sum[i] = dfq[i];
+            if (i + 1 < n) { dfv_sum[i] = sv_add(dfv_sum[i], dfv_sum[i + 1]); dfq_sum[i] = sv_add(dfq_sum[i], dfq_sum[i + 1]); }
+        }
+        for (int i = 0; i < n; i++) {
+            dtau_dv[i * n + j] = sv_dot(S[i], dfv_sum[i]);
+            double dq_ij = sv_dot(S[i], dfq_sum[i]);
+            if (j < i) dq_ij += sv_dot(crm(S[j], S[i]), fC[i]);      /* (d S_i / d q_j)^T f_i^C */
+            dtau_dq[i * n + j] = dq_ij;
+        }
+    }
+    /* composite rigid body algorithm: M_ij = S_i^T I_i^C S_j (j <= i), I_i^C = sum_{k >= i} I_k */
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) {
+            sv6 h = sv_zero();
+            for (int k = i; k < n; k++) h = sv_add(h, si_mul(&I[k], S[j]));
+            M[i * n + j] = M[j * n + i] = sv_dot(S[i], h);
+        }
+}
+
 /* world placement of every joint frame */
 static void fk_all(const orc_model *m, const double *q, double Rw[ORC_NJ][9], double pw[ORC_NJ][3]) {
     double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};

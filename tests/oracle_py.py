@@ -98,6 +98,14 @@ def rnea_derivatives(q, v, a, model=None):
     return tau, dq, dv, M
 
 
+def rnea_derivatives_analytic(q, v, a, model=None):
+    """closed-form partials in world-frame spatial algebra (the formulation of pinocchio::computeRNEADerivatives / crba): independent of rnea_derivatives"""
+    model = model or default_model(); q, v, a = f64(q), f64(v), f64(a)
+    tau, dq, dv, M = np.zeros(7), np.zeros((7, 7)), np.zeros((7, 7)), np.zeros((7, 7))
+    lib().orc_rnea_derivatives_analytic(C.byref(model), _p(q), _p(v), _p(a), _p(tau), _p(dq), _p(dv), _p(M))
+    return tau, dq, dv, M
+
+
 def fk(q, model=None):
     model = model or default_model(); q = f64(q)
     p7, R7, p8, pt = np.zeros(3), np.zeros((3, 3)), np.zeros(3), np.zeros(3)
