@@ -379,6 +379,21 @@ def test_receding_horizon_with_carried_multipliers_survives_the_degenerate_tail(
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_more_than_255_capped_qps_are_counted(M):
+    """mpcmp_info.qp_capped used to live in eight bits of the status word and wrapped at 256: 300 SQP iterations of a QP capped at ONE
+    ADMM iteration each — every QP is capped — are counted as 300, the QP_CAPPED bit stays set, and the oracle reports the same record"""
+    cfg, ocfg = _cfgs(M, 1, 300, qp_iters=1, check_every=1)
+    from mpc_motion_planner_amd import scenarios
+    x0, xf = scenarios.make_batch(2, stream_offset=61)
+    s = M.Solver(cfg, 2)
+    wx, wu, wT = s.warm_start(x0, xf)
+    sx, su, sT, info = s.solve(x0, xf, (wx, wu, wT))
+    assert np.all(info["qp_capped"] == 300) and np.all(info["status"] & 8) and np.all(info["qp_iters_total"] == 300)
+    for b in range(2):
+        xs, us, T, oi = o.solve(ocfg, x0[b], xf[b], wx[b], wu[b], wT[b])
+        assert oi.qp_capped == 300 and oi.status == info["status"][b] and abs(sT[b] - T) <= 1e-6 * abs(T)
+
+
 def test_traj_stats_vs_oracle(M):
     """examples/benchmark.cpp:58-160: extrema, terminal error and the four pass flags of a resampled trajectory"""
     cfg, ocfg = _cfgs(M, 4, 3)
