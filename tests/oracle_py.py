@@ -226,6 +226,18 @@ def solve_multi(models, cfg, x0, xf, xg, ug, Tg):
     return xs, us, T.value, info
 
 
+def solve_carry_multi(models, cfg, x0, xf, xg, ug, Tg, lam=None):
+    """multi-arm form of solve_carry: lam [m + n] in / out (None: zeros).  Returns xs, us, T, info, lam"""
+    narm = len(models); N = 3 * cfg.num_seg + 1
+    lib().orc_num_multipliers.restype = C.c_int
+    mn = lib().orc_num_multipliers(C.byref(cfg), narm)
+    lam = np.zeros(mn) if lam is None else f64(lam).copy()
+    x0, xf, xg, ug = f64(x0), f64(xf), f64(xg), f64(ug)
+    xs, us, T, info = np.zeros((N, 14 * narm)), np.zeros((N, 7 * narm)), C.c_double(0), Info()
+    lib().orc_solve_carry(models, narm, C.byref(cfg), _p(x0), _p(xf), _p(xg), _p(ug), C.c_double(Tg), _p(lam), _p(xs), _p(us), C.byref(T), C.byref(info))
+    return xs, us, T.value, info, lam
+
+
 def solve_batch_multi(models, cfg, x0, xf, xg, ug, Tg, threads=1):
     narm = len(models); N = 3 * cfg.num_seg + 1
     x0, xf, xg, ug, Tg = f64(x0), f64(xf), f64(xg), f64(ug), f64(Tg)

@@ -72,6 +72,36 @@ def test_dual_arm_solve_vs_oracle(M, nseg, sqp, B, warm):
         assert abs(info["term_err_inf"][b] - oi.term_err_inf) < 1e-6
 
 
+def test_dual_arm_carried_multipliers_vs_oracle(M):
+    """mpcmp_config.carry_multipliers + qp_warm_start on the dual-arm OCP (N = 19, k_qp3<6, 2>): a solve and its re-solve from the solution with the end
+    states re-pinned (motionPlanner.cpp:199-207), the second one starting from the multipliers of the first: identical ADMM iteration counts and status
+    words against orc_solve_carry; after mpcmp_reset_multipliers the first solve again, bit for bit"""
+    nseg, sqp, B = 6, 2, 2
+    cfg = M.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=1, carry_multipliers=1)
+    ocfg = o.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=1, carry_multipliers=1)
+    x0, xf = dual_states(B, off=77)
+    s = M.Solver(cfg, B, models=M.arm_models(M.DUAL_BASES))
+    N = 3 * nseg + 1
+    wx = np.zeros((B, N, 28)); wu = np.zeros((B, N, 14)); wT = np.zeros(B)
+    for b in range(B):
+        wx[b], wu[b], wT[b] = o.warm_start_jerk_multi(nseg, *_limits(), x0[b], xf[b])
+    sx1, su1, sT1, i1 = s.solve(x0, xf, (wx, wu, wT))
+    gx = sx1.copy(); gx[:, 0] = x0; gx[:, -1] = xf
+    sx2, su2, sT2, i2 = s.solve(x0, xf, (gx, su1, sT1))
+    s.reset_multipliers()
+    sx3, su3, sT3, i3 = s.solve(x0, xf, (wx, wu, wT))
+    assert np.array_equal(sx3, sx1) and np.array_equal(i3["qp_iters_total"], i1["qp_iters_total"])
+    models = o.arm_models(o.DUAL_BASES)
+    for b in range(B):
+        xs, us, T, oi, lam = o.solve_carry_multi(models, ocfg, x0[b], xf[b], wx[b], wu[b], wT[b])
+        assert oi.qp_iters_total == i1["qp_iters_total"][b] and abs(sT1[b] - T) <= 1e-6 * T
+        g = xs.copy(); g[0] = x0[b]; g[-1] = xf[b]
+        xs2, us2, T2, oi2, _ = o.solve_carry_multi(models, ocfg, x0[b], xf[b], g, us, T, lam=lam)
+        assert oi2.qp_iters_total == i2["qp_iters_total"][b] and oi2.status == i2["status"][b], (b, oi2.qp_iters_total, i2["qp_iters_total"][b])
+        assert abs(sT2[b] - T2) <= 1e-6 * T2 and np.abs(sx2[b] - xs2).max() <= 1e-5
+        assert oi2.qp_iters_total != oi.qp_iters_total or not np.array_equal(xs2, xs)      # (the re-solve is another solve)
+
+
 def test_single_arm_n25_builtin_warm_start_and_reguess(M):
     """N = 25 single arm runs on the same kernels (k_init_m / k_qp3 / k_step_m): built-in quintic initialiser, receding horizon"""
     cfg = M.default_config(8, 2, margins=MARGINS); ocfg = o.default_config(8, 2, margins=MARGINS)
