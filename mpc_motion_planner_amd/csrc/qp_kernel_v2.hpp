@@ -220,6 +220,7 @@ struct Qp2Ctx {
 #ifndef MPCMP_ABL
 #define MPCMP_ABL 0
 #endif
+#define ABL_ON(n) (MPCMP_ABL != (n) && MPCMP_ABL != 10)      /* 10: every piece off — the bare five-barrier loop with its termination tests */
 #ifdef MPCMP_STAMPS
 // the accumulators of the loop stamps live in LDS: role A1 has no registers to spare
 #define STAMP2(slot) do { if (c.tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
@@ -315,7 +316,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
     STAMP2(12);                 // role prologue: register blocks fetched from the factor scratch, constants published
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: wave 0 sums the T column of A^T w ----
-        if (tid < 64 && MPCMP_ABL != 4) {
+        if (tid < 64 && ABL_ON(4)) {
             // all operand reads in flight at once (a rolled loop serialises one LDS round trip per 64 rows)
             constexpr int NR = (meq + 63) / 64;
             double tv[NR + 1];
@@ -337,7 +338,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
             constexpr int JS = 4;                                          // 16-byte operand pairs taken in P1
             double a0 = 0.0, a1 = 0.0;
             D2 bv[7];
-            if (MPCMP_ABL != 6) {
+            if (ABL_ON(6)) {
 #pragma unroll
                 for (int j = 0; j < JS; j++) bv[j] = lds2(bj + 2 * j);
 #pragma unroll
@@ -348,7 +349,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
             }
             BUSY_SYNC(1);
             STAMP2(4);
-            if (MPCMP_ABL != 9) {
+            if (ABL_ON(9)) {
 #pragma unroll
                 for (int j = JS; j < 7; j++) bv[j] = lds2(bj + 2 * j);
 #pragma unroll
@@ -363,7 +364,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         BUSY_SYNC(2);
         STAMP2(5);
         // ---- P3 ----
-        if (MPCMP_ABL != 8) {
+        if (ABL_ON(8)) {
             double a0 = 0.0, a1 = 0.0;
             D2 xv[4];
 #pragma unroll
@@ -529,7 +530,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         // ---- A (role B) ----
         BUSY_SYNC(0);
         // ---- P1 ----
-        if (MPCMP_ABL != 5) {
+        if (ABL_ON(5)) {
             double a0 = 0.0, a1 = 0.0;
             D2 bv[7];
 #pragma unroll
@@ -561,7 +562,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         // ---- E: z~ = A x~, relaxation, projection, dual update ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
-        if (isPath && MPCMP_ABL != 2) {
+        if (isPath && ABL_ON(2)) {
             path_rows(p0, p1, xn, lds + L::oGp, [&](double zt) -> double {
                 double w = 0.0;
                 if (ownsRow) {
@@ -759,7 +760,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     BUSY_DECL;
     for (it = 1; it <= cfg.qp_iters; it++) {
         // ---- A: rhs = sigma x - q + rho_b zb - yb + A^T w ----
-        if (isVar && MPCMP_ABL != 3) {
+        if (isVar && ABL_ON(3)) {
             const double sx = sigma * x, bz = v_rb * zb - yb;      // q is zero except for T (cost = T)
             if (isT) lds[v_rpos] = (sx - 1.0) + bz;      // b_T; its column sum and coupling terms are added by roles A1/A2
             else lds[v_rpos] = (sx + bz) + col_gather(wg, lds + L::oGp);
@@ -768,7 +769,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         // ---- P1: (group A) ----
         BUSY_SYNC(1);
         // ---- P2: x_I = S^-1 r_I  (2 rows x 10 columns per lane, 8-lane reduction; r_I was completed by role A2) ----
-        if (isP2 && MPCMP_ABL != 7) {
+        if (isP2 && ABL_ON(7)) {
             double a0 = 0.0, a1 = 0.0;
             const double *rv = rI + part2 * 10;
             D2 r[5];
@@ -798,7 +799,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         // ---- E: variables and dynamics rows ----
         const bool check = (--until_check == 0);
         if (check) until_check = cfg.check_every;
-        if (MPCMP_ABL == 1) {
+        if (MPCMP_ABL == 1 || MPCMP_ABL == 10) {
         } else if (waveDyn) {
             // waves whose lanes own dynamics rows (all of them also own a variable): one straight-line block, so the two
             // independent update chains interleave; lanes past the last row compute on row 0's operands and store nothing
