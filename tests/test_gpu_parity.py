@@ -494,6 +494,27 @@ def test_headline_configuration_full_size(M):
         assert info["qp_iters_total"][b] == oi.qp_iters_total
 
 
+@pytest.mark.parametrize("nseg,sqp", [(4, 3), (6, 2)])
+def test_ragged_batch_sizes_around_the_two_stream_split(M, nseg, sqp):
+    """a batch of 512 problems or more is solved as parts on several streams (mpcmp.hip: solve_impl): sizes that do not split evenly (513, 1023), the
+    threshold itself and one below it (512, 511), a single problem, and a context used below its capacity — every problem's result is the one it has
+    in the full batch, bit for bit, whatever the split it travels in (N = 13: k_qp2, N = 19: k_qp3f + k_qp5)"""
+    cfg, _ = _cfgs(M, nseg, sqp)
+    from mpc_motion_planner_amd import scenarios
+    Bmax = 1023
+    x0, xf = scenarios.make_batch(Bmax, stream_offset=5000)
+    s = M.Solver(cfg, 1024)
+    sx, su, sT, info = s.solve(x0, xf)
+    assert np.all((info["status"] & 7) == 0) and np.all(np.isfinite(sx))
+    for B in (1, 511, 512, 513):
+        sxb, sub, sTb, ib = s.solve(x0[:B], xf[:B])
+        assert np.array_equal(sTb, sT[:B]) and np.array_equal(sxb, sx[:B]) and np.array_equal(sub, su[:B]), B
+        assert np.array_equal(ib["qp_iters_total"], info["qp_iters_total"][:B]) and np.array_equal(ib["status"], info["status"][:B])
+    off = 700                                                      # the tail of the batch as a batch of its own: other slots, other part
+    sxt, _, sTt, it = s.solve(x0[off:], xf[off:])
+    assert np.array_equal(sTt, sT[off:]) and np.array_equal(sxt, sx[off:]) and np.array_equal(it["qp_iters_total"], info["qp_iters_total"][off:])
+
+
 def test_reference_as_shipped_configuration_full_size(M):
     """BASELINE.json configs[0] depth at batch size (1024 problems, N = 19, 2 SQP iterations: robot_ocp.hpp:32, motionPlanner.cpp:15) from
     the jerk-limited warm start, through k_qp3f (Schur products on the matrix cores) + k_qp3: every problem reported ok, bitwise
