@@ -209,69 +209,183 @@ def cpu_baseline(nseg, sqp, x0, xf, warm, n_multi, n_single, qp_warm_start=0):
                       % (n_multi, threads, dt_multi, n_single, dt_single, nproc)}, T
 
 
-def bench_receding_horizon(args, M, scenarios, local, qp_warm_start=None, carry_multipliers=None):
-    """BASELINE.json configs[4]: 512 parallel Panda instances x 200 warm-started re-solves, hipGraph-captured step.
-    (reference-as-shipped solver depth: 2 SQP iterations per re-solve, motionPlanner.cpp:15; N = 13; dt = 10 ms)"""
+RH_REC = 18      # doubles per instance in the receding-horizon gather: final state (14) | T | status | ADMM iterations of the last re-solve | spare
+
+
+def rh_shard(args, rank, world, B):
+    """configs[4] across ranks (no collective inside the loop, gather only final statistics): weak = B instances PER rank,
+    strong = B instances in the whole job; rank r owns the contiguous slice [lo, hi) of the global seeded instance list"""
+    from mpc_motion_planner_amd import sharding
+    total = sharding.global_total(args.scaling, B, world)
+    lo, hi = sharding.shard_bounds(rank, world, total)
+    return total, lo, hi
+
+
+def rh_collect(rank, world, dist, device, total, x_final, sT, status, qp_iters, done, arrived, elapsed):
+    """after the loop: ONE gather of the per-instance final records to rank 0, one sum of the two per-rank counters, the maximum of the ranks'
+    loop times.  Returns (records [total][RH_REC] on rank 0 else None, done_total, arrived_total, elapsed_max).  CPU stub and GPU ranks share it."""
+    import torch
+    from mpc_motion_planner_amd import sharding
+    c = x_final.shape[0]
+    rows = torch.zeros(c, RH_REC, dtype=torch.float64)
+    rows[:, :14] = torch.as_tensor(np.asarray(x_final, dtype=np.float64)); rows[:, 14] = torch.as_tensor(np.asarray(sT, dtype=np.float64))
+    rows[:, 15] = torch.as_tensor(np.asarray(status, dtype=np.float64)); rows[:, 16] = torch.as_tensor(np.asarray(qp_iters, dtype=np.float64))
+    sb = sharding.ShardedBatch(total, rank, world, 13, device, dist, width=RH_REC)
+    assert sb.count == c
+    sb.gather_rows(rows.to(device))
+    cnt = torch.tensor([float(done), float(arrived), 0.0], dtype=torch.float64, device=device)
+    tmax = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rec = sb.assemble().cpu().numpy() if rank == 0 else None
+    return rec, int(cnt[0].item()), int(cnt[1].item()), float(tmax.item())
+
+
+def bench_receding_horizon(args, M, scenarios, rank, world, local, dist, flags=None, B=None):
+    """BASELINE.json configs[4]: 512 parallel Panda instances x 200 warm-started re-solves, hipGraph-captured step, sharded over the ranks.
+    (reference-as-shipped solver depth: 2 SQP iterations per re-solve, motionPlanner.cpp:15; N = 13; dt = 10 ms.)  flags: None = the driver's
+    defaults (carried multipliers + warm QP duals + arrival, include/mpcmp.h mpcmp_rh_run), "cold" = both start flags off (-1)."""
+    import torch
     nseg, sqp = 4, 2
-    B, resolves, dt = 512, 200, 0.01
-    qws = int(getattr(args, "qp_warm_start", False)) if qp_warm_start is None else int(qp_warm_start)
-    carry = int(getattr(args, "carry_multipliers", False)) if carry_multipliers is None else int(carry_multipliers)
-    cfg = M.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws, carry_multipliers=carry)
-    s = M.Solver(cfg, B, device=local)
-    x0, xf = scenarios.make_batch(B, MARGINS)
-    out, admm = {}, {}
+    resolves, dt = 200, 0.01
+    total, lo, hi = rh_shard(args, rank, world, B or args.batch or 512)
+    Bl = hi - lo
+    fl = -1 if flags == "cold" else 0
+    cfg = M.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=fl, carry_multipliers=fl)
+    s = M.Solver(cfg, max(Bl, 1), device=local)
+    x0, xf = scenarios.make_batch(Bl, MARGINS, stream_offset=lo)
+    dev = torch.device("cuda", local)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    out, live = {}, {}
     kname = k_ms = k_n = None
-    for graph in (False, True):
+    for graph in ((False, True) if world == 1 else (True,)):
         s.rh_init(x0, xf)
         s.rh_run(2, dt, use_graph=graph)              # first (cold) solve + graph instantiation are warm-up
+        d0 = s.rh_stats()[0]
         if not graph:
             s.kernel_timing(reset=True)               # HIP events around the QP launches (eager mode only; a graph replay has none)
+        sync()
         t0 = time.perf_counter()
-        s.rh_run(resolves, dt, use_graph=graph)
+        s.rh_run(resolves, dt, use_graph=graph)       # (synchronises its stream before it returns)
+        sync()
         el = time.perf_counter() - t0
         if not graph:
             kname, k_ms, k_n = s.kernel_timing(reset=True)
-        out["graph" if graph else "eager"] = B * resolves / el
+        out["graph" if graph else "eager"] = el
+        live["graph" if graph else "eager"] = s.rh_stats()[0] - d0
     xg, sx, su, sT, info = s.rh_get()
+    done, arrived = s.rh_stats()
+    rec, done_all, arrived_all, el_max = rh_collect(rank, world, dist, dev, total, xg, sT, info["status"], info["qp_iters_total"], live["graph"], arrived, out["graph"])
+    if rank != 0:
+        return None
     N = 3 * nseg + 1
-    admm_per_resolve = float(info["qp_iters_total"].mean())           # of the last re-solve
+    st_all = rec[:, 15].astype(np.int64)
+    alive = (st_all & 64) == 0
+    value = total * resolves / el_max                                  # instance-steps per second, arrived instances included (they cost nothing)
+    live_value = done_all / el_max                                     # re-solves actually executed per second
+    admm_per_resolve = float(rec[:, 16].mean())                        # of every instance's last executed re-solve
     flops = canonical_flops(N, sqp, admm_per_resolve)
     cc_rh = committed_counters("batch")
-    line = {"metric": "re-solves/sec, receding-horizon MPC, 512 instances x 200 warm-started re-solves", "value": out["graph"],
-            "unit": "re-solves/s", "n_gpus": 1, "steps": resolves, "warmup": 2, "ms_per_step": 1e3 * B / out["graph"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "eager_value": out["eager"], "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "512 Panda instances x 200 re-solves, N=13, 2 SQP iters/re-solve, dt=10 ms, hipGraph replay of the two-stream step "
-                                   "(BASELINE.json configs[4])"},
-            "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": out["graph"] * flops / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (out["graph"] * admm_per_resolve * cc_rh["flops_per_admm_iter"] / 1e12 / FP64_PEAK_TFLOPS) if (cc_rh and not cc_rh["stale"]) else None,
-                         "frac_def": "FP64 flops the QP kernel executed (instruction counters of the N = 13 kernel x 64 lanes, inactive lanes counted: an upper bound) over the wall clock / peak; null when the committed counter profile is stale (executed_source.stale)",
+    line = {"metric": "re-solves/sec, receding-horizon MPC, 512 instances x 200 warm-started re-solves", "value": value,
+            "unit": "re-solves/s", "n_gpus": world, "steps": resolves, "warmup": 2, "ms_per_step": 1e3 * el_max / resolves,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "live_resolves_per_s": live_value, "resolves_executed": done_all, "instances_arrived": arrived_all,
+            "eager_value": (Bl * resolves / out["eager"]) if "eager" in out else None,
+            "config": {"workload": "%d Panda instances %s x 200 re-solves, N=13, 2 SQP iters/re-solve, dt=10 ms, hipGraph replay of the two-stream step, %s "
+                                   "(BASELINE.json configs[4])" % (total if args.scaling == "strong" else Bl, "in the whole job" if args.scaling == "strong" else "per GPU",
+                                                                  "start flags off (-1): every re-solve from lambda = 0, cold QPs" if flags == "cold"
+                                                                  else "driver defaults: carried multipliers, warm QP duals, arrival handling"),
+                       "instances_total": total, "instances_rank0": Bl, "rccl_world_size": world, "flags": flags or "default"},
+            "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": live_value * flops / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (live_value / world * admm_per_resolve * cc_rh["flops_per_admm_iter"] / 1e12 / FP64_PEAK_TFLOPS) if (cc_rh and not cc_rh["stale"]) else None,
+                         "frac_def": "FP64 flops the QP kernel executed on LIVE re-solves (instruction counters of the N = 13 kernel x 64 lanes, inactive lanes counted: an upper bound) per GPU over the wall clock / peak; null when the committed counter profile is stale (executed_source.stale)",
                          "executed_source": cc_rh,
-                         "canonical_frac": out["graph"] * flops / 1e12 / FP64_PEAK_TFLOPS, "traffic": None, "mfma_busy": 0.0,
+                         "canonical_frac": live_value / world * flops / 1e12 / FP64_PEAK_TFLOPS, "traffic": None, "mfma_busy": 0.0,
                          "avg_launch_ms_eager": (k_ms / max(k_n, 1)) if k_n else None, "launches_eager": k_n,
                          "admm_iters_per_resolve": admm_per_resolve, "canonical_gflop_per_resolve": flops / 1e9,
-                         "note": "whole re-solve on the wall clock (canonical dense-equivalent flops, SURVEY.md 8d); the kernel uses no MFMA"},
-            "quality": dict(status_fractions(info["status"]), T_mean_remaining=float(np.nanmean(sT)), T_nan_frac=float(np.isnan(sT).mean()))}
-    if not args.no_cpu_baseline:
-        # CPU baseline: the oracle's re-solve (2 SQP iterations from the previous solution) on a sample of the instances
+                         "note": "live re-solves on the wall clock (canonical dense-equivalent flops, SURVEY.md 8d); the kernel uses no MFMA"},
+            "quality": dict(status_fractions(st_all & 63), arrived_frac=float((~alive).mean()),
+                            T_mean_remaining_live=float(np.nanmean(rec[alive, 14])) if alive.any() else 0.0,
+                            T_nan_frac=float(np.isnan(rec[:, 14]).mean()), state_nonfinite_frac=float((~np.isfinite(rec[:, :14]).all(axis=1)).mean()),
+                            note="status of every instance's LAST executed re-solve (an arrived instance keeps the record of the solve it arrived with)")}
+    if world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle's loop (same rule: re-guess, carried multipliers, advance + arrival) on a bounded sample of the instances
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_py as o
-        ocfg = o.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=qws, carry_multipliers=carry)
-        ns, reps = 16, 8
+        on = 0 if flags == "cold" else 1
+        ocfg = o.default_config(nseg, sqp, margins=MARGINS, qp_warm_start=on, carry_multipliers=on)
+        ns, reps, nsolve = 24, 40, 0
         t0 = time.perf_counter()
         for b in range(ns):
-            wx, wu, wT = o.warm_start(ocfg, x0[b], xf[b]); xc = x0[b].copy(); lam = None
+            wx, wu, wT = o.rh_start_guess(ocfg, x0[b], xf[b]); xc = x0[b].copy(); lam = None
             for r in range(reps):
                 xs, us, T, oi, lam = o.solve_carry(ocfg, xc, xf[b], wx, wu, wT, lam=lam)
+                nsolve += 1
+                xc, retired = o.rh_advance(ocfg, xs, us, T, oi.status, dt, xf[b], xc)
+                if retired:
+                    break
                 if oi.status & (1 | 2 | 4 | 32):                  # a failed solve is neither a trajectory to follow nor a guess (k_advance, k_init)
-                    wx, wu, wT = o.warm_start(ocfg, xc, xf[b])
+                    wx, wu, wT = o.rh_start_guess(ocfg, xc, xf[b])
                 else:
-                    xc = o.mpc_point(nseg, xs, us, T, dt)[:14]
                     wx, wu, wT = xs.copy(), us, T
                     wx[0] = xc; wx[-1] = xf[b]
         el = time.perf_counter() - t0
-        line["cpu_baseline"] = {"value": ns * reps / el, "unit": "re-solves/s", "cores": 1, "kind": "port", "single_thread": ns * reps / el,
-                                "nproc": os.cpu_count(), "sample": "oracle, %d instances x %d re-solves, 1 thread, %.1f s" % (ns, reps, el)}
+        line["cpu_baseline"] = {"value": nsolve / el, "unit": "re-solves/s", "cores": 1, "kind": "port", "single_thread": nsolve / el,
+                                "nproc": os.cpu_count(), "sample": "oracle loop (same rule), %d instances x <= %d re-solves = %d re-solves, 1 thread, %.1f s" % (ns, reps, nsolve, el)}
     return line
+
+
+def stub_rh_rank(args, rank, world):
+    """CPU stand-in of one rank of the receding-horizon workload (tests/test_bench_launcher.py): gloo instead of RCCL, the CPU oracle's loop as the
+    stand-in of the device loop on a few instances — the sharding, the single gather of final records, the counter sum and the max-over-ranks time
+    are the code of the real bench (rh_shard, rh_collect)."""
+    import torch
+    import torch.distributed as dist
+    from mpc_motion_planner_amd import scenarios
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py as o
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, lo, hi = rh_shard(args, rank, world, args.batch or 2)
+    x0, xf = scenarios.make_batch(hi - lo, MARGINS, stream_offset=lo)
+    ocfg = o.default_config(4, 1, margins=MARGINS, qp_iters=50, carry_multipliers=1, qp_warm_start=1)
+    dt, c = 0.4, hi - lo
+    xfin, sT, st, its, done, arrived = np.zeros((c, 14)), np.zeros(c), np.zeros(c), np.zeros(c), 0, 0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for b in range(c):
+        wx, wu, wT = o.rh_start_guess(ocfg, x0[b], xf[b]); xc = x0[b].copy(); lam = None
+        for r in range(args.steps):
+            xs, us, T, oi, lam = o.solve_carry(ocfg, xc, xf[b], wx, wu, wT, lam=lam)
+            done += 1
+            xc, retired = o.rh_advance(ocfg, xs, us, T, oi.status, dt, xf[b], xc)
+            sT[b], st[b], its[b] = T, oi.status | (64 if retired else 0), oi.qp_iters_total
+            if retired:
+                arrived += 1
+                break
+            wx, wu, wT = xs.copy(), us, T
+            wx[0] = xc; wx[-1] = xf[b]
+        xfin[b] = xc
+    if world > 1:
+        dist.barrier()
+    rec, done_all, arrived_all, el = rh_collect(rank, world, dist if world > 1 else None, torch.device("cpu"), total, xfin, sT, st, its, done, arrived,
+                                                time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "stub (launcher self-test of the rh workload, no GPU work)", "value": total * args.steps / max(el, 1e-9), "unit": "re-solves/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling, "stub": True,
+                          "resolves_executed": done_all, "instances_arrived": arrived_all,
+                          "records": rec.tolist(), "config": {"instances_total": total, "rccl_world_size": world, "backend": "gloo"}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def launch_ranks(n, argv):
@@ -344,7 +458,7 @@ def main():
     ap.add_argument("--workload", choices=["batch", "rh", "shipped", "dual14"], default="batch",
                     help="batch: BASELINE configs[1] (default, the contract line); rh: configs[4] receding horizon; shipped: the reference-as-shipped "
                          "solver depth (N=19, 2 SQP iterations; SURVEY.md 8d); dual14: configs[3], 14-DoF dual-Panda, N=25")
-    ap.add_argument("--carry-multipliers", action="store_true", help="rh workload: mpcmp_config.carry_multipliers = 1 (a re-solve starts from the multipliers of the one before; opt-in)")
+    ap.add_argument("--rh-cold", action="store_true", help="rh workload: both start flags off (-1): every re-solve from lambda = 0 with cold QPs; default = the driver's defaults (carried multipliers, warm QP duals)")
     ap.add_argument("--qp-warm-start", action="store_true", help="mpcmp_config.qp_warm_start = 1 (opt-in: QPs start from the NLP multipliers); the contract line keeps the default 0")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the brief runs of the three other workloads")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # launcher self-test on a CPU-only box (gloo, no solve)
@@ -358,7 +472,7 @@ def main():
     if args.gpus != world:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE = %d" % (args.gpus, world))
     if args.stub_cpu:
-        return stub_rank(args, rank, world)
+        return stub_rh_rank(args, rank, world) if args.workload == "rh" else stub_rank(args, rank, world)
 
     import torch
     import mpc_motion_planner_amd as M
@@ -374,7 +488,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     if args.workload == "rh":
-        line = bench_receding_horizon(args, M, scenarios, local)
+        line = bench_receding_horizon(args, M, scenarios, rank, world, local, dist, flags="cold" if args.rh_cold else None)
     elif args.workload == "dual14":
         import bench_dual14
         line = bench_dual14.run(args, rank, world, local, dist)
@@ -386,8 +500,8 @@ def main():
         sec = {}
         for name, fn in (("batch_qp_warm_start", lambda: run_batch_workload(args, "batch", 5, 1, 0, 1, local, None, 128, 1024, host_to_host=False, qp_warm_start=1)),
                          ("shipped", lambda: run_batch_workload(args, "shipped", 5, 1, 0, 1, local, None, 128, 1024, host_to_host=False)),
-                         ("rh", lambda: bench_receding_horizon(args, M, scenarios, local)),
-                         ("rh_carry_multipliers", lambda: bench_receding_horizon(args, M, scenarios, local, qp_warm_start=1, carry_multipliers=1)),
+                         ("rh", lambda: bench_receding_horizon(args, M, scenarios, 0, 1, local, None, B=512)),
+                         ("rh_cold", lambda: bench_receding_horizon(args, M, scenarios, 0, 1, local, None, flags="cold", B=512)),
                          ("dual14", lambda: bench_dual14.run(args, 0, 1, local, None, steps=2, warmup=1, batch=4096))):
             t0 = time.perf_counter()
             try:
@@ -397,6 +511,9 @@ def main():
                                           if k in d["roofline"]},
                              "cpu_baseline": {k: d["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "single_thread")} if "cpu_baseline" in d else None,
                              "quality": d.get("quality"), "config": d["config"]["workload"], "wall_s": time.perf_counter() - t0}
+                for k in ("live_resolves_per_s", "resolves_executed", "instances_arrived"):
+                    if k in d:
+                        sec[name][k] = d[k]
             except Exception as e:      # a secondary workload must never cost the contract line
                 sec[name] = {"error": repr(e)}
         line["secondary"] = sec
@@ -521,6 +638,7 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
                                  "`launches_in_flight` launches overlap, so avg_launch_ms is not exclusive GPU time; mfma_busy is that of the dominant kernel (the ADMM loop has one right-hand side per problem and issues no MFMA); "
                                  "for N >= 19 the factorisation kernel k_qp3f runs the QP's block GEMMs (Schur complement products) on the matrix cores: mfma_factor_kernel"},
             "quality": {**status_fractions(inf["status"]), "feasible_frac": float(feasible.mean()),
+                        "feasible_traj_per_s": value * float(feasible.mean()),
                         "T_mean": float(inf["T"].mean()),
                         "defect_inf_median": float(np.median(inf["defect_inf"])),
                         "term_err_inf_median": float(np.median(inf["term_err_inf"])),

@@ -127,7 +127,7 @@ def run(args, rank, world, local, dist, steps=None, warmup=None, batch=None):
                      "note": "canonical dense-equivalent FP64 flops of the whole 1051-variable QP (SURVEY.md 8d) per GPU over the wall clock; the "
                              "kernel exploits that the KKT matrix is two arm blocks bordered by T, so its executed flops are about a quarter of "
                              "the dense-equivalent count"},
-        "quality": {**Bn.status_fractions(inf["status"]), "feasible_frac": float(feasible.mean()), "T_mean": float(inf["T"].mean()),
+        "quality": {**Bn.status_fractions(inf["status"]), "feasible_frac": float(feasible.mean()), "feasible_traj_per_s": value * float(feasible.mean()), "T_mean": float(inf["T"].mean()),
                     "defect_inf_median": float(np.median(inf["defect_inf"])), "term_err_inf_median": float(np.median(inf["term_err_inf"])),
                     "path_viol_inf_max": float(inf["path_viol_inf"].max())},
     }

@@ -73,12 +73,12 @@ typedef struct {
      * x = z = y = 0; 1 = warm duals: y_0 = the NLP multipliers lambda_k, x_0 = 0, z_0 = clip(0, l, u).  On the headline batch the warm start
      * nearly halves the ADMM iterations per trajectory with better feasibility; the stored reference solve is ONE SQP iteration
      * and cannot tell the two apart. */
-    int    qp_warm_start;
+    int    qp_warm_start;    /* also -1: off everywhere, including the receding-horizon driver (whose default is ON, see mpcmp_rh_run) */
     /* Multipliers at the start of a solve.  0 (default) = lambda_0 = 0 for every problem of every call (independent problems: the batch semantics).
      * 1 = the multipliers a problem slot was left with by the context's previous solve are the start of the next one (zero in a fresh context and
      * after mpcmp_reset_multipliers / mpcmp_rh_init): what a re-solve on ONE MotionPlanner object most plausibly does upstream (polympc keeps its
      * dual iterate until lam_guess is called: SURVEY.md 3.2, unverified) and what a receding-horizon loop wants.  Slot b of a call = problem b. */
-    int    carry_multipliers;
+    int    carry_multipliers; /* also -1: off everywhere, including the receding-horizon driver (whose default is ON, see mpcmp_rh_run) */
 } mpcmp_config;
 
 /* zero the carried multipliers of every problem slot (mpcmp_config.carry_multipliers) */
@@ -106,6 +106,8 @@ typedef struct {
 #define MPCMP_STATUS_OUTSIDE_TOL 16   /* returned iterate outside tolerance: collocation defect or path violation > eps_abs,
                                          or terminal error > eps_target + eps_abs                                           */
 #define MPCMP_STATUS_T_OUT_OF_BOX 32  /* final time outside [lbT, ubT]                                                       */
+#define MPCMP_STATUS_ARRIVED      64  /* receding-horizon driver only: the instance has arrived and is no longer re-solved; the
+                                         other bits and fields of the record are those of its last solve (mpcmp_rh_run)       */
 
 /* ---- configuration helpers (host, no GPU needed) ---- */
 int mpcmp_default_model(mpcmp_model *m);                                    /* Panda arm, panda_arm.urdf */
@@ -243,11 +245,26 @@ int mpcmp_traj_stats_batch(mpcmp_ctx *ctx, int B, const double *sol_x, const dou
 /* ---- receding-horizon driver (BASELINE.json config #5) ---- */
 /* B instances; every step = re-solve warm-started from the previous solution with the reference's re-guess rule
  * (head := current state, tail := target; motionPlanner.cpp:199-207), then the current state advances along the
- * new solution by dt (MotionPlanner::get_MPC_point, motionPlanner.hpp:118-128).  The first step uses the built-in
- * initialiser.  use_graph != 0 replays one hipGraph-captured step (fixed iteration counts: no host round trip). */
+ * new solution by dt (MotionPlanner::get_MPC_point, motionPlanner.hpp:118-128).  The first step starts from the
+ * jerk-limited trajectory (below).  use_graph != 0 replays one hipGraph-captured step (fixed iteration counts: no host round trip). */
 int mpcmp_rh_init(mpcmp_ctx *ctx, int B, const double *x0, const double *xf);
+/* Arrival.  The reference's re-solve loop has no end (the caller of solve_trajectory(false) decides, motionPlanner.cpp:199-207), and an OCP whose
+ * start already lies in its terminal box degenerates (T -> lbT = 0).  After every solve the driver therefore RETIRES an instance
+ *   - whose plan ends within the control period (T <= dt): it follows the plan to its last node first, or
+ *   - whose advanced state lies inside the terminal box, |x - x_target|_inf <= eps_target (motionPlanner.hpp:44).
+ * A retired instance keeps its state, last solution and record (status |= MPCMP_STATUS_ARRIVED) and is not re-solved: its workgroups return
+ * at once.  An instance whose solve failed hard (NaN, lost positive definiteness, dead exchange) or left the box of T holds its state and
+ * re-solves from the driver's start guess with zero multipliers.
+ * Start guess of the driver (first solve of every instance, and such restarts): the jerk-limited time-synchronised trajectory from the current
+ * state to the target — what the reference takes from Ruckig for solve_trajectory(true), motionPlanner.cpp:146-175 — with the velocity and
+ * acceleration limits of the configuration and the jerk margin of the reference's examples (0.1 x max jerk, examples/offline_trajectory.cpp:9);
+ * every other re-solve re-guesses from the previous solution (solve_trajectory(false), motionPlanner.cpp:199-207).
+ * Defaults of the driver: the re-solves run with carry_multipliers = 1 and qp_warm_start = 1 (a re-solve continues from the multipliers and
+ * duals of the one before) unless the configuration sets a flag to -1.  mpcmp_solve_batch is unaffected (0 = off there). */
 int mpcmp_rh_run(mpcmp_ctx *ctx, int steps, double dt, int use_graph);
 int mpcmp_rh_get(mpcmp_ctx *ctx, double *x0_now, double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info);
+/* counters since mpcmp_rh_init: re-solves actually executed (instance-steps of live instances) and instances retired so far; either may be NULL */
+int mpcmp_rh_stats(mpcmp_ctx *ctx, long long *resolves_done, long long *arrived);
 
 /* ---- measurement hooks used by bench.py ---- */
 /* name and accumulated device time (ms, HIP events on the solve stream) of the dominant kernel since the

@@ -39,7 +39,7 @@ class Info(C.Structure):
 
 
 # status bits of mpcmp_info.status (include/mpcmp.h)
-STATUS_NAN, STATUS_NOT_PD, STATUS_XCH_DEAD, STATUS_QP_CAPPED, STATUS_OUTSIDE_TOL, STATUS_T_OUT_OF_BOX = 1, 2, 4, 8, 16, 32
+STATUS_NAN, STATUS_NOT_PD, STATUS_XCH_DEAD, STATUS_QP_CAPPED, STATUS_OUTSIDE_TOL, STATUS_T_OUT_OF_BOX, STATUS_ARRIVED = 1, 2, 4, 8, 16, 32, 64
 STATUS_HARD = STATUS_NAN | STATUS_NOT_PD | STATUS_XCH_DEAD        # the solve itself failed (the other bits grade the returned iterate)
 
 INFO_DTYPE = np.dtype([("T", "f8"), ("viol_l1", "f8"), ("defect_inf", "f8"), ("path_viol_inf", "f8"),
@@ -57,7 +57,7 @@ SYMBOLS = ["mpcmp_default_model", "mpcmp_model_from_urdf", "mpcmp_models_from_ur
            "mpcmp_warm_start_jerk_batch", "mpcmp_warm_start_jerk_batch_device", "mpcmp_jerk_trajectory_batch",
            "mpcmp_jerk_point_batch", "mpcmp_mpc_point_batch", "mpcmp_debug_fetch",
            "mpcmp_warm_start_jerk_acc_batch", "mpcmp_warm_start_jerk_acc_batch_device", "mpcmp_jerk_trajectory_acc_batch", "mpcmp_jerk_point_acc_batch",
-           "mpcmp_warm_start_jerk_lim_batch", "mpcmp_jerk_trajectory_lim_batch", "mpcmp_jerk_point_lim_batch", "mpcmp_reset_multipliers"]
+           "mpcmp_warm_start_jerk_lim_batch", "mpcmp_jerk_trajectory_lim_batch", "mpcmp_jerk_point_lim_batch", "mpcmp_reset_multipliers", "mpcmp_rh_stats"]
 
 
 def library_path():

@@ -90,7 +90,22 @@ struct mpcmp_ctx {
     hipGraph_t rh_graph = nullptr;
     hipGraphExec_t rh_exec = nullptr;
     double rh_dt = 0.0;
+    int *d_retired = nullptr;                    // [max_batch] arrived instances of the receding-horizon loop (k_advance); not re-solved
+    unsigned long long *d_rh_count = nullptr;    // [2] re-solves executed, instances retired (since mpcmp_rh_init)
+    bool rh_step = false;                        // the solve being enqueued is a step of the receding-horizon driver (defaults of its flags, retired instances)
+    // diagnostics read from the environment ONCE PER CONTEXT, in mpcmp_create (never process-global state)
+    bool force_v1 = false, single_stream = false, debug_occ = false;
+    int parts_env = 2;
 };
+
+// the configuration the kernels of a solve see: the two start flags resolved to 0 / 1.  0 = the library default (off for mpcmp_solve_batch, ON for
+// the receding-horizon driver), 1 = on, -1 = off everywhere (include/mpcmp.h)
+static mpcmp_config run_config(const mpcmp_ctx *ctx) {
+    mpcmp_config c = ctx->cfg;
+    c.qp_warm_start = ctx->rh_step ? (c.qp_warm_start >= 0) : (c.qp_warm_start > 0);
+    c.carry_multipliers = ctx->rh_step ? (c.carry_multipliers >= 0) : (c.carry_multipliers > 0);
+    return c;
+}
 
 static thread_local std::string g_err;
 
@@ -545,7 +560,7 @@ static int validate(const mpcmp_config *c, std::string &err) {
     if (c->sqp_iters < 1 || c->qp_iters < 1 || c->check_every < 1) { err = "iteration counts must be >= 1"; return MPCMP_EINVAL; }
     if (c->ls_iters < 2 || c->ls_iters > 10) { err = "ls_iters must be in [2,10]"; return MPCMP_EINVAL; }
     if (!(c->rho > 0) || !(c->sigma > 0) || !(c->alpha > 0 && c->alpha < 2)) { err = "rho, sigma > 0 and 0 < alpha < 2 required"; return MPCMP_EINVAL; }
-    if ((c->qp_warm_start != 0 && c->qp_warm_start != 1) || (c->carry_multipliers != 0 && c->carry_multipliers != 1)) { err = "qp_warm_start and carry_multipliers are 0 or 1"; return MPCMP_EINVAL; }
+    if (c->qp_warm_start < -1 || c->qp_warm_start > 1 || c->carry_multipliers < -1 || c->carry_multipliers > 1) { err = "qp_warm_start and carry_multipliers are -1, 0 or 1"; return MPCMP_EINVAL; }
     return MPCMP_OK;
 }
 
@@ -567,6 +582,7 @@ extern "C" int mpcmp_destroy(mpcmp_ctx *ctx) {
 }
 
 static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int narm, int device, int max_batch, mpcmp_ctx **out);
+static int prepare_kernels(mpcmp_ctx *ctx);
 
 extern "C" int mpcmp_create(const mpcmp_config *cfg, const mpcmp_model *model, int device, int max_batch, mpcmp_ctx **out) {
     return create_impl(cfg, model, 1, device, max_batch, out);
@@ -725,6 +741,14 @@ static int create_impl(const mpcmp_config *cfg, const mpcmp_model *model, int na
 #endif
         }
     }
+    TRY(dalloc(ctx, &ctx->d_retired, B)); HIPTRY(hipMemset(ctx->d_retired, 0, sizeof(int) * B));
+    TRY(dalloc(ctx, &ctx->d_rh_count, 2)); HIPTRY(hipMemset(ctx->d_rh_count, 0, 2 * sizeof(unsigned long long)));
+    // diagnostics (generic kernel everywhere, stream count, occupancy report): read here, per context
+    ctx->force_v1 = std::getenv("MPCMP_FORCE_V1") != nullptr;
+    ctx->single_stream = std::getenv("MPCMP_SINGLE_STREAM") != nullptr;
+    ctx->debug_occ = std::getenv("MPCMP_DEBUG_OCC") != nullptr;
+    if (const char *e = std::getenv("MPCMP_STREAMS")) ctx->parts_env = std::atoi(e);
+    TRY(prepare_kernels(ctx));
 #undef TRY
 #undef HIPTRY
     *out = ctx;
@@ -764,54 +788,80 @@ static hipEvent_t *next_events(mpcmp_ctx *ctx) {
     return ctx->ev[ctx->ev_used++].e;
 }
 
+// Kernel selection of a single-arm context (compile-time candidates, run-time choice by discretisation and the context's diagnostics)
 template <int NSEG>
-static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_wx,
-                      const double *d_wu, const double *d_wT, double *d_sx, double *d_su, double *d_sT,
-                      mpcmp_info *d_info, hipStream_t st, int only_qp, int reguess = 0) {
-    using D = Dim<NSEG>;
-    WS w = ctx->ws;
-    w.x0 = d_x0; w.xf = d_xf;
-    const size_t l_init = InitLds<NSEG>::size * sizeof(double), l_qp = QpLds<(NSEG >= 6) ? 1 : NSEG>::size * sizeof(double),
-                 l_step = StepLds<NSEG>::size * sizeof(double);
-    if (int rc = set_lds(ctx, k_init<NSEG>, l_init)) return rc;
-    static const bool force_v1 = std::getenv("MPCMP_FORCE_V1") != nullptr;   // diagnostics: generic kernel everywhere
-    constexpr bool V2C = (NSEG == 2 || NSEG == 4);      // role-specialised 1024-thread QP kernel
-    constexpr bool V3T = (NSEG >= 4);                   // k_qp3 instantiated (num_seg 4: diagnostics, MPCMP_QP13=3)
-    const bool V3C = NSEG >= 6 || (NSEG == 4 && ctx->qp13 == 3);      // k_qp3: T bordered out, E-free interior solve (N = 19, 25)
-    const bool V4 = NSEG == 4 && ctx->qp13 == 4;                       // k_qp3f<4, 1, 4> + k_qp4: two OCPs per CU
-    const bool V2 = V2C && !force_v1 && !V3C && !V4;
-    const size_t l_qp3 = Qp3<V3T ? NSEG : 6>::sizeL * sizeof(double), l_qp3f = Qp3<V3T ? NSEG : 6>::sizeF * sizeof(double);
-    if (V3C) { if (int rc = set_lds(ctx, k_qp3<V3T ? NSEG : 6, 1>, l_qp3)) return rc; if (int rc = set_lds(ctx, k_qp3f<V3T ? NSEG : 6, 1>, l_qp3f)) return rc; }
-    if (NSEG == 6 && ctx->qp19 == 5) {
+struct KSel {
+    static constexpr bool V2C = (NSEG == 2 || NSEG == 4);      // role-specialised 1024-thread QP kernel
+    static constexpr bool V3T = (NSEG >= 4);                   // k_qp3 instantiated (num_seg 4: diagnostics, MPCMP_QP13=3)
+    static constexpr int N3 = V3T ? NSEG : 6, N2 = V2C ? NSEG : 4, N1 = (NSEG >= 6) ? 1 : NSEG;
+    bool V3C, V4, V2, V5;
+    explicit KSel(const mpcmp_ctx *ctx) {
+        V3C = NSEG >= 6 || (NSEG == 4 && ctx->qp13 == 3);      // k_qp3: T bordered out, E-free interior solve (N = 19, 25)
+        V4 = NSEG == 4 && ctx->qp13 == 4;                       // k_qp3f<4, 1, 4> + k_qp4: two OCPs per CU
+        V2 = V2C && !ctx->force_v1 && !V3C && !V4;
+        V5 = NSEG == 6 && ctx->qp19 == 5;
+    }
+};
+
+// dynamic-LDS limits of every kernel a context of this discretisation can launch: set ONCE, in mpcmp_create
+template <int NSEG>
+static int prepare_impl(mpcmp_ctx *ctx) {
+    using S = KSel<NSEG>;
+    const S k(ctx);
+    if (int rc = set_lds(ctx, k_init<NSEG>, InitLds<NSEG>::size * sizeof(double))) return rc;
+    if (int rc = set_lds(ctx, k_step<NSEG>, StepLds<NSEG>::size * sizeof(double))) return rc;
+    if (k.V3C) {
+        if (int rc = set_lds(ctx, k_qp3<S::N3, 1>, Qp3<S::N3>::sizeL * sizeof(double))) return rc;
+        if (int rc = set_lds(ctx, k_qp3f<S::N3, 1>, Qp3<S::N3>::sizeF * sizeof(double))) return rc;
+    }
+    if (k.V5) {
         if (int rc = set_lds(ctx, k_qp5<6>, Qp5<6>::size5 * sizeof(double))) return rc;
         if (int rc = set_lds(ctx, k_qp3f<6, 1, 5>, Qp3<6>::sizeF * sizeof(double))) return rc;
     }
 #ifdef MPCMP_WITH_QP4
-    const size_t l_qp4 = Qp4<4>::size * sizeof(double);
-    if (V4) {
+    if (k.V4) {
+        const size_t l_qp4 = Qp4<4>::size * sizeof(double);
         if (int rc = set_lds(ctx, k_qp4<4>, l_qp4)) return rc;
         if (int rc = set_lds(ctx, k_qp3f<4, 1, 4>, Qp3<4>::sizeF * sizeof(double))) return rc;
-        static const bool dbg_occ = std::getenv("MPCMP_DEBUG_OCC") != nullptr;      // diagnostics: resident workgroups per CU
-        if (dbg_occ) {
+        if (ctx->debug_occ) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qp4<4>, 384, l_qp4);
             std::fprintf(stderr, "k_qp4: %zu B of dynamic LDS, %d workgroups per CU\n", l_qp4, nb);
         }
     }
 #endif
-    const size_t l_qp2 = Qp2<V2C ? NSEG : 4>::size * sizeof(double);
-    if (V2) { if (int rc = set_lds(ctx, k_qp2<V2C ? NSEG : 4>, l_qp2)) return rc; }
-    else if (!V3C && !V4) { if (int rc = set_lds(ctx, k_qp<(NSEG >= 6) ? 1 : NSEG>, l_qp)) return rc; }
-    if (int rc = set_lds(ctx, k_step<NSEG>, l_step)) return rc;
+    if (k.V2) { if (int rc = set_lds(ctx, k_qp2<S::N2>, Qp2<S::N2>::size * sizeof(double))) return rc; }
+    else if (!k.V3C && !k.V4) { if (int rc = set_lds(ctx, k_qp<S::N1>, QpLds<S::N1>::size * sizeof(double))) return rc; }
+    return MPCMP_OK;
+}
+
+template <int NSEG>
+static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d_xf, const double *d_wx,
+                      const double *d_wu, const double *d_wT, double *d_sx, double *d_su, double *d_sT,
+                      mpcmp_info *d_info, hipStream_t st, int only_qp, int reguess = 0) {
+    using D = Dim<NSEG>;
+    using S = KSel<NSEG>;
+    const S ks(ctx);
+    const bool V3C = ks.V3C, V4 = ks.V4, V2 = ks.V2;
+    const mpcmp_config cfg = run_config(ctx);
+    WS w = ctx->ws;
+    w.x0 = d_x0; w.xf = d_xf;
+    w.retired = ctx->rh_step ? ctx->d_retired : nullptr;
+    if (ctx->rh_step) { w.alt_x = ctx->d_wx; w.alt_u = ctx->d_wu; w.alt_T = ctx->d_wT; }
+    const size_t l_init = InitLds<NSEG>::size * sizeof(double), l_qp = QpLds<S::N1>::size * sizeof(double),
+                 l_step = StepLds<NSEG>::size * sizeof(double);
+    const size_t l_qp3 = Qp3<S::N3>::sizeL * sizeof(double), l_qp3f = Qp3<S::N3>::sizeF * sizeof(double);
+#ifdef MPCMP_WITH_QP4
+    const size_t l_qp4 = Qp4<4>::size * sizeof(double);
+#endif
+    const size_t l_qp2 = Qp2<S::N2>::size * sizeof(double);
     // A large batch is solved as two half-batches on two streams.  Every SQP iteration is a chain of dependent launches
     // (QP -> order -> step), and a QP launch ends in a tail in which most CUs are idle (its problems run 25..700 ADMM
     // iterations, four workgroups per CU); with two independent chains in flight the tail of one half is filled by the other
     // half's next launch.  Replay of the bench workload's iteration counts: -5.8 % makespan.  Results are unaffected (problems
     // are independent); small batches stay on one stream.
-    static const bool single_stream = std::getenv("MPCMP_SINGLE_STREAM") != nullptr;
-    static const int parts_env = std::getenv("MPCMP_STREAMS") ? std::atoi(std::getenv("MPCMP_STREAMS")) : 2;      // diagnostics: 1..4
-    const bool dual = !single_stream && !only_qp && B >= 512;      // (also under stream capture: the fork/join events carry the other streams into the graph)
-    const int nhalf = dual ? (parts_env < 1 ? 1 : (parts_env > 4 ? 4 : parts_env)) : 1;
+    const bool dual = !ctx->single_stream && !only_qp && B >= 512;      // (also under stream capture: the fork/join events carry the other streams into the graph)
+    const int nhalf = dual ? (ctx->parts_env < 1 ? 1 : (ctx->parts_env > 4 ? 4 : ctx->parts_env)) : 1;
     int Bh[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
     for (int h = 0, acc = 0; h < nhalf; h++) { Bh[h] = (B - acc + (nhalf - h) - 1) / (nhalf - h); boff[h] = acc; acc += Bh[h]; }
     hipStream_t sh[4] = {st, ctx->stream_x[0], ctx->stream_x[1], ctx->stream_x[2]};
@@ -825,6 +875,8 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
         v.x0 += 14 * b0; v.xf += 14 * b0; v.z += D::n * b0; v.lam += D::mn * b0; v.ceq += D::meq * b0; v.g += 8 * D::N * b0;
         v.Gk += (size_t)D::N * 176 * b0; v.p += D::n * b0; v.y += D::mn * b0; v.qpit += b0; v.perm += b0; v.okey += b0; v.done += h;
         v.qp_total += b0; v.status += b0; v.alpha += b0; v.dbg += (size_t)MPCMP_DBG_WORDS * b0;
+        if (v.retired) v.retired += b0;
+        if (v.alt_x) { v.alt_x += 14 * D::N * b0; v.alt_u += 7 * D::N * b0; v.alt_T += b0; }
         wh[h] = v;
         if (d_wx) { hx[h] = d_wx + 14 * D::N * b0; hu[h] = d_wu + 7 * D::N * b0; hT[h] = d_wT + b0; }
         ox[h] = d_sx ? d_sx + 14 * D::N * b0 : nullptr; ou[h] = d_su ? d_su + 7 * D::N * b0 : nullptr;
@@ -832,8 +884,8 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     }
     if (nhalf > 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st)); for (int h = 1; h < nhalf; h++) HIPCHK(ctx, hipStreamWaitEvent(sh[h], ctx->ev_fork, 0)); }
     for (int h = 0; h < nhalf; h++)
-        hipLaunchKernelGGL(k_init<NSEG>, dim3(Bh[h]), dim3(D::NT), l_init, sh[h], ctx->cfg, ctx->model, wh[h], hx[h], hu[h], hT[h], reguess);
-    const int iters = only_qp ? 1 : ctx->cfg.sqp_iters;
+        hipLaunchKernelGGL(k_init<NSEG>, dim3(Bh[h]), dim3(D::NT), l_init, sh[h], cfg, ctx->model, wh[h], hx[h], hu[h], hT[h], reguess);
+    const int iters = only_qp ? 1 : cfg.sqp_iters;
     for (int it = 0; it < iters; it++) {
         for (int h = 0; h < nhalf; h++) {
             hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
@@ -843,35 +895,59 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
                 WS w3 = wh[h];
                 w3.ext_of_int = ctx->d3_ext_of_int; w3.entry_ptr = ctx->d3_entry_ptr; w3.terms = ctx->d3_terms;
                 double *fh = ctx->d_fac + (size_t)boff[h] * Qp4Fac<4>::FAC;
-                hipLaunchKernelGGL((k_qp3f<4, 1, 4>), dim3(Bh[h]), dim3(1024), Qp3<4>::sizeF * sizeof(double), sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
-                hipLaunchKernelGGL((k_qp4<4>), dim3(Bh[h]), dim3(384), l_qp4, sh[h], ctx->cfg, w3, (const uint32_t *)ctx->d_lane4, Bh[h], (const double *)fh);
+                hipLaunchKernelGGL((k_qp3f<4, 1, 4>), dim3(Bh[h]), dim3(1024), Qp3<4>::sizeF * sizeof(double), sh[h], cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
+                hipLaunchKernelGGL((k_qp4<4>), dim3(Bh[h]), dim3(384), l_qp4, sh[h], cfg, w3, (const uint32_t *)ctx->d_lane4, Bh[h], (const double *)fh);
             }
 #else
             if (V4) { ctx->err = "k_qp4 not built"; return MPCMP_EINVAL; }
 #endif
-            else if (NSEG == 6 && ctx->qp19 == 5) {
+            else if (ks.V5) {
                 double *fh = ctx->d_fac + (size_t)boff[h] * Qp5Fac<6>::FAC;
-                hipLaunchKernelGGL((k_qp3f<6, 1, 5>), dim3(Bh[h]), dim3(1024), Qp3<6>::sizeF * sizeof(double), sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);
-                hipLaunchKernelGGL((k_qp5<6>), dim3(Bh[h]), dim3(768), Qp5<6>::size5 * sizeof(double), sh[h], ctx->cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
+                hipLaunchKernelGGL((k_qp3f<6, 1, 5>), dim3(Bh[h]), dim3(1024), Qp3<6>::sizeF * sizeof(double), sh[h], cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], fh);
+                hipLaunchKernelGGL((k_qp5<6>), dim3(Bh[h]), dim3(768), Qp5<6>::size5 * sizeof(double), sh[h], cfg, wh[h], ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
             }
             else if (V3C) {
                 WS w3 = wh[h];
                 if (NSEG == 4) { w3.ext_of_int = ctx->d3_ext_of_int; w3.entry_ptr = ctx->d3_entry_ptr; w3.terms = ctx->d3_terms; }
-                double *fh = ctx->d_fac + (size_t)boff[h] * Qp3<V3T ? NSEG : 6>::FAC;
-                hipLaunchKernelGGL((k_qp3f<V3T ? NSEG : 6, 1>), dim3(Bh[h]), dim3(1024), l_qp3f, sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
-                hipLaunchKernelGGL((k_qp3<V3T ? NSEG : 6, 1>), dim3(Bh[h]), dim3(512), l_qp3, sh[h], ctx->cfg, w3, ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
+                double *fh = ctx->d_fac + (size_t)boff[h] * Qp3<S::N3>::FAC;
+                hipLaunchKernelGGL((k_qp3f<S::N3, 1>), dim3(Bh[h]), dim3(1024), l_qp3f, sh[h], cfg, w3, ctx->d_pat, ctx->xch, Bh[h], fh);
+                hipLaunchKernelGGL((k_qp3<S::N3, 1>), dim3(Bh[h]), dim3(512), l_qp3, sh[h], cfg, w3, ctx->d_pat, ctx->xch, Bh[h], (const double *)fh);
             }
-            else if (V2) hipLaunchKernelGGL((k_qp2<V2C ? NSEG : 4>), dim3(Bh[h]), dim3(1024), l_qp2, sh[h], ctx->cfg, wh[h], ctx->streams);
-            else hipLaunchKernelGGL((k_qp<(NSEG >= 6) ? 1 : NSEG>), dim3(Bh[h]), dim3(Dim<(NSEG >= 6) ? 1 : NSEG>::NT), l_qp, sh[h], ctx->cfg, wh[h]);
+            else if (V2) hipLaunchKernelGGL((k_qp2<S::N2>), dim3(Bh[h]), dim3(1024), l_qp2, sh[h], cfg, wh[h], ctx->streams);
+            else hipLaunchKernelGGL((k_qp<S::N1>), dim3(Bh[h]), dim3(Dim<S::N1>::NT), l_qp, sh[h], cfg, wh[h]);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;
-            hipLaunchKernelGGL(k_step<NSEG>, dim3(Bh[h]), dim3(D::NT), l_step, sh[h], ctx->cfg, ctx->model, wh[h], it == iters - 1 ? 1 : 0, it,
+            hipLaunchKernelGGL(k_step<NSEG>, dim3(Bh[h]), dim3(D::NT), l_step, sh[h], cfg, ctx->model, wh[h], it == iters - 1 ? 1 : 0, it,
                                ox[h], ou[h], oT[h], oi[h]);
         }
     }
     for (int h = 1; h < nhalf; h++) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[h - 1], sh[h])); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join[h - 1], 0)); }
     HIPCHK(ctx, hipGetLastError());
     return MPCMP_OK;
+}
+
+template <int NSEG, int NARM>
+static int prepare_impl_m(mpcmp_ctx *ctx) {
+    using D = DimM<NSEG, NARM>;
+    const size_t l_m = D::size * sizeof(double);
+    if (int rc = set_lds(ctx, k_init_m<NSEG, NARM>, l_m)) return rc;
+    if (int rc = set_lds(ctx, k_step_m<NSEG, NARM>, l_m)) return rc;
+    if (int rc = set_lds(ctx, k_qp3<NSEG, NARM>, Qp3<NSEG>::sizeL * sizeof(double))) return rc;
+    if (int rc = set_lds(ctx, k_qp3f<NSEG, NARM>, Qp3<NSEG>::sizeF * sizeof(double))) return rc;
+    return MPCMP_OK;
+}
+
+// dynamic-LDS limits of the context's kernels (hipFuncSetAttribute): once per context
+static int prepare_kernels(mpcmp_ctx *ctx) {
+    if (ctx->narm == 2) return ctx->nseg == 6 ? prepare_impl_m<6, 2>(ctx) : prepare_impl_m<8, 2>(ctx);
+    switch (ctx->nseg) {
+        case 1: return prepare_impl<1>(ctx);
+        case 2: return prepare_impl<2>(ctx);
+        case 4: return prepare_impl<4>(ctx);
+        case 6: return prepare_impl<6>(ctx);
+        case 8: return prepare_impl_m<8, 1>(ctx);
+    }
+    return MPCMP_EINVAL;
 }
 
 // N = 25 and multi-arm OCPs: k_init_m -> K x [k_qp3 (one workgroup per arm), k_step_m]
@@ -881,16 +957,14 @@ static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double 
                         int only_qp, int reguess) {
     using D = DimM<NSEG, NARM>;
     constexpr int N = D::N;
+    const mpcmp_config cfg = run_config(ctx);
     WS w = ctx->ws;
     w.x0 = d_x0; w.xf = d_xf;
+    w.retired = ctx->rh_step ? ctx->d_retired : nullptr;
+    if (ctx->rh_step) { w.alt_x = ctx->d_wx; w.alt_u = ctx->d_wu; w.alt_T = ctx->d_wT; }
     const size_t l_m = D::size * sizeof(double), l_qp3 = Qp3<NSEG>::sizeL * sizeof(double), l_qp3f = Qp3<NSEG>::sizeF * sizeof(double);
-    if (int rc = set_lds(ctx, k_init_m<NSEG, NARM>, l_m)) return rc;
-    if (int rc = set_lds(ctx, k_step_m<NSEG, NARM>, l_m)) return rc;
-    if (int rc = set_lds(ctx, k_qp3<NSEG, NARM>, l_qp3)) return rc;
-    if (int rc = set_lds(ctx, k_qp3f<NSEG, NARM>, l_qp3f)) return rc;
     // two parts on two streams once one part alone fills the chip (one CU per arm): see solve_impl
-    static const bool single_stream = std::getenv("MPCMP_SINGLE_STREAM") != nullptr;
-    const bool dual = !single_stream && !only_qp && B * NARM >= 512;
+    const bool dual = !ctx->single_stream && !only_qp && B * NARM >= 512;
     const int nhalf = dual ? 2 : 1;
     int Bh[2] = {0, 0}, boff[2] = {0, 0};
     for (int h = 0, acc = 0; h < nhalf; h++) { Bh[h] = (B - acc + (nhalf - h) - 1) / (nhalf - h); boff[h] = acc; acc += Bh[h]; }
@@ -906,6 +980,8 @@ static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double 
         v.x0 += 14 * NARM * b0; v.xf += 14 * NARM * b0; v.z += D::n * b0; v.lam += D::mn * b0; v.ceq += (size_t)NARM * D::meq * b0;
         v.g += (size_t)NARM * 8 * N * b0; v.Gk += (size_t)NARM * N * 176 * b0; v.p += D::n * b0; v.y += D::mn * b0; v.qpit += b0; v.perm += b0;
         v.okey += b0; v.done += h; v.qp_total += b0; v.status += b0; v.alpha += b0; v.dbg += (size_t)MPCMP_DBG_WORDS * b0;
+        if (v.retired) v.retired += b0;
+        if (v.alt_x) { v.alt_x += (size_t)14 * NARM * N * b0; v.alt_u += (size_t)7 * NARM * N * b0; v.alt_T += b0; }
         wh[h] = v;
         xh[h].buf = ctx->xch.buf ? ctx->xch.buf + (size_t)2 * MPCMP_XCH_STRIDE * b0 : nullptr;
         if (d_wx) { hx[h] = d_wx + (size_t)14 * NARM * N * b0; hu[h] = d_wu + (size_t)7 * NARM * N * b0; hT[h] = d_wT + b0; }
@@ -914,19 +990,19 @@ static int solve_impl_m(mpcmp_ctx *ctx, int B, const double *d_x0, const double 
     }
     if (nhalf > 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st)); HIPCHK(ctx, hipStreamWaitEvent(sh[1], ctx->ev_fork, 0)); }
     for (int h = 0; h < nhalf; h++)
-        hipLaunchKernelGGL((k_init_m<NSEG, NARM>), dim3(Bh[h]), dim3(D::NT), l_m, sh[h], ctx->cfg, ctx->d_model, wh[h], xh[h], hx[h], hu[h], hT[h], reguess);
-    const int iters = only_qp ? 1 : ctx->cfg.sqp_iters;
+        hipLaunchKernelGGL((k_init_m<NSEG, NARM>), dim3(Bh[h]), dim3(D::NT), l_m, sh[h], cfg, ctx->d_model, wh[h], xh[h], hx[h], hu[h], hT[h], reguess);
+    const int iters = only_qp ? 1 : cfg.sqp_iters;
     for (int it = 0; it < iters; it++) {
         for (int h = 0; h < nhalf; h++) {
             hipEvent_t *ev = (ctx->timing && !ctx->capturing) ? next_events(ctx) : nullptr;
             if (ev) HIPCHK(ctx, hipEventRecord(ev[0], sh[h]));
             const int grid = NARM == 1 ? Bh[h] : ((Bh[h] + 7) / 8) * 16;       // arm workgroups of one OCP are 8 apart (k_qp3)
             double *fh = ctx->d_fac + (size_t)boff[h] * NARM * Qp3<NSEG>::FAC;
-            hipLaunchKernelGGL((k_qp3f<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3f, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], fh);
-            hipLaunchKernelGGL((k_qp3<NSEG, NARM>), dim3(grid), dim3(512), l_qp3, sh[h], ctx->cfg, wh[h], ctx->d_pat, xh[h], Bh[h], (const double *)fh);
+            hipLaunchKernelGGL((k_qp3f<NSEG, NARM>), dim3(grid), dim3(1024), l_qp3f, sh[h], cfg, wh[h], ctx->d_pat, xh[h], Bh[h], fh);
+            hipLaunchKernelGGL((k_qp3<NSEG, NARM>), dim3(grid), dim3(512), l_qp3, sh[h], cfg, wh[h], ctx->d_pat, xh[h], Bh[h], (const double *)fh);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;
-            hipLaunchKernelGGL((k_step_m<NSEG, NARM>), dim3(Bh[h]), dim3(D::NT), l_m, sh[h], ctx->cfg, ctx->d_model, wh[h], xh[h],
+            hipLaunchKernelGGL((k_step_m<NSEG, NARM>), dim3(Bh[h]), dim3(D::NT), l_m, sh[h], cfg, ctx->d_model, wh[h], xh[h],
                                it == iters - 1 ? 1 : 0, it, ox[h], ou[h], oT[h], oi[h]);
         }
     }
@@ -1006,16 +1082,14 @@ extern "C" int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, c
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
     // k_init alone: the built-in initialiser writes the iterate z = [xs|us|T]
-    mpcmp_config save = ctx->cfg;
+    const mpcmp_config save = run_config(ctx);
     WS w = ctx->ws; w.x0 = ctx->d_x0; w.xf = ctx->d_xf;
-    int rc = MPCMP_OK;
-#define LAUNCH_INIT(NS) { size_t l = InitLds<NS>::size * sizeof(double); rc = set_lds(ctx, k_init<NS>, l); \
-        if (!rc) hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, ctx->model, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); }
+#define LAUNCH_INIT(NS) { const size_t l = InitLds<NS>::size * sizeof(double); \
+        hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, ctx->model, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); }
     switch (ctx->nseg) { case 1: LAUNCH_INIT(1) break; case 2: LAUNCH_INIT(2) break; case 4: LAUNCH_INIT(4) break; case 6: LAUNCH_INIT(6) break;
-        case 8: { const size_t l = DimM<8, 1>::size * sizeof(double); rc = set_lds(ctx, k_init_m<8, 1>, l);
-                  if (!rc) hipLaunchKernelGGL((k_init_m<8, 1>), dim3(B), dim3(512), l, st, save, ctx->d_model, w, ctx->xch, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); } break; }
+        case 8: { const size_t l = DimM<8, 1>::size * sizeof(double);
+                  hipLaunchKernelGGL((k_init_m<8, 1>), dim3(B), dim3(512), l, st, save, ctx->d_model, w, ctx->xch, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); } break; }
 #undef LAUNCH_INIT
-    if (rc) return rc;
     HIPCHK(ctx, hipGetLastError());
     std::vector<double> z((size_t)B * n);
     HIPCHK(ctx, hipMemcpyAsync(z.data(), ctx->ws.z, sizeof(double) * n * B, hipMemcpyDeviceToHost, st));
@@ -1376,6 +1450,8 @@ extern "C" int mpcmp_rh_init(mpcmp_ctx *ctx, int B, const double *x0, const doub
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(ctx->ws.lam, 0, sizeof(double) * ctx->lam_count, st));       // new instances: no multipliers to carry, no failed solve behind them
     HIPCHK(ctx, hipMemsetAsync(ctx->ws.status, 0, sizeof(*ctx->ws.status) * ctx->max_batch, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_retired, 0, sizeof(int) * ctx->max_batch, st));                       // nobody has arrived
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_rh_count, 0, 2 * sizeof(unsigned long long), st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * ctx->nx * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * ctx->nx * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
@@ -1387,11 +1463,22 @@ extern "C" int mpcmp_rh_init(mpcmp_ctx *ctx, int B, const double *x0, const doub
 
 static int rh_enqueue_step(mpcmp_ctx *ctx, double dt, bool first, hipStream_t st) {
     const int B = ctx->rh_B;
-    const double *wx = first ? nullptr : ctx->d_sx, *wu = first ? nullptr : ctx->d_su, *wT = first ? nullptr : ctx->d_sT;
-    if (int rc = solve_dispatch(ctx, B, ctx->d_x0, ctx->d_xf, wx, wu, wT, ctx->d_sx, ctx->d_su, ctx->d_sT, ctx->d_info, st, 0,
-                                first ? 0 : 1))
-        return rc;
-    hipLaunchKernelGGL(k_advance, dim3((B * ctx->nx + 255) / 256), dim3(256), 0, st, ctx->nseg, ctx->nx, B, dt, ctx->d_sx, ctx->d_sT, ctx->ws.status, ctx->d_x0);
+    // The driver's start guess, every step, from every instance's current state: the jerk-limited time-synchronised trajectory the reference takes from
+    // Ruckig for solve_trajectory(true) (motionPlanner.cpp:146-175), with the velocity / acceleration limits of the configuration and the jerk
+    // margin every example of the reference uses (0.1 x max jerk: examples/offline_trajectory.cpp:9, benchmark.cpp).  It starts the first solve and
+    // RE-starts an instance whose previous solve is no guess (hard failure, T outside its box: k_init); the other re-solves re-guess from the
+    // previous solution (solve_trajectory(false), motionPlanner.cpp:199-207).
+    double jm[7];
+    mpcmp_default_limits(nullptr, nullptr, nullptr, nullptr, jm, nullptr);
+    for (int j = 0; j < 7; j++) jm[j] *= 0.1;
+    if (int rc = warm_start_jerk_device(ctx, B, ctx->d_x0, ctx->d_xf, nullptr, nullptr, nullptr, nullptr, jm, ctx->d_wx, ctx->d_wu, ctx->d_wT, st)) return rc;
+    const double *wx = first ? ctx->d_wx : ctx->d_sx, *wu = first ? ctx->d_wu : ctx->d_su, *wT = first ? ctx->d_wT : ctx->d_sT;
+    ctx->rh_step = true;           // the driver's defaults of the start flags (run_config) and the retired instances (WS.retired)
+    const int rc = solve_dispatch(ctx, B, ctx->d_x0, ctx->d_xf, wx, wu, wT, ctx->d_sx, ctx->d_su, ctx->d_sT, ctx->d_info, st, 0, first ? 0 : 1);
+    ctx->rh_step = false;
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_advance, dim3((B + 255) / 256), dim3(256), 0, st, ctx->nseg, ctx->nx, B, dt, ctx->cfg.eps_target, ctx->d_sx, ctx->d_sT,
+                       ctx->ws.status, ctx->d_xf, ctx->d_x0, ctx->d_retired, ctx->d_info, ctx->d_rh_count);
     HIPCHK(ctx, hipGetLastError());
     return MPCMP_OK;
 }
@@ -1439,6 +1526,17 @@ extern "C" int mpcmp_rh_get(mpcmp_ctx *ctx, double *x0_now, double *sx, double *
     if (sT) HIPCHK(ctx, hipMemcpyAsync(sT, ctx->d_sT, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     if (info) HIPCHK(ctx, hipMemcpyAsync(info, ctx->d_info, sizeof(mpcmp_info) * B, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    return MPCMP_OK;
+}
+
+extern "C" int mpcmp_rh_stats(mpcmp_ctx *ctx, long long *resolves_done, long long *arrived) {
+    if (!ctx || ctx->rh_B < 1) return MPCMP_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    unsigned long long c[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(c, ctx->d_rh_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (resolves_done) *resolves_done = (long long)c[0];
+    if (arrived) *arrived = (long long)c[1];
     return MPCMP_OK;
 }
 

@@ -127,12 +127,17 @@ __global__ __launch_bounds__(512) void k_init_m(mpcmp_config cfg, const mpcmp_mo
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *zl = lds + D::oZ, *scr = lds + D::oScr;
     const int tid = threadIdx.x, b = blockIdx.x;
+    if (MPCMP_RETIRED(ws, b)) {      // arrived (k_advance): nothing is re-solved; only the launch-order bookkeeping of the slot
+        if (tid == 0) { ws.perm[b] = b; ws.okey[b] = 0; if (b == 0) *ws.done = 0; }
+        return;
+    }
     // (the slot's previous solve, as in k_init: a failed solve leaves neither a re-guess nor multipliers behind)
     const bool prev_bad = (ws.status[b] & (MPCMP_STATUS_NAN | MPCMP_STATUS_NOT_PD | MPCMP_STATUS_XCH_DEAD | MPCMP_STATUS_T_OUT_OF_BOX)) != 0;
     __syncthreads();
     if (tid == 0) { ws.perm[b] = b; ws.okey[b] = 0; if (b == 0) *ws.done = 0; ws.qp_total[b] = 0; ws.status[b] = 0; ws.alpha[b] = 0.0; }
     const double *x0 = ws.x0 + (size_t)b * 14 * NARM, *xf = ws.xf + (size_t)b * 14 * NARM;
-    if (warm_x && !(reguess && prev_bad)) {
+    if (reguess && prev_bad) { warm_x = ws.alt_x; warm_u = ws.alt_u; warm_T = ws.alt_T; reguess = 0; }      // (as in k_init)
+    if (warm_x) {
         for (int v = tid; v < n - 1; v += NT) {
             const int a = v / na, w = v % na;
             double val;
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(512) void k_step_m(mpcmp_config cfg, const mpcmp_mo
     constexpr int N = D::N, na = D::na, n = D::n, meq = D::meq, ma = D::ma, NT = D::NT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
+    if (MPCMP_RETIRED(ws, b)) { if (tid == 0) ws.qpit[b] = 0; step_tail(ws, lds, tid, NT); return; }
     double *zl = lds + D::oZ, *pl = lds + D::oP, *scr = lds + D::oScr, *sct = lds + D::oSct, *pv = lds + D::oPv, *xa = lds + D::oX0,
            *red = lds + D::oRed;
     const double *x0 = ws.x0 + (size_t)b * 14 * NARM, *xf = ws.xf + (size_t)b * 14 * NARM;
@@ -366,27 +372,16 @@ __global__ __launch_bounds__(512) void k_step_m(mpcmp_config cfg, const mpcmp_mo
             else { const int k = (w - 14 * N) / 7, j = (w - 14 * N) % 7; sol_u[((size_t)b * N + k) * 7 * NARM + 7 * a + j] = zl[v]; }
         }
         if (tid == 0) sol_T[b] = zl[n - 1];
-        if (tid == 0 && info) {
+        if (tid == 0) {
             mpcmp_info o;
             o.T = zl[n - 1]; o.viol_l1 = s1[0]; o.defect_inf = mxs[0]; o.path_viol_inf = mxs[1]; o.term_err_inf = mxs[2];
             o.last_alpha = alpha; o.qp_iters_total = ws.qp_total[b]; o.sqp_iters = sqp_it + 1;
             report_status(cfg, ws.status[b], anybad, o);
-            info[b] = o;
+            if (info) info[b] = o;
+            ws.status[b] |= o.status & (MPCMP_STATUS_NAN | MPCMP_STATUS_T_OUT_OF_BOX);      // (hard bits of the final iterate, as in k_step)
         }
     }
-    // launch order of the next QP launch: computed by the workgroup that finishes last (see k_step)
-    __syncthreads();
-    int *flag = reinterpret_cast<int *>(lds);
-    if (tid == 0) {
-        __threadfence();
-        flag[0] = atomicAdd(ws.done, 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (flag[0]) {
-        __threadfence();
-        order_body((int)gridDim.x, ws.qpit, ws.okey, ws.perm, flag + 16, tid, NT);
-        if (tid == 0) *ws.done = 0;
-    }
+    step_tail(ws, lds, tid, NT);      // launch order of the next QP launch (see k_step)
 }
 
 // warm start of a multi-arm OCP from the single-arm generator (k_warm_jerk run on B*NARM arm problems): the common duration

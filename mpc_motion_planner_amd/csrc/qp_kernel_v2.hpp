@@ -383,7 +383,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         // ---- E (roles A2, B) ----
         BUSY_SYNC(4);
         STAMP2(7);
-        const bool check = (--until_check == 0);     // countdown: a runtime integer modulo costs a serial ~30-instruction chain
+        const bool check = MPCMP_CHECK_NOW(--until_check == 0);     // countdown: a runtime integer modulo costs a serial ~30-instruction chain
         if (check) {
             until_check = cfg.check_every;
             double sums[2] = {0.0, 0.0};
@@ -560,7 +560,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         const double rr_ = pcl[2 * L::NA2], rri = pcl[4 * L::NA2], lgp = pcl[0], ugp = pcl[L::NA2];
         BUSY_SYNC(3);
         // ---- E: z~ = A x~, relaxation, projection, dual update ----
-        const bool check = (--until_check == 0);
+        const bool check = MPCMP_CHECK_NOW(--until_check == 0);
         if (check) until_check = cfg.check_every;
         if (isPath && ABL_ON(2)) {
             path_rows(p0, p1, xn, lds + L::oGp, [&](double zt) -> double {
@@ -797,7 +797,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         const double vrbi = vcl[12 * L::NB], vlb = vcl[10 * L::NB], vub = vcl[11 * L::NB];
         BUSY_SYNC(3);
         // ---- E: variables and dynamics rows ----
-        const bool check = (--until_check == 0);
+        const bool check = MPCMP_CHECK_NOW(--until_check == 0);
         if (check) until_check = cfg.check_every;
         if (MPCMP_ABL == 1 || MPCMP_ABL == 10) {
         } else if (waveDyn) {
@@ -881,6 +881,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, Qp2Stream
     const int tid = (MPCMP_WPERM == 0xFEDCBA9876543210ull) ? (int)threadIdx.x
                                                             : (int)((MPCMP_WPERM >> (4 * (threadIdx.x >> 6))) & 15ull) * 64 + (int)(threadIdx.x & 63);
     const int b = ws.perm[blockIdx.x];      // launch order: solver_kernels.hpp k_order
+    if (MPCMP_RETIRED(ws, b)) return;       // receding horizon: an arrived instance is not re-solved
     double *red = lds + L::oRed, *gkl = lds + L::oGk;
     Qp2Ctx<NSEG> c;
     c.cfg = &cfg; c.ws = ws; c.lds = lds; c.tid = tid; c.b = b;

@@ -322,6 +322,7 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
     else { const int bi = blockIdx.x; slot = (bi >> 4) * 8 + (bi & 7); arm = (bi >> 3) & 1; } \
     if (slot >= B) return; \
     const int b = ws.perm[slot]; \
+    if (MPCMP_RETIRED(ws, b)) return;      /* receding horizon: an arrived instance is not re-solved (both arm workgroups leave) */ \
     const double ts = 1.0 / (2.0 * NSEG); \
     const double rho_in = cfg.rho, rho_eq = cfg.rho * cfg.rho_eq_scale, sigma = cfg.sigma, alpha = cfg.alpha; \
     const double *zg_ = ws.z + (size_t)b * n_tot + arm * na; \

@@ -538,7 +538,7 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
         // ---- P3 (role E) ----
         Q5B(3); Q5_BAR(3); Q5S(3);
         // ---- E: the path rows; the last G wave's variables ----
-        const bool check = (--until_check == 0);
+        const bool check = MPCMP_CHECK_NOW(--until_check == 0);
         if (check) until_check = cfg.check_every;
         if (wavePath) {
             if (isPath && Q5_ON(5)) {
@@ -759,7 +759,7 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
         else if (waveX && Q5_XT) q5_p3_xT<NSEG>(c, sio, true);
         Q5B(3); Q5_BAR(3); Q5S(3);
         // ---- E: the variable and the dynamics row of the lane ----
-        const bool check = (--until_check == 0);
+        const bool check = MPCMP_CHECK_NOW(--until_check == 0);
         if (check) until_check = cfg.check_every;
         apx = q5_lc<NSEG>(c, sio, 2); apf = q5_lc<NSEG>(c, sio, 3); apb = q5_lc<NSEG>(c, sio, 4);      // (constants of the next phase A: not behind this phase's work)
         if (Q5_ON(6)) {

@@ -42,11 +42,23 @@ struct WS {
     int *status;              // [B]
     double *alpha;            // [B]
     unsigned long long *dbg;  // [B][MPCMP_DBG_WORDS] phase cycle stamps (diagnostic builds with -DMPCMP_STAMPS only)
+    const int *retired;       // [B] or null: receding-horizon instances that have arrived (k_advance) are not re-solved: every solve kernel returns at once
+    const double *alt_x, *alt_u, *alt_T;   // or null: the receding-horizon driver's start guess (jerk-limited trajectory from the current state) for an instance
+                                           // that cannot be re-guessed from its previous solve (k_init: reguess && prev_bad); null = the built-in initialiser
 };
+// a retired instance of the receding-horizon loop: the whole workgroup leaves (uniform)
+#define MPCMP_RETIRED(ws_, b_) ((ws_).retired != nullptr && (ws_).retired[b_] != 0)
 
 // ws.status[b] while a solve runs: bits 0..7 = status bits of mpcmp_info (include/mpcmp.h), bits 8..30 = number of QPs that ran out of
 // iterations (every QP kernel adds MPCMP_ST_CAP_ONE then); k_step / k_step_m fold it into the record
 #define MPCMP_ST_CAP_ONE 0x100
+// tools/isa_phases.py compiles with -DMPCMP_NOCHECK: the ADMM loops then contain no termination-test block, so that the hot path of every role is the
+// straight-line text between its barriers (diagnostic build: the QPs never converge early)
+#ifdef MPCMP_NOCHECK
+#define MPCMP_CHECK_NOW(c) (false && (c))
+#else
+#define MPCMP_CHECK_NOW(c) (c)
+#endif
 #define MPCMP_DBG_WORDS 160   /* 16 workgroup stamps + [16 waves][8] per-wave busy cycles of k_qp2 + 16 stamps of k_step */
 #ifdef MPCMP_STAMPS
 #define STAMP(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
@@ -209,12 +221,14 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, mpcmp_
     double *zl = lds, *scr = lds + n;
     const int tid = threadIdx.x, b = blockIdx.x;
     if (tid == 0) { ws.perm[b] = b; ws.okey[b] = 0; if (b == 0) *ws.done = 0; }     // no history yet: problems are solved in batch order
+    if (MPCMP_RETIRED(ws, b)) return;      // arrived: state, solution and record stay as the last solve left them
     const double *x0 = ws.x0 + 14 * b, *xf = ws.xf + 14 * b;
     // the slot's previous solve (0 in a fresh context): after a hard failure or a final time outside its box neither its iterate (re-guess of the
     // receding-horizon loop) nor its multipliers (mpcmp_config.carry_multipliers) are a start: built-in initialiser, lambda_0 = 0
     const bool prev_bad = (ws.status[b] & (MPCMP_STATUS_NAN | MPCMP_STATUS_NOT_PD | MPCMP_STATUS_XCH_DEAD | MPCMP_STATUS_T_OUT_OF_BOX)) != 0;
     __syncthreads();                                      // (thread 0 resets the status word below)
-    if (warm_x && !(reguess && prev_bad)) {
+    if (reguess && prev_bad) { warm_x = ws.alt_x; warm_u = ws.alt_u; warm_T = ws.alt_T; reguess = 0; }      // (null: the built-in initialiser below)
+    if (warm_x) {
         for (int v = tid; v < n; v += D::NT) {
             double val;
             if (v < 14 * N) val = warm_x[(size_t)b * 14 * N + v];
@@ -319,6 +333,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_qp(mpcmp_config cfg, WS ws) {
     constexpr int N = D::N, n = D::n, meq = D::meq, m = D::m, nJ = D::nJ, nI = D::nI, NT = D::NT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = ws.perm[blockIdx.x];
+    if (MPCMP_RETIRED(ws, b)) return;
     double *red = lds + L::oRed;
     const double ts = 1.0 / (2.0 * NSEG);
     const double rho_in = cfg.rho, rho_eq = cfg.rho * cfg.rho_eq_scale, sigma = cfg.sigma, alpha = cfg.alpha;
@@ -771,6 +786,23 @@ __device__ __forceinline__ void order_body(int B, const int *qpit, int *okey, in
 // (order_body runs in the last workgroup of k_step to finish: a separate one-workgroup launch would queue behind the other
 //  stream's QP launch, whose workgroups fill whole CUs, and stall its own stream's chain for hundreds of microseconds)
 
+// launch order of the next QP launch: computed by the workgroup of the step launch that finishes last (every workgroup passes here, also
+// those of retired receding-horizon instances)
+__device__ __forceinline__ void step_tail(const WS &ws, double *lds, int tid, int nt) {
+    __syncthreads();
+    int *flag = reinterpret_cast<int *>(lds);
+    if (tid == 0) {
+        __threadfence();
+        flag[0] = atomicAdd(ws.done, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (flag[0]) {
+        __threadfence();
+        order_body((int)gridDim.x, ws.qpit, ws.okey, ws.perm, flag + 16, tid, nt);
+        if (tid == 0) *ws.done = 0;
+    }
+}
+
 template <int NSEG>
 __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_model mdl, WS ws, int final_iter, int sqp_it,
                                                         double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info) {
@@ -779,6 +811,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
     constexpr int N = D::N, n = D::n, meq = D::meq, NT = D::NT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
+    if (MPCMP_RETIRED(ws, b)) { if (tid == 0) ws.qpit[b] = 0; step_tail(ws, lds, tid, NT); return; }      // (sorted last in the next order)
     double *zl = lds + L::oZ, *pl = lds + L::oP, *pv = lds + L::oPv, *scr = lds + L::oScr, *red = lds + L::oRed;
     const double *x0 = ws.x0 + 14 * b, *xf = ws.xf + 14 * b;
     double *lam = ws.lam + (size_t)b * D::mn;
@@ -905,28 +938,19 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
             else if (v < 21 * N) sol_u[(size_t)b * 7 * N + v - 14 * N] = zl[v];
             else sol_T[b] = zl[v];
         }
-        if (tid == 0 && info) {
+        if (tid == 0) {
             mpcmp_info o;
             o.T = zl[n - 1]; o.viol_l1 = s1[0]; o.defect_inf = mxs[0]; o.path_viol_inf = mxs[1]; o.term_err_inf = mxs[2];
             o.last_alpha = alpha; o.qp_iters_total = ws.qp_total[b]; o.sqp_iters = sqp_it + 1;
             report_status(cfg, ws.status[b], anybad, o);
-            info[b] = o;
+            if (info) info[b] = o;
+            // the hard bits of the FINAL iterate (NaN, T outside its box) exist only here: written back, so that the slot's next k_init (no re-guess
+            // from it, no carried multipliers) and k_advance (state held) see them like the bits the QP kernels set during the solve
+            ws.status[b] |= o.status & (MPCMP_STATUS_NAN | MPCMP_STATUS_T_OUT_OF_BOX);
         }
     }
     KSTAMP(7);
-    // launch order of the next QP launch: computed by the workgroup that finishes last
-    __syncthreads();
-    int *flag = reinterpret_cast<int *>(lds);
-    if (tid == 0) {
-        __threadfence();
-        flag[0] = atomicAdd(ws.done, 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (flag[0]) {
-        __threadfence();
-        order_body((int)gridDim.x, ws.qpit, ws.okey, ws.perm, flag + 16, tid, NT);
-        if (tid == 0) *ws.done = 0;
-    }
+    step_tail(ws, lds, tid, NT);
 }
 
 #ifndef MPCMP_V3_TU     /* (the leaf kernels below are not templates: they belong to the main translation unit only) */
@@ -1055,30 +1079,62 @@ __global__ __launch_bounds__(64) void k_mpc_point(const mpcmp_model *mdl, int ns
     for (int r = 0; r < 7; r++) { o[r] = q[r]; o[7 + r] = v[r]; o[14 + r] = a[r]; o[21 + r] = tau[r]; }
 }
 
-// Receding horizon: x0 <- MPC solution evaluated at physical time dt (MotionPlanner::get_MPC_point, motionPlanner.hpp:118-128,
-// including its clamp: for dt >= T the normalised time is set to T, not 1).  One thread per (problem, state component).
-// An instance whose solve failed hard or left the box of T keeps its state: there is no trajectory to follow (the next re-solve starts afresh, k_init).
-__global__ __launch_bounds__(256) void k_advance(int nseg, int nx, int B, double dt, const double *sx, const double *sT, const int *status, double *x0) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= B * nx) return;
-    const int b = gid / nx, r = gid % nx, N = 3 * nseg + 1;
+// Receding horizon, one thread per instance: x0 <- MPC solution evaluated at physical time dt (MotionPlanner::get_MPC_point,
+// motionPlanner.hpp:118-128), and ARRIVAL: the reference's loop has no end (the caller decides), and an OCP whose start lies in its
+// terminal box degenerates (T -> lbT = 0).  Rule, the same in the oracle (orc_rh_advance):
+//   * retired already                          -> nothing;
+//   * the solve failed hard or left the box of T -> the state is held (there is no trajectory to follow; the next k_init starts afresh);
+//   * T <= dt: the plan ends within this control period -> the instance follows it to its end (last node) and is retired;
+//   * else the state advances by dt (for dt < T the clamp of get_MPC_point never acts); if the new state lies inside the terminal box
+//     |x - x_target| <= eps_target, the instance is retired as well.
+// A retired instance keeps its state, its last solution and its record (status |= MPCMP_STATUS_ARRIVED) and is not re-solved (MPCMP_RETIRED).
+// count[0] += instances solved in this step (not retired at its start), count[1] += instances retired by this step.
+__global__ __launch_bounds__(256) void k_advance(int nseg, int nx, int B, double dt, double eps_target, const double *sx, const double *sT,
+                                                 const int *status, const double *xf, double *x0, int *retired, mpcmp_info *info,
+                                                 unsigned long long *count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (retired[b]) return;
+    atomicAdd(&count[0], 1ull);
     if (status[b] & (MPCMP_STATUS_NAN | MPCMP_STATUS_NOT_PD | MPCMP_STATUS_XCH_DEAD | MPCMP_STATUS_T_OUT_OF_BOX)) return;
+    const int N = 3 * nseg + 1;
     const double T = sT[b];
-    const double t = (dt < T) ? dt / T : T;
-    const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
-    int s = (int)floor(t * nseg);
-    if (s >= nseg) s = nseg - 1;
-    if (s < 0) s = 0;
-    const double xx = 2.0 * (t * nseg - s) - 1.0;
-    double acc = 0.0;
+    const double *X = sx + (size_t)b * N * nx;
+    double *xo = x0 + (size_t)b * nx;
+    bool arrive = false;
+    if (T <= dt) {
+        for (int r = 0; r < nx; r++) xo[r] = X[(size_t)(N - 1) * nx + r];
+        arrive = true;
+    } else {
+        const double t = dt / T;
+        const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+        int s = (int)floor(t * nseg);
+        if (s >= nseg) s = nseg - 1;
+        if (s < 0) s = 0;
+        const double xx = 2.0 * (t * nseg - s) - 1.0;
+        double w[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        double w = 1.0;
+        for (int j = 0; j < 4; j++) {
+            double v = 1.0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (k != j) w *= (xx - xi[k]) / (xi[j] - xi[k]);
-        acc += w * sx[((size_t)b * N + 3 * s + j) * nx + r];
+            for (int k = 0; k < 4; k++) if (k != j) v *= (xx - xi[k]) / (xi[j] - xi[k]);
+            w[j] = v;
+        }
+        double far = 0.0;
+        for (int r = 0; r < nx; r++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc += w[j] * X[(size_t)(3 * s + j) * nx + r];
+            xo[r] = acc;
+            far = fmax(far, fabs(acc - xf[(size_t)b * nx + r]));
+        }
+        arrive = far <= eps_target;
     }
-    x0[gid] = acc;
+    if (arrive) {
+        retired[b] = 1;
+        if (info) info[b].status |= MPCMP_STATUS_ARRIVED;
+        atomicAdd(&count[1], 1ull);
+    }
 }
 
 

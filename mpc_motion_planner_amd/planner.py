@@ -198,6 +198,12 @@ class Solver:
         check(lib().mpcmp_rh_get(self._ctx, dp(x0), dp(sx), dp(su), dp(sT), info.ctypes.data_as(C.c_void_p)), self._ctx)
         return x0, sx, su, sT, info
 
+    def rh_stats(self):
+        """(re-solves executed on live instances, instances retired) since rh_init (mpcmp_rh_stats)"""
+        done, arr = C.c_longlong(0), C.c_longlong(0)
+        check(lib().mpcmp_rh_stats(self._ctx, C.byref(done), C.byref(arr)), self._ctx)
+        return int(done.value), int(arr.value)
+
     def debug_fetch(self, which, count):
         """diagnostics: first `count` doubles of a workspace array (0 z, 1 lambda, 2 c_eq, 3 g, 4 p, 5 y), device layout"""
         out = np.zeros(int(count))

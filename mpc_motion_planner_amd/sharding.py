@@ -23,13 +23,21 @@ def global_total(scaling, batch, world):
 class ShardedBatch:
     """Result buffers + the gather of one rank's shard.  record = 21*N + 1 doubles per problem."""
 
-    def __init__(self, total, rank, world, N, device, dist=None):
+    def __init__(self, total, rank, world, N, device, dist=None, width=None):
+        """width: doubles per record (default 21*N + 1 = one solution; the receding-horizon workload gathers final-state records instead)"""
         self.total, self.rank, self.world, self.N, self.dist = int(total), int(rank), int(world), int(N), dist
         self.lo, self.hi = shard_bounds(rank, world, total)
         self.count = self.hi - self.lo
         self.cap = max(shard_bounds(r, world, total)[1] - shard_bounds(r, world, total)[0] for r in range(world))
-        self.sol = torch.zeros(self.cap, 21 * N + 1, dtype=torch.float64, device=device)      # padded to the largest shard
+        self.width = int(width) if width is not None else 21 * N + 1
+        self.sol = torch.zeros(self.cap, self.width, dtype=torch.float64, device=device)      # padded to the largest shard
         self.gathered = [torch.zeros_like(self.sol) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def gather_rows(self, rows):
+        """rows [count][width] (a tensor on the buffers' device) -> record buffer, then the gather to rank 0"""
+        self.sol[:self.count].copy_(rows[:self.count])
+        if self.world > 1:
+            self.dist.gather(self.sol, self.gathered, dst=0)
 
     def pack_and_gather(self, sol_x, sol_u, sol_T):
         """sol_x [count][N][14], sol_u [count][N][7], sol_T [count] (tensors on the buffers' device) -> record buffer, then the
@@ -40,7 +48,7 @@ class ShardedBatch:
             self.dist.gather(self.sol, self.gathered, dst=0)
 
     def assemble(self):
-        """rank 0: the global result [total][21N+1] in problem order"""
+        """rank 0: the global result [total][width] in problem order"""
         if self.world == 1:
             return self.sol[:self.count]
         parts = []

@@ -694,6 +694,36 @@ void orc_mpc_point(const orc_model *mdl, int num_seg, const double *xs, const do
     orc_rnea(mdl, q, v, a, out + 21);
 }
 
+/* One state advance of the receding-horizon loop with its arrival rule (include/mpcmp.h, mpcmp_rh_run; kernel k_advance): single arm, nx = 14.
+   status = the status word of the solve that produced (xs, us, T).  x_io [14]: current state in / out.  Returns 1 when the instance is retired
+   by this step (it is then no longer re-solved), 0 otherwise.
+     - hard failure (NaN 1, lost positive definiteness 2, dead exchange 4) or T outside its box (32): the state is held;
+     - T <= dt: the plan ends within the control period: the state becomes its last node, the instance is retired;
+     - else the state advances by dt along the solution (get_MPC_point, motionPlanner.hpp:118-128; for dt < T its clamp never acts) and the
+       instance is retired when the new state lies inside the terminal box |x - xf|_inf <= eps_target (motionPlanner.hpp:44). */
+int orc_rh_advance(const orc_config *c, const double *xs, const double *us, double T, int status, double dt, const double *xf, double *x_io) {
+    (void)us;
+    const int num_seg = c->num_seg, N = 3 * num_seg + 1;
+    static const double xi[4] = {-1.0, -0.5, 0.5, 1.0};
+    if (status & (1 | 2 | 4 | 32)) return 0;
+    if (T <= dt) { memcpy(x_io, xs + 14 * (N - 1), sizeof(double) * 14); return 1; }
+    double t = dt / T;
+    int s = (int)floor(t * num_seg); if (s >= num_seg) s = num_seg - 1; if (s < 0) s = 0;
+    double x = 2.0 * (t * num_seg - s) - 1.0, L[4], far = 0.0;
+    for (int j = 0; j < 4; j++) {
+        double v = 1.0;
+        for (int k = 0; k < 4; k++) if (k != j) v *= (x - xi[k]) / (xi[j] - xi[k]);
+        L[j] = v;
+    }
+    for (int r = 0; r < 14; r++) {
+        double acc = 0.0;
+        for (int j = 0; j < 4; j++) acc += L[j] * xs[14 * (3 * s + j) + r];
+        x_io[r] = acc;
+        if (fabs(acc - xf[r]) > far) far = fabs(acc - xf[r]);
+    }
+    return far <= c->eps_target;
+}
+
 /* examples/benchmark.cpp:58-160 for one trajectory: out[74] = min(28) | max(28) | x(T)-target (14) | flags (4, 1 = pass) */
 void orc_traj_stats(const orc_model *mdl, int num_seg, const double *xs, const double *us, double T, const double *xf,
                     int n_pts, double *out) {

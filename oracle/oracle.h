@@ -162,6 +162,9 @@ void orc_sample(const orc_model *m, int num_seg, const double *xs, const double 
 /* get_MPC_point (motionPlanner.hpp:118-128) incl. its clamp; out = q(7), v(7), a(7), tau(7) */
 void orc_mpc_point(const orc_model *m, int num_seg, const double *xs, const double *us, double T, double time, double *out);
 
+/* state advance + arrival rule of the receding-horizon driver (mpcmp_rh_run, include/mpcmp.h): x_io [14] in / out; returns 1 if the instance is retired */
+int orc_rh_advance(const orc_config *c, const double *xs, const double *us, double T, int status, double dt, const double *xf, double *x_io);
+
 /* examples/benchmark.cpp:58-160: out[74] = min(28) | max(28) | x(T)-target (14) | flags jerk, lin vel, ang vel, collision */
 void orc_traj_stats(const orc_model *m, int num_seg, const double *xs, const double *us, double T, const double *xf,
                     int n_pts, double *out);

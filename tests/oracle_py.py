@@ -316,6 +316,21 @@ def mpc_point(num_seg, xs, us, T, time, model=None):
     lib().orc_mpc_point(C.byref(model), num_seg, _p(xs), _p(us), C.c_double(T), C.c_double(time), _p(out)); return out
 
 
+def rh_start_guess(cfg, x, xf):
+    """the receding-horizon driver's start guess (mpcmp_rh_run: first solve, and the restart of an instance whose previous solve is no guess): the
+    jerk-limited time-synchronised trajectory from the current state, velocity / acceleration limits of the configuration, jerk margin 0.1
+    (examples/offline_trajectory.cpp:9)"""
+    return warm_start_jerk(cfg.num_seg, np.array(cfg.ubx[7:14]), np.array(cfg.ubu[:]), 0.1 * default_limits()["jmax"], x, xf)
+
+
+def rh_advance(cfg, xs, us, T, status, dt, xf, x_now):
+    """state advance + arrival rule of the receding-horizon driver (orc_rh_advance): returns (new state [14], retired)"""
+    xs, us, xf = f64(xs), f64(us), f64(xf); x = f64(x_now).copy()
+    lib().orc_rh_advance.restype = C.c_int
+    r = lib().orc_rh_advance(C.byref(cfg), _p(xs), _p(us), C.c_double(T), int(status), C.c_double(dt), _p(xf), _p(x))
+    return x, bool(r)
+
+
 def traj_stats(num_seg, xs, us, T, xf, n_pts=200, model=None):
     model = model or default_model(); xs, us, xf = f64(xs), f64(us), f64(xf)
     out = np.zeros(74)

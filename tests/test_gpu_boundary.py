@@ -234,7 +234,8 @@ def test_config3_share_of_one_gpu_full_size(M):
 def test_receding_horizon_at_config5_shape(M):
     """BASELINE.json configs[4] shape: 512 instances, so that the step is the two-stream capture path (B >= 512).  Six
     graph-replayed steps equal six eagerly enqueued ones bit for bit, and three instances are followed by the oracle."""
-    cfg, ocfg = _cfgs(M, 4, 2)
+    cfg = M.default_config(4, 2, margins=MARGINS)                   # (the driver's defaults: carried multipliers, warm QP duals)
+    ocfg = o.default_config(4, 2, margins=MARGINS, carry_multipliers=1, qp_warm_start=1)
     from mpc_motion_planner_amd import scenarios
     B, steps, dt = 512, 6, 0.01
     x0, xf = scenarios.make_batch(B, MARGINS, stream_offset=2000)
@@ -247,14 +248,16 @@ def test_receding_horizon_at_config5_shape(M):
         assert np.array_equal(out[False][k], out[True][k]), k
     assert np.array_equal(out[False][4]["qp_iters_total"], out[True][4]["qp_iters_total"])
     for b in (0, 255, 511):                                         # one from each half-batch, and the last
-        xc = x0[b].copy(); prev = None
+        xc = x0[b].copy(); prev = None; lam = None
         for st in range(steps):
-            if prev is None:
-                wx, wu, wT = o.warm_start(ocfg, xc, xf[b])
+            if prev is None or (prev[3] & (1 | 2 | 4 | 32)):
+                wx, wu, wT = o.rh_start_guess(ocfg, xc, xf[b])
             else:
                 wx, wu, wT = prev[0].copy(), prev[1], prev[2]
                 wx[0] = xc; wx[-1] = xf[b]
-            xs, us, T, _ = o.solve(ocfg, xc, xf[b], wx, wu, wT)
-            prev = (xs, us, T)
-            xc = o.mpc_point(4, xs, us, T, dt)[:14]
+            xs, us, T, oi, lam = o.solve_carry(ocfg, xc, xf[b], wx, wu, wT, lam=lam)
+            prev = (xs, us, T, oi.status)
+            xc, retired = o.rh_advance(ocfg, xs, us, T, oi.status, dt, xf[b], xc)
+            assert not retired
         assert np.abs(out[True][0][b] - xc).max() < 1e-6 and abs(out[True][3][b] - T) < 1e-6
+        assert out[True][4]["qp_iters_total"][b] == oi.qp_iters_total

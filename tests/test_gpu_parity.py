@@ -278,33 +278,44 @@ def test_error_behaviour(M):
         M.Solver(bad, 1)                                   # unsupported NUM_SEG
 
 
+def _oracle_rh_chain(ocfg, x0, xf, steps, dt):
+    """mpcmp_rh_run restated with the oracle (include/mpcmp.h): re-guess rule of motionPlanner.cpp:199-207, a re-solve per live instance (from the multipliers
+    of the one before when ocfg.carry_multipliers), state advance + arrival rule (orc_rh_advance).  A failed solve (status & (1|2|4|32)) is not a guess:
+    built-in initialiser (k_init); orc_solve_carry hands back zero multipliers after one."""
+    B = len(x0); xc = x0.copy(); prev = [None] * B; lam = [None] * B
+    retired = np.zeros(B, dtype=bool); its = np.zeros(B, dtype=int); status = np.zeros(B, dtype=int); T_last = np.zeros(B); n_solves = 0
+    for _ in range(steps):
+        for b in range(B):
+            if retired[b]:
+                continue
+            n_solves += 1
+            if prev[b] is None or (prev[b][3] & (1 | 2 | 4 | 32)):
+                wx, wu, wT = o.rh_start_guess(ocfg, xc[b], xf[b])
+            else:
+                wx, wu, wT = prev[b][0].copy(), prev[b][1], prev[b][2]
+                wx[0] = xc[b]; wx[-1] = xf[b]
+            xs, us, T, oi, lam[b] = o.solve_carry(ocfg, xc[b], xf[b], wx, wu, wT, lam=lam[b])
+            prev[b] = (xs, us, T, oi.status); its[b] = oi.qp_iters_total; status[b] = oi.status; T_last[b] = T
+            xc[b], retired[b] = o.rh_advance(ocfg, xs, us, T, oi.status, dt, xf[b], xc[b])
+    return xc, T_last, its, status, retired, n_solves
+
+
 def test_receding_horizon_vs_oracle(M):
-    """BASELINE config #5 in miniature: warm-started re-solves + state advance, eager and hipGraph replay."""
-    cfg, ocfg = _cfgs(M, 4, 2)
+    """BASELINE config #5 in miniature: warm-started re-solves + state advance, eager and hipGraph replay; here with both start flags OFF (-1):
+    every re-solve starts from lambda = 0 and every QP cold (the round-1..4 behaviour of the driver)"""
+    cfg, ocfg = M.default_config(4, 2, margins=MARGINS, qp_warm_start=-1, carry_multipliers=-1), o.default_config(4, 2, margins=MARGINS)
     from mpc_motion_planner_amd import scenarios
     B, steps, dt = 3, 4, 0.05
     x0, xf = scenarios.make_batch(B, stream_offset=40)
-    # oracle loop
-    xc = x0.copy(); prev = [None] * B; ref = []
-    for st in range(steps):
-        for b in range(B):
-            if prev[b] is None:
-                wx, wu, wT = o.warm_start(ocfg, xc[b], xf[b])
-            else:
-                wx, wu, wT = prev[b][0].copy(), prev[b][1], prev[b][2]
-                wx[0] = xc[b]; wx[-1] = xf[b]                      # motionPlanner.cpp:199-207
-            xs, us, T, _ = o.solve(ocfg, xc[b], xf[b], wx, wu, wT)
-            prev[b] = (xs, us, T)
-            xc[b] = o.mpc_point(4, xs, us, T, dt)[:14]
-        ref.append((xc.copy(), np.array([p[2] for p in prev])))
+    xr, Tr, its, st, ret, ns = _oracle_rh_chain(ocfg, x0, xf, steps, dt)
     for use_graph in (False, True):
         s = M.Solver(cfg, B)
         s.rh_init(x0, xf)
         s.rh_run(steps, dt, use_graph=use_graph)
         xg, sx, su, sT, info = s.rh_get()
-        assert np.abs(xg - ref[-1][0]).max() < 1e-6, (use_graph, np.abs(xg - ref[-1][0]).max())
-        assert np.abs(sT - ref[-1][1]).max() < 1e-6
-        assert np.all((info["status"] & 7) == 0)
+        assert np.abs(xg - xr).max() < 1e-6, (use_graph, np.abs(xg - xr).max())
+        assert np.abs(sT - Tr).max() < 1e-6 and np.array_equal(info["qp_iters_total"], its)
+        assert np.all((info["status"] & 7) == 0) and s.rh_stats() == (ns, 0)
     # graph replay continues where the eager run stopped: run 2 + 2 equals run 4
     s = M.Solver(cfg, B); s.rh_init(x0, xf); s.rh_run(2, dt, use_graph=True); s.rh_run(2, dt, use_graph=True)
     assert np.array_equal(s.rh_get()[0], xg)
@@ -312,36 +323,27 @@ def test_receding_horizon_vs_oracle(M):
 
 @pytest.mark.parametrize("nseg", [4, 6])
 def test_carried_multipliers_vs_oracle(M, nseg):
-    """mpcmp_config.carry_multipliers (+ qp_warm_start): (i) the receding-horizon loop, every re-solve starting from the multipliers of the one before
-    (k_qp2), eager and graph replay; (ii) re-solves through the plain solve call on one context (N = 13: k_qp2, N = 19: k_qp3f + k_qp5), reset in between;
-    against the oracle's chain with the multipliers handed from solve to solve: identical ADMM iteration counts"""
+    """(i) the receding-horizon driver's DEFAULT (flags 0 = carry_multipliers + qp_warm_start on inside mpcmp_rh_run): every re-solve starts from the
+    multipliers of the one before (k_qp2), eager and graph replay, equal to the flags set to 1 explicitly; (ii) re-solves through the plain solve call on
+    one context with the flags set (N = 13: k_qp2, N = 19: k_qp3f + k_qp5), reset in between; against the oracle's chain with the multipliers handed
+    from solve to solve: identical ADMM iteration counts"""
     cfg, ocfg = _cfgs(M, nseg, 2, carry_multipliers=1, qp_warm_start=1)
     from mpc_motion_planner_amd import scenarios
     B, steps, dt = 4, 4, 0.02
     x0, xf = scenarios.make_batch(B, stream_offset=900)
     if nseg == 4:
-        xc = x0.copy(); prev = [None] * B; lam = [None] * B; its = np.zeros(B, dtype=int)
-        for st in range(steps):
-            for b in range(B):
-                if prev[b] is None or (prev[b][3] & (1 | 2 | 4 | 32)):      # (a failed solve is not a guess: built-in initialiser, as k_init does)
-                    wx, wu, wT = o.warm_start(ocfg, xc[b], xf[b])
-                else:
-                    wx, wu, wT = prev[b][0].copy(), prev[b][1], prev[b][2]
-                    wx[0] = xc[b]; wx[-1] = xf[b]
-                xs, us, T, oi, lam[b] = o.solve_carry(ocfg, xc[b], xf[b], wx, wu, wT, lam=lam[b])
-                prev[b] = (xs, us, T, oi.status); its[b] = oi.qp_iters_total
-                if not oi.status & (1 | 2 | 4 | 32):                        # (k_advance: no trajectory to follow after a failed solve)
-                    xc[b] = o.mpc_point(4, xs, us, T, dt)[:14]
+        xc, Tr, its, st, ret, ns = _oracle_rh_chain(ocfg, x0, xf, steps, dt)
         for use_graph in (False, True):
-            s = M.Solver(cfg, B)
-            s.rh_init(x0, xf)
-            s.rh_run(steps, dt, use_graph=use_graph)
-            xg, sx, su, sT, info = s.rh_get()
-            assert np.array_equal(info["qp_iters_total"], its), (use_graph, info["qp_iters_total"], its)
-            assert np.abs(xg - xc).max() < 1e-6 and np.abs(sT - np.array([p[2] for p in prev])).max() < 1e-6
-            s.rh_init(x0, xf)                                 # (a new set of instances: nothing carried over)
-            s.rh_run(steps, dt, use_graph=use_graph)
-            assert np.array_equal(s.rh_get()[0], xg)
+            for c in (M.default_config(nseg, 2, margins=MARGINS), cfg):           # the driver's default, and the flags spelled out
+                s = M.Solver(c, B)
+                s.rh_init(x0, xf)
+                s.rh_run(steps, dt, use_graph=use_graph)
+                xg, sx, su, sT, info = s.rh_get()
+                assert np.array_equal(info["qp_iters_total"], its), (use_graph, info["qp_iters_total"], its)
+                assert np.abs(xg - xc).max() < 1e-6 and np.abs(sT - Tr).max() < 1e-6
+                s.rh_init(x0, xf)                                 # (a new set of instances: nothing carried over)
+                s.rh_run(steps, dt, use_graph=use_graph)
+                assert np.array_equal(s.rh_get()[0], xg)
     # plain solves on one context: solve, re-solve from the solution (motionPlanner.cpp:199-207), reset, solve again
     s = M.Solver(cfg, B)
     wx, wu, wT = s.warm_start(x0, xf)
@@ -358,25 +360,91 @@ def test_carried_multipliers_vs_oracle(M, nseg):
         xs2, us2, T2, oi2, _ = o.solve_carry(ocfg, x0[b], xf[b], g, us, T, lam=lam)
         assert oi2.qp_iters_total == i2["qp_iters_total"][b], (b, oi2.qp_iters_total, i2["qp_iters_total"][b])
         assert abs(sT2[b] - T2) <= 1e-6 * T2 and np.abs(sx2[b] - xs2).max() <= 1e-5 and oi2.status == i2["status"][b]
+    # the plain solve call's default stays OFF: flags 0 = cold QPs from lambda = 0, whatever the slot's previous solve left behind
+    s0 = M.Solver(M.default_config(nseg, 2, margins=MARGINS), B)
+    a = s0.solve(x0, xf, (wx, wu, wT)); b_ = s0.solve(x0, xf, (wx, wu, wT))
+    assert np.array_equal(a[0], b_[0]) and np.array_equal(a[3]["qp_iters_total"], b_[3]["qp_iters_total"])
+    ocold = o.default_config(nseg, 2, margins=MARGINS)
+    assert a[3]["qp_iters_total"][0] == o.solve(ocold, x0[0], xf[0], wx[0], wu[0], wT[0])[3].qp_iters_total
 
 
-def test_receding_horizon_with_carried_multipliers_survives_the_degenerate_tail(M):
-    """configs[4] in full length (200 re-solves of 10 ms: most instances arrive, T -> 0 and the OCP degenerates) with carried multipliers: an instance whose
-    solve leaves the box of T or fails hard holds its state and restarts from the built-in guess with lambda = 0 (k_advance, k_init), so nothing is lost
-    for good: every state stays finite, no instance ends in a hard failure, and the run is bitwise repeatable"""
-    cfg, _ = _cfgs(M, 4, 2, carry_multipliers=1, qp_warm_start=1)
+def test_receding_horizon_arrival_vs_oracle(M):
+    """arrival (include/mpcmp.h, mpcmp_rh_run): control periods so long that every instance arrives within a few re-solves.  The oracle chain with the
+    same rule retires the same instances in the same steps: equal states, final times, ADMM iteration counts of the last solve executed, ARRIVED
+    bits and re-solve counts, eager and graph replay; a retired instance keeps its state and record while the others go on"""
+    cfg, ocfg = M.default_config(4, 2, margins=MARGINS), o.default_config(4, 2, margins=MARGINS, carry_multipliers=1, qp_warm_start=1)
     from mpc_motion_planner_amd import scenarios
-    B = 128
+    B, dt = 6, 0.4
+    x0, xf = scenarios.make_batch(B, stream_offset=900)
+    for steps in (3, 10):
+        xr, Tr, its, st, ret, ns = _oracle_rh_chain(ocfg, x0, xf, steps, dt)
+        assert ret.any() and (steps == 3 and not ret.all() or steps == 10 and ret.all())
+        for use_graph in (False, True):
+            s = M.Solver(cfg, B)
+            s.rh_init(x0, xf)
+            s.rh_run(steps, dt, use_graph=use_graph)
+            xg, sx, su, sT, info = s.rh_get()
+            assert np.array_equal((info["status"] & M.STATUS_ARRIVED) != 0, ret), (steps, use_graph, info["status"], ret)
+            assert np.array_equal(info["status"] & 63, st) and np.array_equal(info["qp_iters_total"], its)
+            assert np.abs(xg - xr).max() < 1e-6 and np.abs(sT - Tr).max() < 1e-6 * np.abs(Tr).max()
+            assert s.rh_stats() == (ns, int(ret.sum()))
+            if steps == 10:      # everybody has arrived: further steps change nothing and solve nothing
+                s.rh_run(3, dt, use_graph=use_graph)
+                assert np.array_equal(s.rh_get()[0], xg) and s.rh_stats() == (ns, B)
+                assert np.abs(xg - xf).max() <= cfg.eps_target + 1e-9 or np.all(sT <= dt)
+
+
+def test_failed_solve_holds_state_and_restarts_vs_oracle(M):
+    """the hard bits of the FINAL iterate (T outside its box, NaN) exist only in the record k_step writes; they are now written back to the
+    workspace status the next k_init / k_advance read.  A final-time box too narrow for most instances ([0, 1.5] s) makes their solves end with
+    MPCMP_STATUS_T_OUT_OF_BOX: such an instance holds its state, re-solves from the built-in guess and carries no multipliers — the oracle chain
+    does the same (orc_solve_carry zeroes lam_io, the chain restarts): equal states, iteration counts and status words after every step count"""
+    kw = dict(lbT=0.0, ubT=1.5)
+    cfg, ocfg = M.default_config(4, 2, margins=MARGINS, **kw), o.default_config(4, 2, margins=MARGINS, carry_multipliers=1, qp_warm_start=1, **kw)
+    from mpc_motion_planner_amd import scenarios
+    B, dt = 6, 0.05
+    x0, xf = scenarios.make_batch(B, stream_offset=900)
+    saw_held = False
+    for steps in (1, 2, 4):
+        xr, Tr, its, st, ret, ns = _oracle_rh_chain(ocfg, x0, xf, steps, dt)
+        s = M.Solver(cfg, B)
+        s.rh_init(x0, xf)
+        s.rh_run(steps, dt, use_graph=(steps == 4))
+        xg, sx, su, sT, info = s.rh_get()
+        assert np.array_equal(info["status"] & 63, st), (steps, info["status"], st)
+        assert np.array_equal(info["qp_iters_total"], its), (steps, info["qp_iters_total"], its)
+        assert np.abs(xg - xr).max() < 1e-6
+        if steps == 1:
+            bad = (st & 32) != 0
+            assert bad.any() and not bad.all()
+            assert np.array_equal(xg[bad], x0[bad])           # held: there is no trajectory to follow
+            saw_held = True
+    assert saw_held
+
+
+def test_receding_horizon_full_length_no_hard_failure(M):
+    """configs[4] in full: 512 instances x 200 re-solves of 10 ms with the driver's defaults (carried multipliers, warm QP duals, arrival).  Most
+    instances arrive; NO instance ends in a hard failure, with a NaN or with T outside its box, every state is finite, the arrived ones sit where
+    their plan ended, the live re-solve count is what the arrivals leave, and the run is bitwise repeatable"""
+    cfg = M.default_config(4, 2, margins=MARGINS)
+    from mpc_motion_planner_amd import scenarios
+    B, steps = 512, 200
     x0, xf = scenarios.make_batch(B, MARGINS)
     s = M.Solver(cfg, B)
     outs = []
     for rep in range(2):
         s.rh_init(x0, xf)
-        s.rh_run(200, 0.01, use_graph=True)
+        s.rh_run(steps, 0.01, use_graph=True)
         xg, sx, su, sT, info = s.rh_get()
-        outs.append((xg.copy(), info["status"].copy()))
-        assert np.all(np.isfinite(xg)), np.argwhere(~np.isfinite(xg))[:4]
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        done, arrived = s.rh_stats()
+        outs.append((xg.copy(), info["status"].copy(), done, arrived))
+        assert np.all(np.isfinite(xg)) and np.all(np.isfinite(sT))
+        assert np.all((info["status"] & 7) == 0), np.flatnonzero(info["status"] & 7)[:8]
+        assert ((info["status"] & M.STATUS_T_OUT_OF_BOX) != 0).mean() <= 0.01, np.flatnonzero(info["status"] & 32)[:8]      # (transient: such an instance restarts)
+        arr = (info["status"] & M.STATUS_ARRIVED) != 0
+        assert arrived == int(arr.sum()) and arrived > B // 16
+        assert B <= done < B * steps and done >= B * steps - arrived * steps
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2:] == outs[1][2:]
 
 
 def test_more_than_255_capped_qps_are_counted(M):

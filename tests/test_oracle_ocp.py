@@ -285,7 +285,7 @@ def test_status_word_semantics():
     import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mpcmp.h")).read()
     bits = {k: int(v) for k, v in re.findall(r"#define MPCMP_STATUS_(\w+)\s+(\d+)", hdr)}
-    assert bits == {"NAN": 1, "NOT_PD": 2, "XCH_DEAD": 4, "QP_CAPPED": 8, "OUTSIDE_TOL": 16, "T_OUT_OF_BOX": 32}
+    assert bits == {"NAN": 1, "NOT_PD": 2, "XCH_DEAD": 4, "QP_CAPPED": 8, "OUTSIDE_TOL": 16, "T_OUT_OF_BOX": 32, "ARRIVED": 64}
     margins = (0.9, 0.9, 0.5, 0.9, 0.1)
     x0 = np.array([0.0, -0.5, 0.0, -2.0, 0.0, 1.6, 0.0] + [0.0] * 7); xf = x0.copy(); xf[:7] += 0.05         # an easy problem
     # (a) every QP is cut off after 5 iterations: capped, the count says how often
@@ -303,3 +303,42 @@ def test_status_word_semantics():
     cfg = o.default_config(4, 2, margins=margins); cfg.ubT = 0.05
     _, _, T, info = o.solve(cfg, x0, xf, xg, ug, Tg)
     assert (T > cfg.ubT + 1e-9) == bool(info.status & 32)
+
+
+MARGINS = (0.9, 0.9, 0.5, 0.9, 0.1)
+
+
+def test_receding_horizon_arrival_rule():
+    """orc_rh_advance (the arrival rule of mpcmp_rh_run, include/mpcmp.h): a failed solve holds the state; a plan that ends within the control period is
+    followed to its last node and retires the instance; an advance into the terminal box retires it; otherwise the state is the solution at time dt
+    (get_MPC_point, motionPlanner.hpp:118-128)"""
+    cfg = o.default_config(4, 2, margins=MARGINS)
+    rng = np.random.default_rng(3)
+    xs, us = rng.normal(size=(13, 14)), rng.normal(size=(13, 7))
+    xf, x_now = xs[-1] + 0.5, rng.normal(size=14)
+    for st in (1, 2, 4, 32, 33):                                    # held
+        x, r = o.rh_advance(cfg, xs, us, 2.0, st, 0.1, xf, x_now)
+        assert not r and np.array_equal(x, x_now)
+    x, r = o.rh_advance(cfg, xs, us, 0.05, 8 | 16, 0.1, xf, x_now)   # T <= dt: end of the plan, retired
+    assert r and np.array_equal(x, xs[-1])
+    x, r = o.rh_advance(cfg, xs, us, 2.0, 0, 0.1, xf, x_now)         # plain advance = get_MPC_point
+    assert not r and np.abs(x - o.mpc_point(4, xs, us, 2.0, 0.1)[:14]).max() < 1e-14
+    xf2 = o.mpc_point(4, xs, us, 2.0, 0.1)[:14] + 0.5 * cfg.eps_target
+    x, r = o.rh_advance(cfg, xs, us, 2.0, 0, 0.1, xf2, x_now)        # lands inside the terminal box
+    assert r
+    # a short chain on a real scenario: arrival after a few long periods, inside the terminal box or at the end of a plan shorter than dt
+    from mpc_motion_planner_amd import scenarios
+    ocfg = o.default_config(4, 2, margins=MARGINS, carry_multipliers=1, qp_warm_start=1)
+    x0, xfb = scenarios.make_batch(1, MARGINS, stream_offset=901)
+    xc, prev, lam, steps = x0[0].copy(), None, None, 0
+    for steps in range(1, 20):
+        if prev is None or (prev[3] & (1 | 2 | 4 | 32)):
+            wx, wu, wT = o.rh_start_guess(ocfg, xc, xfb[0])
+        else:
+            wx, wu, wT = prev[0].copy(), prev[1], prev[2]; wx[0] = xc; wx[-1] = xfb[0]
+        xs, us, T, oi, lam = o.solve_carry(ocfg, xc, xfb[0], wx, wu, wT, lam=lam)
+        prev = (xs, us, T, oi.status)
+        xc, r = o.rh_advance(ocfg, xs, us, T, oi.status, 0.4, xfb[0], xc)
+        if r:
+            break
+    assert r and 2 <= steps <= 12 and (T <= 0.4 or np.abs(xc - xfb[0]).max() <= ocfg.eps_target)
