@@ -90,8 +90,10 @@ def _torch_runtime_first():
     if importlib.util.find_spec("torch") is not None:
         try:
             import torch  # noqa: F401
-        except Exception:
-            pass
+        except Exception as e:      # (say so — the system HIP runtime is mapped first now, and a later `import torch` would find no GPU)
+            import warnings
+            warnings.warn("mpc_motion_planner_amd: importing torch before loading libmpcmp.so failed (%r); a later `import torch` in this process "
+                          "may report no GPU.  Set MPCMP_NO_TORCH_PRELOAD=1 to skip the preload." % (e,))
 
 
 def lib():

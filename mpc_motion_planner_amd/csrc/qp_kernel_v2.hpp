@@ -220,6 +220,18 @@ struct Qp2Ctx {
 #ifndef MPCMP_ABL
 #define MPCMP_ABL 0
 #endif
+// LDS-queue staggering (tools/isa_phases.py): a phase lasts (LDS-array time of everything queued ahead of the critical role's operand reads) +
+// (that role's chain).  The roles that are NOT on a phase's critical path sleep 64 x n cycles before they issue their own reads of that phase.
+#ifndef MPCMP_SLP_P1
+#define MPCMP_SLP_P1 0      /* role A1 before its P1 operand reads (critical: role A2) */
+#endif
+#ifndef MPCMP_SLP_P2
+#define MPCMP_SLP_P2 0      /* role A1 before its P2 operand reads (critical: role B) */
+#endif
+#ifndef MPCMP_SLP_P3
+#define MPCMP_SLP_P3 0      /* roles A2 and B before their constant prefetches in P3 (critical: role A1) */
+#endif
+#define MPCMP_SLEEP(n) do { if ((n) > 0) __builtin_amdgcn_s_sleep(n); } while (0)
 #define ABL_ON(n) (MPCMP_ABL != (n) && MPCMP_ABL != 10)      /* 10: every piece off — the bare five-barrier loop with its termination tests */
 #ifdef MPCMP_STAMPS
 // the accumulators of the loop stamps live in LDS: role A1 has no registers to spare
@@ -339,6 +351,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
             double a0 = 0.0, a1 = 0.0;
             D2 bv[7];
             if (ABL_ON(6)) {
+                MPCMP_SLEEP(MPCMP_SLP_P1);
 #pragma unroll
                 for (int j = 0; j < JS; j++) bv[j] = lds2(bj + 2 * j);
 #pragma unroll
@@ -350,6 +363,7 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
             BUSY_SYNC(1);
             STAMP2(4);
             if (ABL_ON(9)) {
+                MPCMP_SLEEP(MPCMP_SLP_P2);
 #pragma unroll
                 for (int j = JS; j < 7; j++) bv[j] = lds2(bj + 2 * j);
 #pragma unroll
@@ -552,6 +566,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         // ---- P3 (role A1): this role is idle, so the constant operands of the E phase (Jacobian rows, row bounds) are
         // fetched now and only x~ remains to be read once P3 has produced it ----
         D2 p0[3], p1[3];
+        MPCMP_SLEEP(MPCMP_SLP_P3);
         {
             const double *g0 = gkl + groff + (pq & 1) * GS, *g1 = gkl + groff + (1 - (pq & 1)) * GS;     // own row first
 #pragma unroll
@@ -793,6 +808,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         BUSY_SYNC(2);
         // ---- P3: (group A); this role is idle: the remaining copies of x_T, and the constant operands of the E phase ----
         if (u < N && (u % 3 != 0 || u == 0)) xn[u * XS + 21] = xn[3 * XS + 21];
+        MPCMP_SLEEP(MPCMP_SLP_P3);
         const double rc[4] = {rcl[0], rcl[1], rcl[2], rcl[3]};
         const double vrbi = vcl[12 * L::NB], vlb = vcl[10 * L::NB], vub = vcl[11 * L::NB];
         BUSY_SYNC(3);
@@ -1089,6 +1105,89 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, Qp2Stream
     if (isVar && ipos < nJ) KJC[(ipos / 49) * D::JC + (ipos % 49) * 29 + 28] += v_ha;
     __syncthreads();
     STAMP(9);
+#ifndef MPCMP_QP2_AUGSWEEP
+    // Interior blocks: K_JJ,s <- -G_s = -(K_JJ,s^-1) by one symmetric sweep per segment (49 pivots, all segments concurrently, 91 tiles each), then
+    // the two block GEMMs of the QP on the MATRIX CORES (v_mfma_f64_16x16x4_f64; north star: "MFMA only for the one true dense block GEMM"):
+    //     E_s = G_s K_JC,s        (49 x 49 by 49 x 29)        and        K_CJ,s E_s        (29 x 49 by 49 x 29, the segment's Schur complement term).
+    // Two waves per segment, one 16-column tile of E_s each.  Lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; register r of the result holds
+    // row (l >> 4) + 4 r, column l & 15.  So register r of row tile mt of E_s IS the B operand of k-step 4 mt + r of the second product, and a
+    // fragment of K_JC is the B operand of the first product and the A operand (K_CJ = K_JC^T) of the second: no data movement between the GEMMs.
+    // (Until round 4 one sweep of the augmented [[K_JJ, K_JC], [K_CJ, 0]] (78 x 78) did all three on the vector ALUs: -DMPCMP_QP2_AUGSWEEP.)
+    sweep(49, 49, NSEG, 80,
+          [&](int blk, int i, int j) -> double { return KJJ[blk * D::JP + packed(i, j)]; },
+          [&](int blk, int i, int j, double val) { KJJ[blk * D::JP + packed(i, j)] = val; },
+          [&](int, int, int, double) {});
+    STAMP(11);
+    {
+        using V4 = __attribute__((ext_vector_type(4))) double;
+        const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+        const int sw = wv >> 1, hf = wv & 1;
+        const bool mm = wv < 2 * NSEG;
+        const double *Gn = KJJ + (mm ? sw : 0) * D::JP;
+        double *Kc = KJC + (mm ? sw : 0) * D::JC;
+        V4 e[4], sacc[2];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) e[mt] = V4{0.0, 0.0, 0.0, 0.0};
+        sacc[0] = V4{0.0, 0.0, 0.0, 0.0}; sacc[1] = V4{0.0, 0.0, 0.0, 0.0};
+        if (mm) {
+            // fragment (ks, t) of K_JC: entry [4 ks + lk][16 t + li] (rows >= 49, columns >= 29: zero); loads with safe indices, then selects
+            auto frag = [&](int ks, int t) -> double {
+                const int row = 4 * ks + lk, col = 16 * t + li;
+                const bool in = row < 49 && col < 29;
+                const double v = Kc[(in ? row : 0) * 29 + (in ? col : 0)];
+                return in ? v : 0.0;
+            };
+#pragma unroll
+            for (int ks = 0; ks < 13; ks++) {
+                const int k = 4 * ks + lk;
+                const double bf = frag(ks, hf);
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const int i = 16 * mt + li;
+                    const bool in = i < 49 && k < 49;
+                    const double g = -Gn[packed(in ? i : 0, in ? k : 0)];
+                    e[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? g : 0.0, bf, e[mt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 13; ks++) {
+#pragma unroll
+                for (int mt2 = 0; mt2 < 2; mt2++)
+                    if (mt2 >= hf) sacc[mt2] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag(ks, mt2), e[ks >> 2][ks & 3], sacc[mt2], 0, 0, 0);
+            }
+        }
+        __syncthreads();          // every fragment of K_JC has been read: E_s takes its place
+        if (mm) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int R = 16 * mt + lk + 4 * r, Cc = 16 * hf + li;
+                    if (R < 49 && Cc < 29) Kc[R * 29 + Cc] = e[mt][r];
+                }
+            }
+        }
+        // S -= K_CJ,s E_s (lower triangle), one segment at a time: neighbouring segments share the block of their common interface node, all share T
+        for (int sblk = 0; sblk < NSEG; sblk++) {
+            if (mm && sw == sblk) {
+#pragma unroll
+                for (int mt2 = 0; mt2 < 2; mt2++) {
+                    if (mt2 >= hf) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int R = 16 * mt2 + lk + 4 * r, Cc = 16 * hf + li;
+                            if (R < 29 && Cc < 29 && R >= Cc) {
+                                const int ia = R < 28 ? 14 * sw + R : nI - 1, ib = Cc < 28 ? 14 * sw + Cc : nI - 1;
+                                S[packed(ia, ib)] -= sacc[mt2][r];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#else
     // One sweep per segment of the symmetric [[K_JJ, K_JC], [K_CJ, 0]] (78 x 78) on its 49 interior pivots, all segments
     // concurrently:  K_JJ <- -G_s,  K_JC <- E_s = G_s K_JC,  trailing block = -K_CJ E_s, which is the segment's Schur
     // complement contribution and is added to S.
@@ -1106,6 +1205,7 @@ __global__ __launch_bounds__(1024) void k_qp2(mpcmp_config cfg, WS ws, Qp2Stream
               S[packed(ia, ib)] += val;
           });
     STAMP(11);
+#endif
     // -G_s and E_s stay where the sweep left them (K_JJ / K_JC areas): the role threads pick their register blocks up from
     // there before the ADMM view overlays the factor area
     STAMP(14);

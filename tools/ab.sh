@@ -9,8 +9,8 @@ git show HEAD:mpc_motion_planner_amd/csrc/qp_kernel_v2.hpp > "$TMP/qp_kernel_v2.
 for f in mpc_motion_planner_amd/csrc/*.hpp mpc_motion_planner_amd/csrc/mpcmp.hip; do [ "$(basename $f)" = qp_kernel_v2.hpp ] || cp "$f" "$TMP/"; done
 mkdir -p "$TMP/../include_ab" && true
 ( cd "$TMP" && sed -i 's|"../../include/mpcmp.h"|"'"$ROOT"'/include/mpcmp.h"|' mpcmp.hip *.hpp && \
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xclang -target-feature -Xclang -load-store-opt -o "$ROOT/tools/micro/libabl0.bin" mpcmp.hip ) &
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xclang -target-feature -Xclang -load-store-opt -o tools/micro/libabl11.bin mpc_motion_planner_amd/csrc/mpcmp.hip &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xclang -target-feature -Xclang -load-store-opt -falign-loops=64 -o "$ROOT/tools/micro/libabl0.bin" mpcmp.hip ) &
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xclang -target-feature -Xclang -load-store-opt -falign-loops=64 -o tools/micro/libabl11.bin mpc_motion_planner_amd/csrc/mpcmp.hip &
 wait
 rm -rf "$TMP"
 timeout 3000 /usr/local/graft/bin/gpurun --timeout 900 -- 'python tools/ablate.py 0 11 0 11 0 11 0 11 2>&1 | tail -8' 2>&1 | tail -8

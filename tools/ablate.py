@@ -20,7 +20,7 @@ from mpc_motion_planner_amd import scenarios
 for n in which:
     so = os.path.join(ROOT, "tools", "micro", "libabl%d.bin" % n)
     if not os.path.exists(so):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt", *(["-DMPCMP_WPERM=" + WPERM[n]] if n in WPERM else ["-DMPCMP_ABL=%d" % n]),
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-falign-loops=64", *(["-DMPCMP_WPERM=" + WPERM[n]] if n in WPERM else ["-DMPCMP_ABL=%d" % n]),
                                "-o", so, os.path.join(ROOT, "mpc_motion_planner_amd", "csrc", "mpcmp.hip")])
 if "--build-only" in os.environ.get("ABLATE_MODE", ""):
     sys.exit(0)

@@ -21,7 +21,7 @@ KERNELS = {"k_qp5": "_ZN5mpcmp5k_qp5ILi6E", "k_qp3": "_ZN5mpcmp5k_qp3ILi6ELi1E",
 
 def compile_isa(tmp):
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang",
-           "-load-store-opt", "-DMPCMP_SPLIT_N25", "--save-temps", "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include"),
+           "-load-store-opt", "-falign-loops=64", "-DMPCMP_SPLIT_N25", "--save-temps", "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include"),
            "-c", "-o", os.path.join(tmp, "m.o"), os.path.join(CSRC, "mpcmp.hip")]
     r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
     if r.returncode:
