@@ -232,13 +232,6 @@ struct Qp2Ctx {
 #ifndef MPCMP_SLP_P3
 #define MPCMP_SLP_P3 0      /* roles A2 and B before their constant prefetches in P3 (critical: role A1) */
 #endif
-// iterations of the next test period, and whether a period ends without a test (cut short by qp_iters; -DMPCMP_NOCHECK: never a test)
-#define MPCMP_PERIOD(cfg, it) (((cfg).qp_iters - (it)) < (cfg).check_every ? ((cfg).qp_iters - (it)) : (cfg).check_every)
-#ifdef MPCMP_NOCHECK
-#define MPCMP_NO_TEST(cfg, period) (true || (period) < (cfg).check_every)
-#else
-#define MPCMP_NO_TEST(cfg, period) ((period) < (cfg).check_every)
-#endif
 #define MPCMP_SLEEP(n) do { if ((n) > 0) __builtin_amdgcn_s_sleep(n); } while (0)
 #define ABL_ON(n) (MPCMP_ABL != (n) && MPCMP_ABL != 10)      /* 10: every piece off — the bare five-barrier loop with its termination tests */
 #ifdef MPCMP_STAMPS

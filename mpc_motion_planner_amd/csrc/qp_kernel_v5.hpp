@@ -342,21 +342,29 @@ __device__ __forceinline__ void q5_finish_border(const Qp5Ctx<NSEG> &c) {
     __syncthreads();
 }
 
-// termination test, common tail (every thread): combine the maxima and the two sums of the T row / column in ONE reduction, add the row /
-// column of T, decide.  Two barriers.
+// termination test in two stages (every thread; the result is the conjunction the one-stage test formed): the PRIMAL residual first — it fails in
+// nine tests of ten on the bench workloads — and the dual one, with everything it needs (A^T y of the path rows, the gathers, the sums of the T row /
+// column), only if it passes.  Two barriers each; the T variable's own terms are added from its published state.
 template <int NSEG>
-__device__ __forceinline__ int q5_check_tail(const Qp5Ctx<NSEG> &c, const double (&sums)[2], const double (&mxi)[6]) {
+__device__ __forceinline__ int q5_primal_ok(const Qp5Ctx<NSEG> &c, const double (&mp)[3]) {
     using L = Qp5<NSEG>;
     const double *misc = c.lds + L::oMisc;
-    double v[8] = {mxi[0], mxi[1], mxi[2], mxi[3], mxi[4], mxi[5], sums[0], sums[1]};
-    block_reduce_lean<L::NWV, 8, 6>(v, c.lds + L::oRedP, c.tid);
-    const double xTv = misc[L::M_xT], zT = misc[L::M_zbT], yT = misc[L::M_ybT];
-    const double hxT = misc[L::M_hdT] * xTv + v[7], atyT = v[6] + yT;
+    double v[3] = {mp[0], mp[1], mp[2]};
+    block_reduce_lean<L::NWV, 3, 3>(v, c.lds + L::oRedP, c.tid);
+    const double xTv = misc[L::M_xT], zT = misc[L::M_zbT];
     const double m0 = fmax(v[0], fabs(xTv - zT)), m1 = fmax(v[1], fabs(xTv)), m2 = fmax(v[2], fabs(zT));
-    const double m3 = fmax(v[3], fabs(hxT + atyT + 1.0)), m4 = fmax(v[4], fabs(hxT)), m5 = fmax(v[5], fabs(atyT));
-    const double ep = c.cfg->eps_abs + c.cfg->eps_rel * fmax(m1, m2);
-    const double ed = c.cfg->eps_abs + c.cfg->eps_rel * fmax(fmax(m4, m5), 1.0);      // ||q||_inf = 1
-    return (m0 <= ep && m3 <= ed) ? 1 : 0;
+    return m0 <= c.cfg->eps_abs + c.cfg->eps_rel * fmax(m1, m2) ? 1 : 0;
+}
+template <int NSEG>
+__device__ __forceinline__ int q5_dual_ok(const Qp5Ctx<NSEG> &c, const double (&sums)[2], const double (&md)[3]) {
+    using L = Qp5<NSEG>;
+    const double *misc = c.lds + L::oMisc;
+    double v[5] = {md[0], md[1], md[2], sums[0], sums[1]};
+    block_reduce_lean<L::NWV, 5, 3>(v, c.lds + L::oRedP + 48, c.tid);      // (its own slots: the primal reduction's are still being read)
+    const double xTv = misc[L::M_xT], yT = misc[L::M_ybT];
+    const double hxT = misc[L::M_hdT] * xTv + v[4], atyT = v[3] + yT;
+    const double m3 = fmax(v[0], fabs(hxT + atyT + 1.0)), m4 = fmax(v[1], fabs(hxT)), m5 = fmax(v[2], fabs(atyT));
+    return m3 <= c.cfg->eps_abs + c.cfg->eps_rel * fmax(fmax(m4, m5), 1.0) ? 1 : 0;      // ||q||_inf = 1
 }
 
 // ---- a variable lane (k_qp2's role B): ADMM state of one variable, its constants lane-transposed in LDS ----
@@ -428,6 +436,23 @@ __device__ __forceinline__ double q5_path_rows(double *lds, int gro, int xno, in
     return ax;
 }
 
+// A x of the owned path row alone (stage one of the termination test)
+template <int NSEG>
+__device__ __forceinline__ double q5_path_ax(const double *lds, int gro, int xno, int t, const double *xe) {
+    const double *xv = xe + xno;
+    v2d x2[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) x2[j] = ldv2(xv + 2 * j);
+    const PathOp5 o = q5_path_fetch<NSEG>(lds, gro, t);
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        a0 += o.pa[j].x * x2[j].x; a1 += o.pb[j].x * x2[j].x;
+        a0 += o.pa[j].y * x2[j].y; a1 += o.pb[j].y * x2[j].y;
+    }
+    return quad_sum2(a0, a1);
+}
+
 // ---- role G: waves 0 .. NSEG - 1.  P1 (wave = segment).  The path rows live here, sixteen lanes per node on the lanes below NPN: these
 // waves are idle in P2 and P3 (their Jacobian operands and row constants are fetched then) and their factor block leaves the most
 // registers.  The first sixteen lanes of the last G wave carry the variables that have no lane on the E / S waves, and T (state in LDS). ----
@@ -475,7 +500,7 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
     __syncthreads();
     q5_finish_border<NSEG>(c);
     Q5_STAMP_RESET;
-    int it = 0, done = 0, until_check = cfg.check_every;
+    int it = 0, done = 0;
     int pxr, prf, prb;          // last G wave: constants of phase A, fetched ahead of the barrier that ends the previous iteration
     {
         int t = tid;
@@ -514,7 +539,11 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
         }
         __syncthreads();
     }
-    for (it = 1; it <= cfg.qp_iters; it++) {
+    // (periods of check_every iterations in an inner loop without test code, the test after it: solver_kernels.hpp MPCMP_PERIOD)
+    while (it < cfg.qp_iters) {
+      const int period = MPCMP_PERIOD(cfg, it);
+#pragma nounroll
+      for (int kk = 0; kk < period; kk++) {
         int sio = tid;
         asm volatile("" : "+v"(sio));
         const int k0 = q5_lc<NSEG>(c, sio, 0), k1 = q5_lc<NSEG>(c, sio, 1), k2 = q5_lc<NSEG>(c, sio, 2), k3 = q5_lc<NSEG>(c, sio, 3);
@@ -538,8 +567,6 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
         // ---- P3 (role E) ----
         Q5B(3); Q5_BAR(3); Q5S(3);
         // ---- E: the path rows; the last G wave's variables ----
-        const bool check = MPCMP_CHECK_NOW(--until_check == 0);
-        if (check) until_check = cfg.check_every;
         if (wavePath) {
             if (isPath && Q5_ON(5)) {
                 q5_path_rows<NSEG>(lds, gro, xno, sio, lds + L::vXn, lds + L::vGp, [&](double zt, const PathOp5 &po) -> double {
@@ -560,13 +587,12 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
                 const double *rcl = lds + L::vRc + r;
                 const double lgd = ldv(rcl), rcT = ldv(rcl + L::NRC);
                 const double zt = row_dot_dyn(lds + L::vXn, q5_l5<NSEG>(c, sio & 63, 3), L::oCD + 4 * ((prb >> 17) & 3), rcT);
-                const double zr = alpha * zt + c.oma * ((it > 1 || warm) ? lgd : 0.0);
+                const double zr = alpha * zt + c.oma * ((it + kk > 0 || warm) ? lgd : 0.0);
                 yg += rho_eq * (zr - lgd);                  // the row is an equality: the projection of anything onto [l, l] is l
                 const double w = rho_eq * lgd - yg;
                 lds[L::vWg + r] = w;
                 const double tp = sum8(rcT * w);            // (ND5 is not a multiple of 8: the lanes behind the last row are masked off, their partial sum slot gets the sum of the group's rows from a lane that is not)
                 lds[L::vRedT + (r >> 3)] = tp;
-                if (check) lds[L::vYs + r] = yg;
             }
             if (laneV) {
                 const int vi = L::NG + (sio - L::tV5);
@@ -585,52 +611,66 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
                 if (vi == na) {     // the shared variable T: its state is published for the border solve and the tests
                     misc[L::M_xT] = vx; misc[L::M_zbT] = vzb; misc[L::M_ybT] = vyb;
                     misc[L::M_baseT] = (sigma * vx - 1.0) + (rb * vzb - vyb);
-                    if (check) { for (int k = 0; k < N; k++) lds[L::vXx + k * XS + 21] = vx; }
-                } else if (check) lds[L::vXx + xpos] = vx;
+                }
             }
         }
         pxr = q5_l5<NSEG>(c, sio & 63, 0); prf = q5_l5<NSEG>(c, sio & 63, 1); prb = q5_l5<NSEG>(c, sio & 63, 2);
         Q5B(4); Q5_BAR(4); Q5S(4);
-        if (__builtin_expect(check, 0)) {
+      }
+      it += period;
+      if (MPCMP_NO_TEST(cfg, period)) break;
+      {
             int t = tid;
             asm volatile("" : "+v"(t));
-            double sums[2] = {0.0, 0.0};
-            double mx[6] = {0, 0, 0, 0, 0, 0};
-            if (isPath) {       // A x of the owned row and the path-row part of A^T y (read by the variable lanes after the reduction's barriers)
-                const int gro2 = q5_lc<NSEG>(c, t, 4), xno2 = q5_lc<NSEG>(c, t, 5);
-                const double ygc = yg;
-                const double ax = q5_path_rows<NSEG>(lds, gro2, xno2, t, lds + L::vXx, lds + L::vGpy, [&](double, const PathOp5 &) -> double { return ownsRow ? ygc : 0.0; });
-                if (ownsRow) {
-                    sums[0] = lds[lo16(gro2) - (xno2 % XS) + ((gro2 >> 16) & 1) * L::GS + 21] * yg;      // T coefficient of the owned row (column 21)
-                    mx[0] = fabs(ax - zg); mx[1] = fabs(ax); mx[2] = fabs(zg);
-                }
-            }
-            double rcT5 = 0.0;
-            if (laneD) { rcT5 = ldv(lds + L::vRc + L::NRC + L::DR0 + (t - L::tV5)); sums[0] = rcT5 * yg; }
             const int vi = laneV ? L::NG + (t - L::tV5) : 0;
             const bool isVar = laneV && vi < na;
             const double *vcl = lds + L::vVc + vi, *vst = lds + L::vVst + (laneV ? t - L::tV5 : 0);
             const double ha = isVar ? ldv(vcl + 3 * L::NVL) : 0.0, vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32);
-            if (isVar) sums[1] = ha * vx;
-            __syncthreads();                                      // (gpy published)
+            // the relaxed iterate and the duals of this wave's dynamics rows, for every role's test
+            if (laneD) lds[L::vYs + L::DR0 + (t - L::tV5)] = yg;
+            if (laneV) {
+                if (vi == na) { for (int k = 0; k < N; k++) lds[L::vXx + k * XS + 21] = vx; }
+                else lds[L::vXx + lo16(q5_l5<NSEG>(c, t & 63, 0))] = vx;
+            }
+            __syncthreads();
+            // stage one: the primal residual
+            double mp[3] = {0, 0, 0};
+            double rcT5 = 0.0;
+            const int gro2 = isPath ? q5_lc<NSEG>(c, t, 4) : 0, xno2 = isPath ? q5_lc<NSEG>(c, t, 5) : 0;
+            if (isPath) {
+                const double ax = q5_path_ax<NSEG>(lds, gro2, xno2, t, lds + L::vXx);
+                if (ownsRow) { mp[0] = fabs(ax - zg); mp[1] = fabs(ax); mp[2] = fabs(zg); }
+            }
             if (laneD) {
+                rcT5 = ldv(lds + L::vRc + L::NRC + L::DR0 + (t - L::tV5));
                 const double zgd = ldv(lds + L::vRc + L::DR0 + (t - L::tV5));
                 const double ax = row_dot_dyn(lds + L::vXx, q5_l5<NSEG>(c, t & 63, 3), L::oCD + 4 * ((q5_l5<NSEG>(c, t & 63, 2) >> 17) & 3), rcT5);
-                mx[0] = fabs(ax - zgd); mx[1] = fabs(ax); mx[2] = fabs(zgd);
+                mp[0] = fabs(ax - zgd); mp[1] = fabs(ax); mp[2] = fabs(zgd);
             }
-            if (isVar) {
-                const double hx = (fabs(ha) + cfg.hess_reg) * vx + ha * lds[L::vXx + 21];
-                const double aty = q5_col_gather<NSEG>(lds, q5_l5<NSEG>(c, t & 63, 0), q5_l5<NSEG>(c, t & 63, 1), q5_l5<NSEG>(c, t & 63, 2), vcl, lds + L::vYs, lds + L::vGpy) + vyb;
-                mx[0] = fmax(mx[0], fabs(vx - vzb)); mx[1] = fmax(mx[1], fabs(vx)); mx[2] = fmax(mx[2], fabs(vzb));
-                mx[3] = fabs(hx + aty); mx[4] = fabs(hx); mx[5] = fabs(aty);
+            if (isVar) { mp[0] = fmax(mp[0], fabs(vx - vzb)); mp[1] = fmax(mp[1], fabs(vx)); mp[2] = fmax(mp[2], fabs(vzb)); }
+            if (q5_primal_ok<NSEG>(c, mp)) {
+                // stage two: the dual residual
+                double sums[2] = {0.0, 0.0}, md[3] = {0, 0, 0};
+                if (isPath) {       // the path-row part of A^T y (read by the variable lanes after the barrier below)
+                    const double ygc = yg;
+                    q5_path_rows<NSEG>(lds, gro2, xno2, t, lds + L::vXx, lds + L::vGpy, [&](double, const PathOp5 &) -> double { return ownsRow ? ygc : 0.0; });
+                    if (ownsRow) sums[0] = lds[lo16(gro2) - (xno2 % XS) + ((gro2 >> 16) & 1) * L::GS + 21] * yg;      // T coefficient of the owned row (column 21)
+                }
+                if (laneD) sums[0] = rcT5 * yg;
+                if (isVar) sums[1] = ha * vx;
+                __syncthreads();                                      // (gpy published)
+                if (isVar) {
+                    const double hx = (fabs(ha) + cfg.hess_reg) * vx + ha * lds[L::vXx + 21];
+                    const double aty = q5_col_gather<NSEG>(lds, q5_l5<NSEG>(c, t & 63, 0), q5_l5<NSEG>(c, t & 63, 1), q5_l5<NSEG>(c, t & 63, 2), vcl, lds + L::vYs, lds + L::vGpy) + vyb;
+                    md[0] = fabs(hx + aty); md[1] = fabs(hx); md[2] = fabs(aty);
+                }
+                done = q5_dual_ok<NSEG>(c, sums, md);
             }
-            done = q5_check_tail<NSEG>(c, sums, mx);
             Q5S(5);
-        }
-        if (done) break;
+      }
+      if (done) break;
     }
-    const bool capped = it > cfg.qp_iters;
-    if (capped) it = cfg.qp_iters;
+    const bool capped = !done;
     Q5_STAMP_DUMP(it);
     if (tid == 0) { c.ws.qpit[c.b] = it; c.ws.qp_total[c.b] += it; if (capped) atomicAdd(&c.ws.status[c.b], MPCMP_ST_CAP_ONE); }
     if (laneV) {
@@ -711,7 +751,7 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
     }
     q5_finish_border<NSEG>(c);
     Q5_STAMP_RESET;
-    int it = 0, done = 0, until_check = cfg.check_every;
+    int it = 0, done = 0;
     int apx, apf, apb;          // constants of phase A, fetched ahead of the barrier that ends the previous iteration
     {
         int t = tid;
@@ -733,7 +773,10 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
         }
         __syncthreads();
     }
-    for (it = 1; it <= cfg.qp_iters; it++) {
+    while (it < cfg.qp_iters) {
+      const int period = MPCMP_PERIOD(cfg, it);
+#pragma nounroll
+      for (int kk = 0; kk < period; kk++) {
         int sio = tid;
         asm volatile("" : "+v"(sio));
         const int vi = L::vi_of(sio);
@@ -759,8 +802,6 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
         else if (waveX && Q5_XT) q5_p3_xT<NSEG>(c, sio, true);
         Q5B(3); Q5_BAR(3); Q5S(3);
         // ---- E: the variable and the dynamics row of the lane ----
-        const bool check = MPCMP_CHECK_NOW(--until_check == 0);
-        if (check) until_check = cfg.check_every;
         apx = q5_lc<NSEG>(c, sio, 2); apf = q5_lc<NSEG>(c, sio, 3); apb = q5_lc<NSEG>(c, sio, 4);      // (constants of the next phase A: not behind this phase's work)
         if (Q5_ON(6)) {
             const double *vcl = lds + L::vVc + vi, *rcl = lds + L::vRc + (isDyn ? vi : 0);
@@ -770,48 +811,55 @@ __device__ __forceinline__ void qp5_role_es(const Qp5Ctx<NSEG> &c) {
             if (isDyn) {
                 const double lgd = ldv(rcl), rcT = ldv(rcl + L::NRC);
                 const double zt = row_dot_dyn(lds + L::vXn, eix, L::oCD + 4 * ((epb >> 17) & 3), rcT);
-                const double zr = alpha * zt + c.oma * ((it > 1 || warm) ? lgd : 0.0);
+                const double zr = alpha * zt + c.oma * ((it + kk > 0 || warm) ? lgd : 0.0);
                 ygd += rho_eq * (zr - lgd);                 // the row is an equality: the projection of anything onto [l, l] is l
                 const double w = rho_eq * lgd - ygd;
                 lds[L::vWg + vi] = w;
                 const double tp = sum8(rcT * w);
                 lds[L::vRedT + (vi >> 3)] = tp;
-                if (check) lds[L::vYs + vi] = ygd;
             }
             vx = alpha * xtv + c.oma * vx;
             const double zrv = alpha * xtv + c.oma * vzb;
             const double znv = clip(zrv + vyb * rbi, vlb, vub);
             vyb += rb * (zrv - znv);
             vzb = znv;
-            if (check) lds[L::vXx + xpos] = vx;
         }
         Q5B(4); Q5_BAR(4); Q5S(4);
-        if (__builtin_expect(check, 0)) {
+      }
+      it += period;
+      if (MPCMP_NO_TEST(cfg, period)) break;
+      {
             int t = tid;
             asm volatile("" : "+v"(t));
             const int vc_ = L::vi_of(t);
             const double *vcl = lds + L::vVc + vc_, *rcl = lds + L::vRc + (isDyn ? vc_ : 0), *xx = lds + L::vXx;
             const int pxc = q5_lc<NSEG>(c, t, 2), prfc = q5_lc<NSEG>(c, t, 3), prbc = q5_lc<NSEG>(c, t, 4), ixc = q5_lc<NSEG>(c, t, 5);
+            // the relaxed iterate and the dual of the lane's dynamics row, for every role's test
+            if (isDyn) lds[L::vYs + vc_] = ygd;
+            lds[L::vXx + lo16(pxc)] = vx;
+            __syncthreads();
             const double ha = ldv(vcl + 3 * L::NVL);
             const double rcT = isDyn ? ldv(rcl + L::NRC) : 0.0, zgd = isDyn ? ldv(rcl) : 0.0;
-            double sums[2] = {isDyn ? rcT * ygd : 0.0, ha * vx};
-            __syncthreads();                                      // (gpy published)
-            double mx[6] = {0, 0, 0, 0, 0, 0};
+            // stage one: the primal residual
+            double mp[3] = {0, 0, 0};
             if (isDyn) {
                 const double ax = row_dot_dyn(xx, ixc, L::oCD + 4 * ((prbc >> 17) & 3), rcT);
-                mx[0] = fabs(ax - zgd); mx[1] = fabs(ax); mx[2] = fabs(zgd);
+                mp[0] = fabs(ax - zgd); mp[1] = fabs(ax); mp[2] = fabs(zgd);
             }
-            {
+            mp[0] = fmax(mp[0], fabs(vx - vzb)); mp[1] = fmax(mp[1], fabs(vx)); mp[2] = fmax(mp[2], fabs(vzb));
+            if (q5_primal_ok<NSEG>(c, mp)) {
+                // stage two: the dual residual
+                double sums[2] = {isDyn ? rcT * ygd : 0.0, ha * vx}, md[3];
+                __syncthreads();                                      // (gpy published)
                 const double hx = (fabs(ha) + cfg.hess_reg) * vx + ha * xx[21], aty = q5_col_gather<NSEG>(lds, pxc, prfc, prbc, vcl, lds + L::vYs, lds + L::vGpy) + vyb;
-                mx[0] = fmax(mx[0], fabs(vx - vzb)); mx[1] = fmax(mx[1], fabs(vx)); mx[2] = fmax(mx[2], fabs(vzb));
-                mx[3] = fabs(hx + aty); mx[4] = fabs(hx); mx[5] = fabs(aty);
+                md[0] = fabs(hx + aty); md[1] = fabs(hx); md[2] = fabs(aty);
+                done = q5_dual_ok<NSEG>(c, sums, md);
             }
-            done = q5_check_tail<NSEG>(c, sums, mx);
             Q5S(5);
-        }
-        if (done) break;
+      }
+      if (done) break;
     }
-    Q5_STAMP_DUMP(it > cfg.qp_iters ? cfg.qp_iters : it);
+    Q5_STAMP_DUMP(it);
     c.ws.p[(size_t)c.b * (D::na + 1) + vi0] = vx;
     c.ws.y[(size_t)c.b * (D::ma + D::na + 1) + D::ma + vi0] = vyb;
     if (isDyn) c.ws.y[(size_t)c.b * (D::ma + D::na + 1) + vi0] = ygd;

@@ -59,6 +59,14 @@ struct WS {
 #else
 #define MPCMP_CHECK_NOW(c) (c)
 #endif
+// ADMM loops of k_qp2 / k_qp5: periods of check_every iterations in an inner loop WITHOUT test code, the termination test after it.
+// iterations of the next period, and whether a period ends without a test (cut short by qp_iters: tests happen at multiples of check_every)
+#define MPCMP_PERIOD(cfg, it) (((cfg).qp_iters - (it)) < (cfg).check_every ? ((cfg).qp_iters - (it)) : (cfg).check_every)
+#ifdef MPCMP_NOCHECK
+#define MPCMP_NO_TEST(cfg, period) (true || (period) < (cfg).check_every)
+#else
+#define MPCMP_NO_TEST(cfg, period) ((period) < (cfg).check_every)
+#endif
 #define MPCMP_DBG_WORDS 160   /* 16 workgroup stamps + [16 waves][8] per-wave busy cycles of k_qp2 + 16 stamps of k_step */
 #ifdef MPCMP_STAMPS
 #define STAMP(slot) do { if (tid == 0) { const unsigned long long now_ = clock64(); stamp_acc[slot] += now_ - stamp_t; stamp_t = now_; } } while (0)
