@@ -72,19 +72,33 @@ def _tree_sha():
         return None
 
 
+def _newest_profile(suffix):
+    """newest committed profiles/rNN_<suffix> (round number descending), or None"""
+    import glob
+    import re
+    c = [(int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix))]
+    return max(c)[1] if c else None
+
+
 def committed_traffic(kname, problems_per_launch, workload=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes: (bytes, MFMA busy cycles, source record).
-    Round 4's file (profiles/r04_traffic.json, tools/traffic_from_summary.py) is keyed by workload and kernel and names the kernel sources it was
+    The newest round's file (profiles/rNN_traffic.json, tools/traffic_from_summary.py) is keyed by workload and kernel and names the kernel sources it was
     measured on; the figure is withheld (None) when the tree differs.  Older files (one kernel each, no hash) are used for an unchanged kernel only."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+        tf = _newest_profile("traffic.json")
+        tj = json.load(open(tf))
         rec = tj["workloads"].get(workload or "", {})
         e = rec.get("kernels", {}).get(kname)
         if e is not None and rec.get("problems_per_launch") == problems_per_launch and "traffic_bytes_per_launch" in e:
             stale = tj.get("csrc_sha16") != _tree_sha()
-            src = {"file": "profiles/r04_traffic.json", "csrc_sha16": tj.get("csrc_sha16"), "stale": stale,
+            src = {"file": "profiles/" + os.path.basename(tf), "csrc_sha16": tj.get("csrc_sha16"), "stale": stale,
                    "what": "FETCH_SIZE x 2 + WRITE_SIZE of the dominant kernel, per launch (committed profile, not this run)"}
-            return (None if stale else e["traffic_bytes_per_launch"]), e.get("SQ_VALU_MFMA_BUSY_CYCLES"), src
+            busy = e.get("SQ_VALU_MFMA_BUSY_CYCLES")
+            if busy is not None and e.get("avg_us_kernel_trace"):
+                # fraction of the kernel's SIMD time (256 CUs x 4 SIMDs, 2.4 GHz nominal) in which a matrix-core instruction was executing
+                src["mfma_busy_frac_of_simd_time"] = busy / (e["avg_us_kernel_trace"] * 1e-6 * 2.4e9 * 1024)
+                src["mfma_insts_per_launch"] = e.get("SQ_INSTS_MFMA")
+            return (None if stale else e["traffic_bytes_per_launch"]), busy, src
     except Exception:
         pass
     for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -100,15 +114,17 @@ def committed_traffic(kname, problems_per_launch, workload=None):
 
 def committed_mfma(workload):
     """MFMA counters of the factorisation kernel k_qp3f (its Schur complement products run on the matrix cores) from the committed
-    rocprofv3 PMC pass (profiles/r04_traffic.json, else r03_mfma.json); None for the N = 13 path, whose kernel k_qp2 issues no MFMA"""
+    newest committed rocprofv3 PMC pass (profiles/rNN_traffic.json, else r03_mfma.json)"""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+        tf = _newest_profile("traffic.json")
+        tj = json.load(open(tf))
         rec = tj["workloads"].get(workload, {})
-        e = rec.get("kernels", {}).get("k_qp3f")
-        if e is not None and "SQ_INSTS_MFMA" in e:
-            return {"kernel": "k_qp3f", "insts_mfma_per_launch": e["SQ_INSTS_MFMA"], "mfma_busy_cycles_per_launch": e.get("SQ_VALU_MFMA_BUSY_CYCLES"),
-                    "mops_f64_per_launch": e.get("SQ_INSTS_VALU_MFMA_MOPS_F64"), "problems_per_launch": rec.get("problems_per_launch"),
-                    "source": "committed_profile: profiles/r04_traffic.json", "stale": tj.get("csrc_sha16") != _tree_sha()}
+        for kf in ("k_qp3f", "k_qp2"):      # N >= 19: the factorisation kernel; N = 13: k_qp2 factorises itself (Schur products on the matrix cores since round 5)
+            e = rec.get("kernels", {}).get(kf)
+            if e is not None and e.get("SQ_INSTS_MFMA"):
+                return {"kernel": kf, "insts_mfma_per_launch": e["SQ_INSTS_MFMA"], "mfma_busy_cycles_per_launch": e.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                        "mops_f64_per_launch": e.get("SQ_INSTS_VALU_MFMA_MOPS_F64"), "problems_per_launch": rec.get("problems_per_launch"),
+                        "source": "committed_profile: profiles/" + os.path.basename(tf), "stale": tj.get("csrc_sha16") != _tree_sha()}
     except Exception:
         pass
     try:
@@ -151,7 +167,8 @@ def committed_counters(workload):
     the ratio; wave-level counts x 64 lanes, inactive lanes included: an upper bound).  `stale` is True when the kernel sources of the working tree
     (tools/src_hash.py) are not the ones the profile was measured on: the fraction is then withheld.  None if no profile has the workload."""
     now = _tree_sha()
-    for f in ("r04_fp64_counters.json", "r03_fp64_counters.json"):
+    import glob
+    for f in sorted((os.path.basename(g) for g in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_fp64_counters.json"))), reverse=True):
         try:
             cj = json.load(open(os.path.join(ROOT, "profiles", f)))
             e = cj["workloads"].get(workload)
