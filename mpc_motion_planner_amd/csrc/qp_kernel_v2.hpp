@@ -361,7 +361,11 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
         // bound by the LDS reads of b by roles A1 and A2 together, P2 only has role B's reads of r_I) ----
         double tq;              // (G_s b_J)[own row]
         {
+#ifdef MPCMP_FOLDSIM
+            constexpr int JS = 7;                                          // (what-if build: the whole product in P1, phase P2 does not exist)
+#else
             constexpr int JS = 4;                                          // 16-byte operand pairs taken in P1
+#endif
             double a0 = 0.0, a1 = 0.0;
             D2 bv[7];
             if (ABL_ON(6)) {
@@ -389,7 +393,9 @@ __device__ __forceinline__ void qp2_role_a1(const Qp2Ctx<NSEG> &c) {
             } else { tq = a0 + a1; }
         }
         // ---- P2 (role B) ----
+#ifndef MPCMP_FOLDSIM
         BUSY_SYNC(2);
+#endif
         STAMP2(5);
         // ---- P3 ----
         if (ABL_ON(8)) {
@@ -468,7 +474,12 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         const int e = et - TL - G8, side = e / 28, pr = (e % 28) / 4, cc = 2 * pr;
         seg = side == 0 ? 0 : NSEG - 1; ec0 = side == 0 ? cc : 14 + cc; ec1 = ec0 + 1; irow = (side == 0 ? 0 : 14 * NSEG) + cc;
     }
+#ifdef MPCMP_FOLDSIM
+    double m1[2][18];
+    for (int a = 0; a < 2; a++) for (int j = 14; j < 18; j++) m1[a][j] = 1e-3 * (tid + j);
+#else
     double m1[2][14];
+#endif
     {
         const double *Es = lds + L::oKJC + seg * D::JC;
 #pragma unroll
@@ -564,12 +575,17 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         // ---- P1 ----
         if (ABL_ON(5)) {
             double a0 = 0.0, a1 = 0.0;
-            D2 bv[7];
+#ifdef MPCMP_FOLDSIM
+            constexpr int NJ = 9;                                          // (what-if build: a 2 x 18 block of W = S^-1 [-E^T | I]; numbers are garbage)
+#else
+            constexpr int NJ = 7;
+#endif
+            D2 bv[NJ];
 #pragma unroll
-            for (int j = 0; j < 7; j++) bv[j] = lds2(bj + 2 * j);          // all operand reads in flight first
+            for (int j = 0; j < NJ; j++) bv[j] = lds2(bj + 2 * j);          // all operand reads in flight first
             const double bI0 = rhsI[rsrc], bI1 = lds[xoff];                // (every lane reads: keeps the loads off the tail)
 #pragma unroll
-            for (int j = 0; j < 7; j++) {
+            for (int j = 0; j < NJ; j++) {
                 a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
                 a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
             }
@@ -580,7 +596,9 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
         }
         BUSY_SYNC(1);
         // ---- P2 (role B) ----
+#ifndef MPCMP_FOLDSIM
         BUSY_SYNC(2);
+#endif
         // ---- P3 (role A1): this role is idle, so the constant operands of the E phase (Jacobian rows, row bounds) are
         // fetched now and only x~ remains to be read once P3 has produced it ----
         D2 p0[3], p1[3];
@@ -725,7 +743,14 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
     const bool isVar = u < n, isT = u == n - 1;
     const double sum_ha = lds[L::oMisc + 3];
     // register block: rows 2rp2, 2rp2+1 of S^-1 x columns part2*10..+9
-    double s2[10], s2b[10];
+#ifdef MPCMP_FOLDSIM
+    constexpr int NS2 = 18;
+    double s2[NS2], s2b[NS2];
+    for (int j = 10; j < NS2; j++) { s2[j] = 1e-3 * (tid + j); s2b[j] = 1e-3 * (tid - j); }
+#else
+    constexpr int NS2 = 10;
+    double s2[NS2], s2b[NS2];
+#endif
     {
         const double *S = lds + L::oS;
 #pragma unroll
@@ -824,16 +849,18 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         }
         BUSY_SYNC(0);
         // ---- P1: (group A) ----
+#ifndef MPCMP_FOLDSIM
         BUSY_SYNC(1);
+#endif
         // ---- P2: x_I = S^-1 r_I  (2 rows x 10 columns per lane, 8-lane reduction; r_I was completed by role A2) ----
         if (isP2 && ABL_ON(7)) {
             double a0 = 0.0, a1 = 0.0;
             const double *rv = rI + part2 * 10;
-            D2 r[5];
+            D2 r[NS2 / 2];
 #pragma unroll
-            for (int j = 0; j < 5; j++) r[j] = lds2(rv + 2 * j);
+            for (int j = 0; j < NS2 / 2; j++) r[j] = lds2(rv + 2 * j);
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
+            for (int j = 0; j < NS2 / 2; j++) {
                 a0 += s2[2 * j] * r[j].x; a1 += s2b[2 * j] * r[j].x;
                 a0 += s2[2 * j + 1] * r[j].y; a1 += s2b[2 * j + 1] * r[j].y;
             }
