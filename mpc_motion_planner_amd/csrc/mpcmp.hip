@@ -1173,6 +1173,29 @@ extern "C" int mpcmp_warm_start_jerk_batch_device(mpcmp_ctx *ctx, int B, const d
     return mpcmp_warm_start_jerk_acc_batch_device(ctx, B, d_x0, d_xf, nullptr, nullptr, jmax, d_wx, d_wu, d_wT, hip_stream);
 }
 
+// Boundary states the generator cannot honour: the acceleration limit yields to a boundary acceleration above it (include/mpcmp.h), but an
+// acceleration that cannot be brought to zero inside the VELOCITY limit — |v0 + a0 |a0| / 2J| > V at the start, |vT - aT |aT| / 2J| > V at the target —
+// would overshoot the state box of the OCP: MPCMP_EINVAL, as Ruckig rejects such an input (ErrorInvalidInput; the shim's otg.calculate returns it).
+// Host-pointer entry points only: the *_device variants never read their inputs on the host.
+static int check_boundary_acc(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
+                              const double *vmax, const double *jmax) {
+    if ((!acc0 && !accT) || ctx->narm != 1) return MPCMP_OK;
+    for (int b = 0; b < B; b++)
+        for (int j = 0; j < 7; j++) {
+            const double V = (vmax ? vmax[j] : ctx->cfg.ubx[7 + j]) * (1.0 + 1e-9), J = jmax[j];
+            if (!(J > 0.0)) continue;      // (reported by jerk_limits)
+            const double a0 = acc0 ? acc0[7 * b + j] : 0.0, aT = accT ? accT[7 * b + j] : 0.0;
+            const double va = x0[14 * b + 7 + j] + a0 * std::fabs(a0) / (2.0 * J), vb = xf[14 * b + 7 + j] - aT * std::fabs(aT) / (2.0 * J);
+            if (std::fabs(va) > V || std::fabs(vb) > V) {
+                std::ostringstream os;
+                os << "problem " << b << ", joint " << j << ": the boundary acceleration cannot be brought to zero inside the velocity limit";
+                ctx->err = os.str();
+                return MPCMP_EINVAL;
+            }
+        }
+    return MPCMP_OK;
+}
+
 // host [B][7] boundary accelerations (either may be NULL) staged next to the states; returns the device pointers (or NULL)
 static int stage_acc(mpcmp_ctx *ctx, TmpBuf &tb, int B, const double *acc0, const double *accT, hipStream_t st, const double **d0, const double **dT) {
     *d0 = *dT = nullptr;
@@ -1196,6 +1219,7 @@ extern "C" int mpcmp_warm_start_jerk_lim_batch(mpcmp_ctx *ctx, int B, const doub
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * nx * B, hipMemcpyHostToDevice, st));
     TmpBuf tb(ctx, (acc0 || accT) ? 14 * (size_t)B * sizeof(double) : 0);
     const double *da0, *daT;
+    if (int rc = check_boundary_acc(ctx, B, x0, xf, acc0, accT, vmax, jmax)) return rc;
     if (int rc = stage_acc(ctx, tb, B, acc0, accT, st, &da0, &daT)) return rc;
     if (int rc = warm_start_jerk_device(ctx, B, ctx->d_x0, ctx->d_xf, da0, daT, vmax, amax, jmax, ctx->d_wx, ctx->d_wu, ctx->d_wT, st)) return rc;
     HIPCHK(ctx, hipMemcpyAsync(wx, ctx->d_wx, sizeof(double) * nx * N * B, hipMemcpyDeviceToHost, st));
@@ -1230,6 +1254,7 @@ extern "C" int mpcmp_jerk_trajectory_lim_batch(mpcmp_ctx *ctx, int B, const doub
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_x0, x0, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
     const double *da0, *daT;
+    if (int rc = check_boundary_acc(ctx, B, x0, xf, acc0, accT, vmax, jmax)) return rc;
     if (int rc = stage_acc(ctx, tb, B, acc0, accT, st, &da0, &daT)) return rc;
     hipLaunchKernelGGL(k_jerk_traj, dim3(B), dim3(64), 0, st, lim, ctx->d_x0, ctx->d_xf, da0, daT, n_pts, dout, ctx->d_wT);
     HIPCHK(ctx, hipGetLastError());
@@ -1265,6 +1290,7 @@ extern "C" int mpcmp_jerk_point_lim_batch(mpcmp_ctx *ctx, int B, const double *x
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_xf, xf, sizeof(double) * 14 * B, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(dt, time, sizeof(double) * B, hipMemcpyHostToDevice, st));
     const double *da0, *daT;
+    if (int rc = check_boundary_acc(ctx, B, x0, xf, acc0, accT, vmax, jmax)) return rc;
     if (int rc = stage_acc(ctx, tb, B, acc0, accT, st, &da0, &daT)) return rc;
     hipLaunchKernelGGL(k_jerk_point, dim3(B), dim3(64), 0, st, ctx->d_model, lim, ctx->d_x0, ctx->d_xf, da0, daT, dt, dout, ctx->d_wT);
     HIPCHK(ctx, hipGetLastError());

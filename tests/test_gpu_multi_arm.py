@@ -158,7 +158,7 @@ def test_set_config_rejects_iteration_caps_beyond_the_exchange_slots(M):
 
 def test_dual_arm_two_stream_soak_no_dead_exchange(M):
     """The two arm workgroups of a dual-arm OCP exchange through device memory and rely on being co-resident (qp_kernel_v3.hpp: bounded
-    spins, XCH_DEAD on time-out).  Short soak in the two-stream mode (B x 2 arms >= 512 workgroups, a competing stream): 3 back-to-back
+    spins, XCH_DEAD on time-out).  Soak in the two-stream mode (B x 2 arms >= 512 workgroups, a competing stream): 20 back-to-back
     solves of 512 dual-arm OCPs at N = 19, no problem may report a dead exchange or any other hard failure, and the repeats are bitwise
     equal (profiles/r03_soak_runs.txt is the long version of this)."""
     cfg = M.default_config(6, 2, margins=MARGINS)
@@ -168,7 +168,7 @@ def test_dual_arm_two_stream_soak_no_dead_exchange(M):
     jmax = MARGINS[4] * M.default_limits()["jmax"]
     warm = s.warm_start_jerk(x0, xf, jmax)
     ref = None
-    for rep in range(3):
+    for rep in range(20):
         sx, su, sT, info = s.solve(x0, xf, warm)
         assert not np.any(info["status"] & M.STATUS_XCH_DEAD), "dead arm exchange"
         assert np.all((info["status"] & M.STATUS_HARD) == 0) and np.all(np.isfinite(sT))

@@ -666,6 +666,15 @@ def test_jerk_limited_warm_start_vs_oracle_and_stored_ruckig(M, golden_dir):
     assert np.array_equal(wxe, wx) and np.array_equal(wue, wu) and np.array_equal(wTe, wT)
     with pytest.raises(Exception):
         s.warm_start_jerk(x0, xf, jmax, vmax=0.0 * vmax)
+    # a boundary acceleration that cannot be brought to zero inside the velocity limit (v0 + a0 |a0| / 2J > vmax) is rejected (MPCMP_EINVAL,
+    # as Ruckig's ErrorInvalidInput), by all three host entry points; the same acceleration at a slower start is accepted
+    xv = x0s[:1].copy(); xv[0, 7:] = 0.999 * vmax; av = amax[None].copy()
+    for call in (lambda: s.warm_start_jerk(xv, xfs[:1], jmax, acc0=av), lambda: s.jerk_trajectory(xv, xfs[:1], jmax, 10, acc0=av),
+                 lambda: s.jerk_point(xv, xfs[:1], jmax, np.array([0.1]), acc0=av), lambda: s.warm_start_jerk(xfs[:1], xv, jmax, accT=-av)):
+        with pytest.raises(M.MpcmpError):
+            call()
+    xv[0, 7:] = 0.9 * vmax
+    s.warm_start_jerk(xv, xfs[:1], jmax, acc0=av)
     # KAT-RK through the GPU path (6 stored digits)
     g = json.load(open(os.path.join(golden_dir, "gold_traj.json")))
     k0 = np.concatenate([g["q0"], g["v0"]])[None]; kf = np.concatenate([g["qT"], g["vT"]])[None]
