@@ -197,8 +197,8 @@ int mpcmp_jerk_point_batch(mpcmp_ctx *ctx, int B, const double *x0, const double
                            double *out, double *T_out);
 /* The three entry points above with boundary accelerations acc0 / accT [B][7] (either may be NULL = zero; with both NULL the result is
  * the plain entry point's bit for bit).  Single-arm contexts.  The acceleration limit yields to a given boundary acceleration above it.  A boundary
- * acceleration that cannot be brought to zero inside the velocity limit (|v0 + a0 |a0| / 2J| > vmax at the start, |vT - aT |aT| / 2J| > vmax at the target)
- * is rejected with MPCMP_EINVAL by the host-pointer entry points, as Ruckig rejects such an input; the *_device variant does not read its inputs on the
+ * acceleration that drives a velocity from inside its limit to outside it however hard the jerk brakes (|v0| <= vmax < |v0 + a0 |a0| / 2J| at the start,
+ * |vT| <= vmax < |vT - aT |aT| / 2J| at the target) is rejected with MPCMP_EINVAL by the host-pointer entry points, as Ruckig rejects such an input; the *_device variant does not read its inputs on the
  * host and does not check. */
 int mpcmp_warm_start_jerk_acc_batch(mpcmp_ctx *ctx, int B, const double *x0, const double *xf, const double *acc0, const double *accT,
                                     const double *jmax, double *warm_x, double *warm_u, double *warm_T);

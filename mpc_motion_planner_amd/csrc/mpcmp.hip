@@ -1185,8 +1185,10 @@ static int check_boundary_acc(mpcmp_ctx *ctx, int B, const double *x0, const dou
             const double V = (vmax ? vmax[j] : ctx->cfg.ubx[7 + j]) * (1.0 + 1e-9), J = jmax[j];
             if (!(J > 0.0)) continue;      // (reported by jerk_limits)
             const double a0 = acc0 ? acc0[7 * b + j] : 0.0, aT = accT ? accT[7 * b + j] : 0.0;
-            const double va = x0[14 * b + 7 + j] + a0 * std::fabs(a0) / (2.0 * J), vb = xf[14 * b + 7 + j] - aT * std::fabs(aT) / (2.0 * J);
-            if (std::fabs(va) > V || std::fabs(vb) > V) {
+            const double v0 = x0[14 * b + 7 + j], vT = xf[14 * b + 7 + j];
+            const double va = v0 + a0 * std::fabs(a0) / (2.0 * J), vb = vT - aT * std::fabs(aT) / (2.0 * J);
+            // (a boundary VELOCITY outside the limit is the caller's business, as before: that joint falls back to the quintic of the common duration)
+            if ((std::fabs(v0) <= V && std::fabs(va) > V) || (std::fabs(vT) <= V && std::fabs(vb) > V)) {
                 std::ostringstream os;
                 os << "problem " << b << ", joint " << j << ": the boundary acceleration cannot be brought to zero inside the velocity limit";
                 ctx->err = os.str();
