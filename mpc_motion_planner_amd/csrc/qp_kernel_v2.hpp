@@ -580,6 +580,22 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
 #else
             constexpr int NJ = 7;
 #endif
+#ifdef MPCMP_FOLDSIM
+            const double bI0 = rhsI[rsrc], bI1 = lds[xoff];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j0 = h ? 5 : 0, j1 = h ? NJ : 5;
+                D2 bv[5];
+#pragma unroll
+                for (int j = j0; j < j1; j++) bv[j - j0] = lds2(bj + 2 * j);
+#pragma unroll
+                for (int j = j0; j < j1; j++) {
+                    a0 += m1[0][2 * j] * bv[j - j0].x; a1 += m1[1][2 * j] * bv[j - j0].x;
+                    a0 += m1[0][2 * j + 1] * bv[j - j0].y; a1 += m1[1][2 * j + 1] * bv[j - j0].y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
             D2 bv[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; j++) bv[j] = lds2(bj + 2 * j);          // all operand reads in flight first
@@ -589,6 +605,7 @@ __device__ __forceinline__ void qp2_role_a2(const Qp2Ctx<NSEG> &c) {
                 a0 += m1[0][2 * j] * bv[j].x; a1 += m1[1][2 * j] * bv[j].x;
                 a0 += m1[0][2 * j + 1] * bv[j].y; a1 += m1[1][2 * j + 1] * bv[j].y;
             }
+#endif
             double sq = quad_sum2(a0, a1);                  // even lanes: row ec0, odd lanes: row ec1
             sq += f8 * dpp_xor4(sq);                        // 8-lane groups: the other segment's quad
             sq += f16 * dpp_mov<0x128>(sq);                 // the T group of 16: row_ror:8 = lane ^ 8
@@ -774,6 +791,9 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         cv[0] = vr.cf;
 #pragma unroll
         for (int i = 0; i < 3; i++) { cv[1 + i] = vr.dA[i]; cv[4 + i] = vr.dB[i]; }
+#ifdef MPCMP_FOLDSIM
+        for (int i = 0; i < 7; i++) vcl[i * L::NB] = cv[i];       // (what-if build: the dynamics-column coefficients live in LDS too)
+#endif
         vcl[7 * L::NB] = vr.hd; vcl[8 * L::NB] = vr.ha; vcl[9 * L::NB] = vr.qv;
         vcl[10 * L::NB] = vr.lb; vcl[11 * L::NB] = vr.ub; vcl[12 * L::NB] = 1.0 / vr.rb;
         v_rb = vr.rb;
@@ -803,8 +823,16 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         wv[0] = w[v_rf];
 #pragma unroll
         for (int i = 0; i < 3; i++) { wv[1 + i] = w[v_rA + 14 * i]; wv[4 + i] = w[v_rB + 14 * i]; }
+#ifdef MPCMP_FOLDSIM
+        double cq[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) cq[i] = vcl[i * L::NB];
+#pragma unroll
+        for (int i = 0; i < 7; i++) s += cq[i] * wv[i];
+#else
 #pragma unroll
         for (int i = 0; i < 7; i++) s += cv[i] * wv[i];
+#endif
         return s;
     };
     // dynamics row owned by this lane (u < meq): ADMM state in registers, coefficients in the V area of LDS
@@ -856,6 +884,21 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
         if (isP2 && ABL_ON(7)) {
             double a0 = 0.0, a1 = 0.0;
             const double *rv = rI + part2 * 10;
+#ifdef MPCMP_FOLDSIM
+#pragma unroll
+            for (int h = 0; h < 2; h++) {                  // (two operand batches: 5 + 4 pairs)
+                const int j0 = h ? 5 : 0, j1 = h ? NS2 / 2 : 5;
+                D2 r[5];
+#pragma unroll
+                for (int j = j0; j < j1; j++) r[j - j0] = lds2(rv + 2 * j);
+#pragma unroll
+                for (int j = j0; j < j1; j++) {
+                    a0 += s2[2 * j] * r[j - j0].x; a1 += s2b[2 * j] * r[j - j0].x;
+                    a0 += s2[2 * j + 1] * r[j - j0].y; a1 += s2b[2 * j + 1] * r[j - j0].y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
             D2 r[NS2 / 2];
 #pragma unroll
             for (int j = 0; j < NS2 / 2; j++) r[j] = lds2(rv + 2 * j);
@@ -864,6 +907,7 @@ __device__ __forceinline__ void qp2_role_b(const Qp2Ctx<NSEG> &c) {
                 a0 += s2[2 * j] * r[j].x; a1 += s2b[2 * j] * r[j].x;
                 a0 += s2[2 * j + 1] * r[j].y; a1 += s2b[2 * j + 1] * r[j].y;
             }
+#endif
             double xi = quad_sum2(a0, a1);                 // even lanes: row 2 rp2, odd lanes: row 2 rp2 + 1
             xi += dpp_xor4(xi);
             *xiw = xi;                                     // (lanes without an output row, and the T row: the write-only pad slot)
