@@ -95,7 +95,7 @@ struct mpcmp_ctx {
     bool rh_step = false;                        // the solve being enqueued is a step of the receding-horizon driver (defaults of its flags, retired instances)
     // diagnostics read from the environment ONCE PER CONTEXT, in mpcmp_create (never process-global state)
     bool force_v1 = false, single_stream = false, debug_occ = false;
-    int parts_env = 2;
+    int parts_env = 0;                           // MPCMP_STREAMS: parts of a large batch (0 = automatic, see solve_impl)
 };
 
 // the configuration the kernels of a solve see: the two start flags resolved to 0 / 1.  0 = the library default (off for mpcmp_solve_batch, ON for
@@ -861,7 +861,10 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     // half's next launch.  Replay of the bench workload's iteration counts: -5.8 % makespan.  Results are unaffected (problems
     // are independent); small batches stay on one stream.
     const bool dual = !ctx->single_stream && !only_qp && B >= 512;      // (also under stream capture: the fork/join events carry the other streams into the graph)
-    const int nhalf = dual ? (ctx->parts_env < 1 ? 1 : (ctx->parts_env > 4 ? 4 : ctx->parts_env)) : 1;
+    // parts: two; three for the N = 13 kernel from 1024 problems on (round 5, three repeats each: 15.74 - 15.77 k against 15.58 - 15.61 k traj/s on the
+    // headline batch; 512 problems — the receding-horizon step — and N = 19 are faster with two: 135.7 k vs 130.0 k re-solves/s, 67.1 k vs 65.2 k traj/s)
+    const int parts_auto = (NSEG == 4 && V2 && B >= 1024) ? 3 : 2;
+    const int nhalf = dual ? (ctx->parts_env < 1 ? parts_auto : (ctx->parts_env > 4 ? 4 : ctx->parts_env)) : 1;
     int Bh[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
     for (int h = 0, acc = 0; h < nhalf; h++) { Bh[h] = (B - acc + (nhalf - h) - 1) / (nhalf - h); boff[h] = acc; acc += Bh[h]; }
     hipStream_t sh[4] = {st, ctx->stream_x[0], ctx->stream_x[1], ctx->stream_x[2]};

@@ -564,17 +564,17 @@ def test_headline_configuration_full_size(M):
 
 @pytest.mark.parametrize("nseg,sqp", [(4, 3), (6, 2)])
 def test_ragged_batch_sizes_around_the_two_stream_split(M, nseg, sqp):
-    """a batch of 512 problems or more is solved as parts on several streams (mpcmp.hip: solve_impl): sizes that do not split evenly (513, 1023), the
-    threshold itself and one below it (512, 511), a single problem, and a context used below its capacity — every problem's result is the one it has
+    """a batch of 512 problems or more is solved as parts on several streams (mpcmp.hip: solve_impl): sizes that do not split evenly (513, 1023, 1025), the
+    thresholds themselves and one below (511, 512; 1023, 1024: the N = 13 path takes three parts from 1024 on), a single problem, and a context used below its capacity — every problem's result is the one it has
     in the full batch, bit for bit, whatever the split it travels in (N = 13: k_qp2, N = 19: k_qp3f + k_qp5)"""
     cfg, _ = _cfgs(M, nseg, sqp)
     from mpc_motion_planner_amd import scenarios
-    Bmax = 1023
+    Bmax = 1025                                                    # (N = 13: three parts from 1024 problems on, two below)
     x0, xf = scenarios.make_batch(Bmax, stream_offset=5000)
-    s = M.Solver(cfg, 1024)
+    s = M.Solver(cfg, 1025)
     sx, su, sT, info = s.solve(x0, xf)
     assert np.all((info["status"] & 7) == 0) and np.all(np.isfinite(sx))
-    for B in (1, 511, 512, 513):
+    for B in (1, 511, 512, 513, 1023, 1024):
         sxb, sub, sTb, ib = s.solve(x0[:B], xf[:B])
         assert np.array_equal(sTb, sT[:B]) and np.array_equal(sxb, sx[:B]) and np.array_equal(sub, su[:B]), B
         assert np.array_equal(ib["qp_iters_total"], info["qp_iters_total"][:B]) and np.array_equal(ib["status"], info["status"][:B])
