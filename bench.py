@@ -89,7 +89,7 @@ def committed_traffic(kname, problems_per_launch, workload=None):
         tj = json.load(open(tf))
         rec = tj["workloads"].get(workload or "", {})
         e = rec.get("kernels", {}).get(kname)
-        if e is not None and rec.get("problems_per_launch") == problems_per_launch and "traffic_bytes_per_launch" in e:
+        if e is not None and abs((rec.get("problems_per_launch") or -1e9) - problems_per_launch) < 1.0 and "traffic_bytes_per_launch" in e:
             stale = tj.get("csrc_sha16") != _tree_sha()
             src = {"file": "profiles/" + os.path.basename(tf), "csrc_sha16": tj.get("csrc_sha16"), "stale": stale,
                    "what": "FETCH_SIZE x 2 + WRITE_SIZE of the dominant kernel, per launch (committed profile, not this run)"}

@@ -322,7 +322,10 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
     else { const int bi = blockIdx.x; slot = (bi >> 4) * 8 + (bi & 7); arm = (bi >> 3) & 1; } \
     if (slot >= B) return; \
     const int b = ws.perm[slot]; \
-    if (MPCMP_RETIRED(ws, b)) return;      /* receding horizon: an arrived instance is not re-solved (both arm workgroups leave) */ \
+    /* receding horizon: an arrived instance is not re-solved (both arm workgroups leave).  Not at N = 25: k_qp3<8, 2> sits at 256 VGPRs and this early exit \
+       costs it 20 B more scratch and 8 % of its speed (144 -> 164 B, 64.6 -> 70.0 ms per launch: profiles/r05_v2_dual14_*); there a retired instance keeps its \
+       QP workgroups busy on its last linearisation (harmless: k_init_m, k_step_m and k_advance skip it, nothing it writes is read) */ \
+    if (NSEG < 8 && MPCMP_RETIRED(ws, b)) return; \
     const double ts = 1.0 / (2.0 * NSEG); \
     const double rho_in = cfg.rho, rho_eq = cfg.rho * cfg.rho_eq_scale, sigma = cfg.sigma, alpha = cfg.alpha; \
     const double *zg_ = ws.z + (size_t)b * n_tot + arm * na; \

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 QP = ("k_qp2", "k_qp3", "k_qp3f", "k_qp5", "k_qp")
-PROBLEMS = {"batch": 512, "shipped": 512, "dual14": 2048, "rh": 512}      # problems per launch of the bench workloads (two concurrent half batches)
+PROBLEMS = {"batch": 1024 / 3.0, "shipped": 512, "dual14": 2048, "rh": 256}      # problems per launch of the bench workloads (parts of a batch on concurrent streams: three at N = 13 from 1024 problems on, else two)
 
 
 def parse(path):
