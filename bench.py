@@ -642,7 +642,8 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
                          "canonical_frac": achieved / FP64_PEAK_TFLOPS,
                          "peak_measured": peak_meas, "frac_of_measured_peak": (achieved / peak_meas) if peak_meas else None,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "mfma_busy": 0.0 if mfma_busy is None else mfma_busy,
+                         "mfma_busy": (traffic_src or {}).get("mfma_busy_frac_of_simd_time", 0.0) if mfma_busy else 0.0,
+                         "mfma_busy_cycles_per_launch": mfma_busy,
                          "mfma_factor_kernel": committed_mfma(workload),
                          "avg_launch_ms": 1e3 * k_avg_s, "launches": k_launches, "launches_in_flight": parts, "problems_per_launch": problems_per_launch,
                          "canonical_gflop_per_launch": flops_launch / 1e9,
@@ -652,7 +653,7 @@ def run_batch_workload(args, workload, steps, warmup, rank, world, local, dist, 
                                  "peak_gbs": HBM_PEAK_GBS, "frac": alg_bytes_launch / k_avg_s / 1e9 / HBM_PEAK_GBS if k_avg_s > 0 else None},
                          "note": "frac = executed flops (counters) / peak; achieved / canonical_frac = canonical dense-equivalent FP64 flops (SURVEY.md 8d) of the "
                                  "QP kernel per GPU over the wall clock of the timed region (an algorithm-speed figure, not a utilisation); "
-                                 "`launches_in_flight` launches overlap, so avg_launch_ms is not exclusive GPU time; mfma_busy is that of the dominant kernel (the ADMM loop has one right-hand side per problem and issues no MFMA); "
+                                 "`launches_in_flight` launches overlap, so avg_launch_ms is not exclusive GPU time; mfma_busy = fraction of the dominant kernel's SIMD time with a matrix-core instruction executing (committed PMC pass): the ADMM loop has one right-hand side per problem and issues no MFMA, the Schur-complement GEMMs of the factorisation run on the matrix cores (N = 13: inside k_qp2 since round 5); "
                                  "for N >= 19 the factorisation kernel k_qp3f runs the QP's block GEMMs (Schur complement products) on the matrix cores: mfma_factor_kernel"},
             "quality": {**status_fractions(inf["status"]), "feasible_frac": float(feasible.mean()),
                         "feasible_traj_per_s": value * float(feasible.mean()),
