@@ -219,10 +219,14 @@ __device__ inline double jk_plan(const JerkLimits &lim, const double *x0, const 
 }
 
 // warm start of the OCP: node states [N][14], node controls [N][7], duration (motionPlanner.cpp:151-174, 202-203)
-__global__ __launch_bounds__(64) void k_warm_jerk(int nseg, JerkLimits lim, const double *x0, const double *xf, const double *acc0, const double *accT, double *wx, double *wu, double *wT) {
+// (need_status / need_mask / need_div: the receding-horizon driver computes the guess only for the instances that will use it — those whose previous solve is
+//  no guess: status[b / need_div] & need_mask — every step but the first; null = every problem)
+__global__ __launch_bounds__(64) void k_warm_jerk(int nseg, JerkLimits lim, const double *x0, const double *xf, const double *acc0, const double *accT, double *wx, double *wu, double *wT,
+                                                  const int *need_status = nullptr, int need_mask = 0, int need_div = 1) {
     __shared__ JProf pr[7];
     __shared__ double sT;
     const int b = blockIdx.x, tid = threadIdx.x, N = 3 * nseg + 1;
+    if (need_status && !(need_status[b / need_div] & need_mask)) return;
     const double *a0 = x0 + 14 * (size_t)b, *af = xf + 14 * (size_t)b;
     const double T = jk_plan(lim, a0, af, acc0 ? acc0 + 7 * (size_t)b : nullptr, accT ? accT + 7 * (size_t)b : nullptr, pr, &sT);
     for (int t = tid; t < N * 7; t += 64) {
