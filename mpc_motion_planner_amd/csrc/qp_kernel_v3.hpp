@@ -1206,6 +1206,19 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // (5) | the same for the previous segment (5) | has a -ts T term (1); one per row: first operand slot (16) | i = k % 3 (2).
     constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
     static_assert(NV <= 2 && NR <= 2, "two variables and two rows per lane at most");
+    // WHICH lanes own a second item (N = 25: 13 variables, 24 rows): lanes SEC0V .. / SEC0R .. of the last waves since round 5 (second item of lane t:
+    // index 512 + t - SEC0x).  Their first-pass rows are dynamics rows (7 LDS reads); until round 4 the surplus sat on lanes 0 .. of wave 0, whose first pass
+    // is a path row (44 reads), so that wave's two passes in phase E set the phase for all eight: -6.7 % per QP with the surplus on waves 6 and 7
+    // (tools/dual_fixed.py: 4.47 -> 4.09 ms per 700 iterations).
+#ifndef MPCMP_Q3_SEC0V
+#define MPCMP_Q3_SEC0V 384
+#endif
+#ifndef MPCMP_Q3_SEC0R
+#define MPCMP_Q3_SEC0R 448
+#endif
+    constexpr int SEC0V = NV == 2 ? MPCMP_Q3_SEC0V : 0, SEC0R = NR == 2 ? MPCMP_Q3_SEC0R : 0;
+    auto iv2 = [&](int t, int h) -> int { return h == 0 ? t : (t >= SEC0V ? 512 + (t - SEC0V) : (1 << 20)); };      // variable index of lane t's h-th variable
+    auto ir2 = [&](int t, int h) -> int { return h == 0 ? t : (t >= SEC0R ? 512 + (t - SEC0R) : (1 << 20)); };      // row slot of lane t's h-th row
     // Rows in lane order: the 8 N path rows first (44 LDS reads each), then the dynamics rows (7 reads): the few lanes that own a
     // second row (N = 25: 24 of them) get a cheap one.  The state of a lane's second variable / row lives in LDS (the 10 registers
     // it would take in EVERY lane are needed elsewhere).
@@ -1213,11 +1226,11 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     double xv0 = 0, zb0 = 0, yb0 = 0, zg0 = 0, yg0 = 0;             // (z_b .. y_g: registers unless L::STL)
     double *stz = lds + L::oSt, *sty = stz + 512, *stg = stz + 1024, *sth = stz + 1536;
     double *s1x = lds + L::oS1, *s1z = s1x + 32, *s1y = s1x + 64, *s1zg = s1x + 96, *s1yg = s1x + 128;
-    static_assert(na - 512 <= 32 && ma - 512 <= 32, "second-pass state");
+    static_assert(na - 512 <= 32 && ma - 512 <= 32 && SEC0V + 32 <= 512 && SEC0R + 32 <= 512, "second-pass state");
     unsigned dv[NV], dr[NR];
 #pragma unroll
     for (int h = 0; h < NV; h++) {
-        const int v = tid + 512 * h;
+        const int v = iv2(tid, h);
         unsigned d = 0;
         if (v < na) {
             const bool isx = v < 14 * N;
@@ -1230,12 +1243,12 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     }
 #pragma unroll
     for (int h = 0; h < NR; h++) {
-        const int r = tid + 512 * h < ma ? row_of(tid + 512 * h) : ma;
+        const int r = ir2(tid, h) < ma ? row_of(ir2(tid, h)) : ma;
         unsigned d = 0;
         if (r < meq) { const int k = r / 14, rr = r % 14; d = (unsigned)(NS * 3 * (k / 3) + rr) | ((unsigned)(k % 3) << 16); }
         else if (r < ma) d = (unsigned)(NS * ((r - meq) >> 3));
         // bit 20: rho of the lane's variable is rho_eq (x_0, or any box narrower than 1e-4); bit 21: rho of the lane's row is rho_eq
-        const int v = tid + 512 * h;
+        const int v = iv2(tid, h);
         if (v < na) { double ha, rb, lo, hi; var_h(v, ha, rb, lo, hi); if (rb == rho_eq) d |= 1u << 20; }
         if (r < ma && (r < meq || lds[L::oUg + r] - lds[L::oLg + r] < 1e-4)) d |= 1u << 21;
         dr[h] = d;
@@ -1314,21 +1327,21 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
         double tp = 0.0;
 #pragma unroll
         for (int h = 0; h < NR; h++) {
-            if (tid + 512 * h < ma) {
-                const int r = row_of(tid + 512 * h);
+            if (ir2(tid, h) < ma) {
+                const int r = row_of(ir2(tid, h));
                 const double rr = (dr[h] >> 21) & 1u ? rho_eq : rho_in, yg = lam_rows[r], zg = clip(0.0, lds[L::oLg + r], lds[L::oUg + r]);
                 const double w = rr * zg - yg;
                 wg[w_slot(dr[h], r)] = w;
                 tp += lds[L::oCf + r] * w;
-                if (h) { s1zg[tid] = zg; s1yg[tid] = yg; } else if (L::STL) { stg[tid] = zg; sth[tid] = yg; } else { zg0 = zg; yg0 = yg; }
+                if (h) { s1zg[tid - SEC0R] = zg; s1yg[tid - SEC0R] = yg; } else if (L::STL) { stg[tid] = zg; sth[tid] = yg; } else { zg0 = zg; yg0 = yg; }
             }
         }
 #pragma unroll
         for (int h = 0; h < NV; h++) {
-            const int v = tid + 512 * h;
+            const int v = iv2(tid, h);
             if (v < na) {
                 const double yb = lam_vars[v], zb = clip(0.0, lds[L::oLb + v], lds[L::oUb + v]);
-                if (h) { s1z[tid] = zb; s1y[tid] = yb; } else if (L::STL) { stz[tid] = zb; sty[tid] = yb; } else { zb0 = zb; yb0 = yb; }
+                if (h) { s1z[tid - SEC0V] = zb; s1y[tid - SEC0V] = yb; } else if (L::STL) { stz[tid] = zb; sty[tid] = yb; } else { zb0 = zb; yb0 = yb; }
             }
         }
         if (L::P8) { tp = sum8(tp); redT[8 * wave + (lane >> 3)] = tp; }
@@ -1362,9 +1375,9 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 double bp = 0.0;
 #pragma unroll
                 for (int h = 0; h < NV; h++) {
-                    const int v = sio + 512 * h;
+                    const int v = iv2(sio, h);
                     if (v < na) {
-                        const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : (L::STL ? ldv(stz + sio) : zb0), yy = h ? s1y[sio] : (L::STL ? ldv(sty + sio) : yb0);
+                        const double xx = h ? s1x[sio - SEC0V] : xv0, zz = h ? s1z[sio - SEC0V] : (L::STL ? ldv(stz + sio) : zb0), yy = h ? s1y[sio - SEC0V] : (L::STL ? ldv(sty + sio) : yb0);
                         const double rbv = (dro[h < NR ? h : 0] >> 20) & 1u ? rho_eq : rho_in, wv_ = ldv(wvv + (dvo[h] & 0xFFFF));     // (issued with the gather's reads)
                         const double r = (sigma * xx + (rbv * zz - yy)) + col_gather(wg, dvo[h]);
                         lds[h ? rpos[v] : (int)((unsigned)pky >> 16)] = r;
@@ -1407,30 +1420,30 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                         if (L::STL) { stz[sio] = zbv; sty[sio] = ybv; } else { zb0 = zbv; yb0 = ybv; }
                     }
                 }
-                if (NR == 2 && sio + 512 < ma) {              // second row (N = 25: 24 lanes), state in LDS
-                    const int r = row_of(sio + 512);
-                    double zg = s1zg[sio], yg = s1yg[sio];
+                if (NR == 2 && ir2(sio, 1) < ma) {              // second row (N = 25: 24 lanes), state in LDS
+                    const int r = row_of(ir2(sio, 1));
+                    double zg = s1zg[sio - SEC0R], yg = s1yg[sio - SEC0R];
                     const double rr = (dro[NR - 1] >> 21) & 1u ? rho_eq : rho_in, cf = lds[L::oCf + r];
                     const double zt = row_dot(xt, dro[NR - 1], r, cf);
                     const double zr = alpha * zt + (1.0 - alpha) * zg;
                     const double zn = clip(zr + yg * (rr == rho_eq ? inv_eq : inv_in), lds[L::oLg + r], lds[L::oUg + r]);
                     yg += rr * (zr - zn);
                     zg = zn;
-                    s1zg[sio] = zg; s1yg[sio] = yg;
+                    s1zg[sio - SEC0R] = zg; s1yg[sio - SEC0R] = yg;
                     const double w = rr * zg - yg;
                     wg[w_slot(dro[NR - 1], r)] = w;
                     tp += cf * w;
                 }
-                if (NV == 2 && sio + 512 < na) {              // second variable (N = 25: 13 lanes)
-                    const int v = sio + 512;
-                    double xx = s1x[sio], zz = s1z[sio], yy = s1y[sio];
+                if (NV == 2 && iv2(sio, 1) < na) {              // second variable (N = 25: 13 lanes)
+                    const int v = iv2(sio, 1);
+                    double xx = s1x[sio - SEC0V], zz = s1z[sio - SEC0V], yy = s1y[sio - SEC0V];
                     const double xtv = xt[dvo[NV - 1] & 0xFFFF], rb = (dro[NR - 1] >> 20) & 1u ? rho_eq : rho_in;
                     xx = alpha * xtv + (1.0 - alpha) * xx;
                     const double zr = alpha * xtv + (1.0 - alpha) * zz;
                     const double zn = clip(zr + yy * (rb == rho_eq ? inv_eq : inv_in), lds[L::oLb + v], lds[L::oUb + v]);
                     yy += rb * (zr - zn);
                     zz = zn;
-                    s1x[sio] = xx; s1z[sio] = zz; s1y[sio] = yy;
+                    s1x[sio - SEC0V] = xx; s1z[sio - SEC0V] = zz; s1y[sio - SEC0V] = yy;
                 }
                 if (L::P8) { tp = sum8(tp); redT[8 * wave + (lane >> 3)] = tp; }
                 else { tp = wave_sum(tp); if (lane == 0) redT[wave] = tp; }      // (read by the next iteration's P1: two barriers away)
@@ -1465,16 +1478,16 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             __syncthreads();
 #pragma unroll
             for (int h = 0; h < NR; h++) {
-                if (sio + 512 * h < ma) {
-                    const int r = row_of(sio + 512 * h);
-                    const double yg = h ? s1yg[sio] : (L::STL ? sth[sio] : yg0); ys[w_slot(drc[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg;
+                if (ir2(sio, h) < ma) {
+                    const int r = row_of(ir2(sio, h));
+                    const double yg = h ? s1yg[sio - SEC0R] : (L::STL ? sth[sio] : yg0); ys[w_slot(drc[h], r)] = yg; sums[0] += lds[L::oCf + r] * yg;
                 }
             }
 #pragma unroll
             for (int h = 0; h < NV; h++) {
-                const int v = sio + 512 * h;
+                const int v = iv2(sio, h);
                 if (v < na) {
-                    const double xx = h ? s1x[sio] : xv0;
+                    const double xx = h ? s1x[sio - SEC0V] : xv0;
                     double ha, rb_, lo_, hi_;
                     if (L::HAL) ha = lds[L::oHa + v]; else var_h(v, ha, rb_, lo_, hi_);
                     xt[dvc[h] & 0xFFFF] = xx; sums[1] += ha * xx;
@@ -1486,17 +1499,17 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
             const double xTc = xt[21];
 #pragma unroll
             for (int h = 0; h < NR; h++) {
-                if (sio + 512 * h < ma) {
-                    const int r = row_of(sio + 512 * h);
-                    const double zg = h ? s1zg[sio] : (L::STL ? stg[sio] : zg0), ax = row_dot(xt, drc[h], r, lds[L::oCf + r]);
+                if (ir2(sio, h) < ma) {
+                    const int r = row_of(ir2(sio, h));
+                    const double zg = h ? s1zg[sio - SEC0R] : (L::STL ? stg[sio] : zg0), ax = row_dot(xt, drc[h], r, lds[L::oCf + r]);
                     mx[0] = fmax(mx[0], fabs(ax - zg)); mx[1] = fmax(mx[1], fabs(ax)); mx[2] = fmax(mx[2], fabs(zg));
                 }
             }
 #pragma unroll
             for (int h = 0; h < NV; h++) {
-                const int v = sio + 512 * h;
+                const int v = iv2(sio, h);
                 if (v < na) {
-                    const double xx = h ? s1x[sio] : xv0, zz = h ? s1z[sio] : (L::STL ? stz[sio] : zb0), yy = h ? s1y[sio] : (L::STL ? sty[sio] : yb0);
+                    const double xx = h ? s1x[sio - SEC0V] : xv0, zz = h ? s1z[sio - SEC0V] : (L::STL ? stz[sio] : zb0), yy = h ? s1y[sio - SEC0V] : (L::STL ? sty[sio] : yb0);
                     double ha, rb_, lo_, hi_;
                     if (L::HAL) ha = lds[L::oHa + v]; else var_h(v, ha, rb_, lo_, hi_);
                     const double hx = (fabs(ha) + cfg.hess_reg) * xx + ha * xTc, aty = col_gather(ys, dvc[h]) + yy;
@@ -1513,15 +1526,15 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // ---------------- results ----------------
 #pragma unroll
     for (int h = 0; h < NV; h++) {
-        const int v = tid + 512 * h;
+        const int v = iv2(tid, h);
         if (v < na) {
-            ws.p[(size_t)b * n_tot + arm * na + v] = h ? s1x[tid] : xv0;
-            ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? s1y[tid] : (L::STL ? sty[tid] : yb0);
+            ws.p[(size_t)b * n_tot + arm * na + v] = h ? s1x[tid - SEC0V] : xv0;
+            ws.y[(size_t)b * mn_tot + NARM * ma + arm * na + v] = h ? s1y[tid - SEC0V] : (L::STL ? sty[tid] : yb0);
         }
     }
 #pragma unroll
     for (int h = 0; h < NR; h++) {
-        if (tid + 512 * h < ma) ws.y[(size_t)b * mn_tot + arm * ma + row_of(tid + 512 * h)] = h ? s1yg[tid] : (L::STL ? sth[tid] : yg0);
+        if (ir2(tid, h) < ma) ws.y[(size_t)b * mn_tot + arm * ma + row_of(ir2(tid, h))] = h ? s1yg[tid - SEC0R] : (L::STL ? sth[tid] : yg0);
     }
     if (tid == 511 && arm == 0) {
         ws.p[(size_t)b * n_tot + NARM * na] = misc[L::M_xT];
