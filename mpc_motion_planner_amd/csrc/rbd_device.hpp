@@ -57,7 +57,41 @@ __device__ __forceinline__ M3 joint_rot(const double *A, double s, double c) {
 // sc: [7][2] = sin, cos of the joint angles.
 // tw (optional, TANGENT only): lane-private LDS area for the tangent wrenches dF, dN (42 doubles, element e of this
 // lane at tw[e * tws]); keeps the per-thread VGPR footprint below the spill threshold in the 320-thread kernels.
-template <bool TANGENT, bool TW_LDS = false>
+//
+// RELOAD: the model constants of a joint are read (scalar loads) through an opaque copy of the model pointer right where the joint is
+// processed.  Without it the compiler loads all ~180 constants of the chain once per kernel, ahead of everything, runs out of SGPRs and parks
+// them in VGPR lanes: k_step<4> had 3,216 v_readlane_b32 for 4,600 FP64 instructions (round 5, from the ISA).  The model must be readable
+// through the constant address space (a kernel argument by value, or global memory nobody writes during the kernel).
+typedef const __attribute__((address_space(4))) mpcmp_model *cmodel_t;
+struct JointK { double R0[9], p[3], com[3], I[9], mass; };
+template <bool RELOAD, bool FWD>
+__device__ __forceinline__ void joint_consts(const mpcmp_model *__restrict__ M, int i, int ic, JointK &k) {      // (R0, p, I, mass of joint i; com of joint ic)
+    if (RELOAD) {
+        const mpcmp_model *Mo = M;
+        asm volatile("" : "+s"(Mo));
+        cmodel_t Mc = (cmodel_t)Mo;
+#pragma unroll
+        for (int q = 0; q < 9; q++) k.R0[q] = Mc->R0[i][q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { k.p[q] = Mc->p[i][q]; k.com[q] = Mc->com[ic][q]; }
+        if (FWD) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) k.I[q] = Mc->I[i][q];
+            k.mass = Mc->mass[i];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 9; q++) k.R0[q] = M->R0[i][q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { k.p[q] = M->p[i][q]; k.com[q] = M->com[ic][q]; }
+        if (FWD) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) k.I[q] = M->I[i][q];
+            k.mass = M->mass[i];
+        }
+    }
+}
+template <bool TANGENT, bool TW_LDS = false, bool RELOAD = false>
 __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, const double *sc, const double *v,
                                          const double *a, int type, int j, double *tau, double *dtau,
                                          double *tw = nullptr, int tws = 0) {
@@ -66,8 +100,10 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
     V3 dw = mk(0, 0, 0), dwd = mk(0, 0, 0), dal = mk(0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        const M3 R = joint_rot(M->R0[i], sc[2 * i], sc[2 * i + 1]);
-        const V3 p = ld3(M->p[i]), c = ld3(M->com[i]);
+        JointK K;
+        joint_consts<RELOAD, true>(M, i, i, K);
+        const M3 R = joint_rot(K.R0, sc[2 * i], sc[2 * i + 1]);
+        const V3 p = ld3(K.p), c = ld3(K.com);
         const double vi = v[i], ai = a[i];
         const V3 u = mulT(R, w), ud = mulT(R, wd);
         const V3 b = al + cross(wd, p) + cross(w, cross(w, p));
@@ -76,9 +112,9 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
         const V3 aln = mulT(R, b);
         const V3 wxc = cross(wn, c);
         const V3 ac = aln + cross(wdn, c) + cross(wn, wxc);
-        const V3 Iw = mulI(M->I[i], wn);
-        F[i] = M->mass[i] * ac;
-        N[i] = mulI(M->I[i], wdn) + cross(wn, Iw);
+        const V3 Iw = mulI(K.I, wn);
+        F[i] = K.mass * ac;
+        N[i] = mulI(K.I, wdn) + cross(wn, Iw);
         if (TANGENT) {
             const double dq = (type == 0 && i == j) ? 1.0 : 0.0;
             const double dv = (type == 1 && i == j) ? 1.0 : 0.0;
@@ -90,8 +126,8 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
             const V3 dwdn = mk(dud.x + du.y * vi + u.y * dv, dud.y - du.x * vi - u.x * dv, dud.z + da);
             const V3 daln = mulT(R, db) - zcross(aln, dq);
             const V3 dac = daln + cross(dwdn, c) + cross(dwn, wxc) + cross(wn, cross(dwn, c));
-            const V3 dFi = M->mass[i] * dac;
-            const V3 dNi = mulI(M->I[i], dwdn) + cross(dwn, Iw) + cross(wn, mulI(M->I[i], dwn));
+            const V3 dFi = K.mass * dac;
+            const V3 dNi = mulI(K.I, dwdn) + cross(dwn, Iw) + cross(wn, mulI(K.I, dwn));
             if (TW_LDS) {
                 tw[(6 * i + 0) * tws] = dFi.x; tw[(6 * i + 1) * tws] = dFi.y; tw[(6 * i + 2) * tws] = dFi.z;
                 tw[(6 * i + 3) * tws] = dNi.x; tw[(6 * i + 4) * tws] = dNi.y; tw[(6 * i + 5) * tws] = dNi.z;
@@ -104,7 +140,9 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
     V3 f = mk(0, 0, 0), n = mk(0, 0, 0), df = mk(0, 0, 0), dn = mk(0, 0, 0);
 #pragma unroll
     for (int i = 6; i >= 0; i--) {
-        const V3 c = ld3(M->com[i]);
+        JointK K;
+        joint_consts<RELOAD, false>(M, i < 6 ? i + 1 : 6, i, K);      // R0, p of joint i + 1 (i = 6: unused), com of joint i
+        const V3 c = ld3(K.com);
         V3 fi = F[i], ni = N[i] + cross(c, F[i]);
         V3 dfi = mk(0, 0, 0), dni = mk(0, 0, 0);
         if (TANGENT) {
@@ -116,8 +154,8 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
             dfi = dFi; dni = dNi + cross(c, dFi);
         }
         if (i < 6) {
-            const M3 R = joint_rot(M->R0[i + 1], sc[2 * (i + 1)], sc[2 * (i + 1) + 1]);
-            const V3 p = ld3(M->p[i + 1]);
+            const M3 R = joint_rot(K.R0, sc[2 * (i + 1)], sc[2 * (i + 1) + 1]);
+            const V3 p = ld3(K.p);
             const V3 gf = mul(R, f), gn = mul(R, n);
             fi = fi + gf; ni = ni + gn + cross(p, gf);
             if (TANGENT) {

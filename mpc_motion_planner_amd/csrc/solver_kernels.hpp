@@ -140,7 +140,8 @@ struct LinLds {
 // ------------------------------------------------------------------------------------------------
 // Linearisation of all nodes of one problem (block-wide). zl: iterate in LDS (external order).
 // scr: LDS scratch of N*14 + N*147 + N*7 doubles. Writes g [8N], Gk [N][8][22], ceq [meq] (global).
-template <int NSEG>
+// GMODEL: mdl points to global memory (WS::model), and the recursion reads the constants of a joint where it processes it (rnea_dir's RELOAD)
+template <int NSEG, bool GMODEL = false>
 __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__restrict__ mdl, const double *zl,
                                 double *scr, double *g_out, double *Gk_out, double *ceq_out, int tid) {
     using D = Dim<NSEG>;
@@ -164,7 +165,7 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
         const double *v = zl + 14 * k + 7, *a = zl + 14 * N + 7 * k;
         if (d < 21) {
             double tau[7], dtau[7];
-            rnea_dir<true, LinLds<NSEG>::TW>(mdl, q_sc, v, a, d / 7, d % 7, tau, dtau, tw + tid, D::NT);
+            rnea_dir<true, LinLds<NSEG>::TW, GMODEL>(mdl, q_sc, v, a, d / 7, d % 7, tau, dtau, tw + tid, D::NT);
 #pragma unroll
             for (int i = 0; i < 7; i++) raw[(k * 7 + i) * 21 + d] = dtau[i];
             if (d == 0) {
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, mpcmp_
     for (int v = tid; v < n; v += D::NT) ws.z[(size_t)b * n + v] = zl[v];
     if (!cfg.carry_multipliers || prev_bad) for (int i = tid; i < D::mn; i += D::NT) ws.lam[(size_t)b * D::mn + i] = 0.0;      // (carried: the slot's multipliers of the previous solve stay)
     if (tid == 0) { ws.qp_total[b] = 0; ws.status[b] = 0; ws.alpha[b] = 0.0; }
-    linearise_block<NSEG>(cfg, &mdl, zl, scr, ws.g + (size_t)b * 8 * N, ws.Gk + (size_t)b * N * 176,
+    linearise_block<NSEG, true>(cfg, ws.model, zl, scr, ws.g + (size_t)b * 8 * N, ws.Gk + (size_t)b * N * 176,
                           ws.ceq + (size_t)b * D::meq, tid);
 }
 template <int NSEG>
@@ -875,9 +876,9 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
             v[j] = zl[14 * k + 7 + j] + al * pl[14 * k + 7 + j];
             a[j] = zl[14 * N + 7 * k + j] + al * pl[14 * N + 7 * k + j];
         }
-        rnea_dir<false>(&mdl, sct + 14 * t, v, a, 0, 0, tau, nullptr);
+        rnea_dir<false, false, true>(ws.model, sct + 14 * t, v, a, 0, 0, tau, nullptr);
         V3 ptool;
-        fk_tool(&mdl, sct + 14 * t, &ptool, nullptr, nullptr, nullptr);
+        fk_tool(ws.model, sct + 14 * t, &ptool, nullptr, nullptr, nullptr);
         double s = viol(ptool.z, cfg.lbg[7], cfg.ubg[7]);
 #pragma unroll
         for (int j = 0; j < 7; j++) s += viol(tau[j], cfg.lbg[j], cfg.ubg[j]);
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
     __syncthreads();
     double *gout = ws.g + (size_t)b * 8 * N, *ceqo = ws.ceq + (size_t)b * meq;
     KSTAMP(5);
-    linearise_block<NSEG>(cfg, &mdl, zl, scr, gout, ws.Gk + (size_t)b * N * 176, ceqo, tid);
+    linearise_block<NSEG, true>(cfg, ws.model, zl, scr, gout, ws.Gk + (size_t)b * N * 176, ceqo, tid);
     KSTAMP(6);
     if (tid == 0) ws.alpha[b] = alpha;
     if (final_iter) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase issue table of the ADMM role loops of a QP kernel, from the ISA (no GPU needed).
 
-    python tools/isa_phases.py [k_qp2|k_qp5|k_qp6] [--raw]
+    python tools/isa_phases.py [k_qp2|k_qp5|k_qp3_n25] [--raw]
 
 Compiles mpc_motion_planner_amd/csrc/mpcmp.hip for gfx950 with the product flags plus -DMPCMP_NOCHECK (the termination-test
 block is compiled out, so the hot path of a role is the straight-line text between its workgroup barriers), finds the role
@@ -25,20 +25,24 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mpc_motion_planner_amd", "csrc")
-KERNELS = {"k_qp5": "_ZN5mpcmp5k_qp5ILi6E", "k_qp2": "_ZN5mpcmp5k_qp2ILi4E", "k_qp6": "_ZN5mpcmp5k_qp6ILi4E"}
+KERNELS = {"k_qp5": "_ZN5mpcmp5k_qp5ILi6E", "k_qp2": "_ZN5mpcmp5k_qp2ILi4E", "k_qp6": "_ZN5mpcmp5k_qp6ILi4E",
+           "k_qp3_n25": "_ZN5mpcmp5k_qp3ILi8ELi2E"}      # (k_qp3_n25: the dual-arm N = 25 loop kernel, from csrc/qp3_n25.hip)
 LDS_R = {"ds_read_b128": 4, "ds_read_b64": 2, "ds_read_b32": 2, "ds_read2_b64": 8, "ds_read2_b32": 4, "ds_read_u16": 2, "ds_read_u8": 2, "ds_read_b96": 8,
          "ds_read_u16_d16": 2, "ds_read_u16_d16_hi": 2, "ds_read2st64_b64": 8}
 LDS_W = {"ds_write_b128": 8, "ds_write_b64": 4, "ds_write_b32": 2, "ds_write2_b64": 8, "ds_write2_b32": 4, "ds_write_b96": 8, "ds_write_b16": 2}
 
 
-def compile_isa(tmp, extra):
+def compile_isa(tmp, extra, n25=False):
+    src = "qp3_n25.hip" if n25 else "mpcmp.hip"
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang",
            "-load-store-opt", "-falign-loops=64", "-DMPCMP_SPLIT_N25", "-DMPCMP_NOCHECK", "--save-temps", "-I", os.path.join(ROOT, "include"),
-           "-c", "-o", os.path.join(tmp, "m.o"), os.path.join(CSRC, "mpcmp.hip")] + extra
+           "-c", "-o", os.path.join(tmp, "m.o"), os.path.join(CSRC, src)] + extra
+    if n25:
+        cmd += ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]      # (as csrc/Makefile builds that translation unit)
     r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
     if r.returncode:
         sys.exit(r.stderr[-4000:])
-    return os.path.join(tmp, "mpcmp-hip-amdgcn-amd-amdhsa-gfx950.s")
+    return os.path.join(tmp, src.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
 def classify(op):
@@ -136,7 +140,7 @@ def main():
     name = args[0] if args else "k_qp2"
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
     with tempfile.TemporaryDirectory() as tmp:
-        path = compile_isa(tmp, extra)
+        path = compile_isa(tmp, extra, name.endswith("n25"))
         loops = role_loops(path, KERNELS.get(name, name))
         print("%s: %d role loops (five barriers each)" % (name, len(loops)))
         for r, (lo, hi, seg) in enumerate(loops):
