@@ -887,7 +887,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
     }
     if (nhalf > 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st)); for (int h = 1; h < nhalf; h++) HIPCHK(ctx, hipStreamWaitEvent(sh[h], ctx->ev_fork, 0)); }
     for (int h = 0; h < nhalf; h++)
-        hipLaunchKernelGGL(k_init<NSEG>, dim3(Bh[h]), dim3(D::NT), l_init, sh[h], cfg, ctx->model, wh[h], hx[h], hu[h], hT[h], reguess);
+        hipLaunchKernelGGL(k_init<NSEG>, dim3(Bh[h]), dim3(D::NT), l_init, sh[h], cfg, wh[h], hx[h], hu[h], hT[h], reguess);
     const int iters = only_qp ? 1 : cfg.sqp_iters;
     for (int it = 0; it < iters; it++) {
         for (int h = 0; h < nhalf; h++) {
@@ -920,7 +920,7 @@ static int solve_impl(mpcmp_ctx *ctx, int B, const double *d_x0, const double *d
             else hipLaunchKernelGGL((k_qp<S::N1>), dim3(Bh[h]), dim3(Dim<S::N1>::NT), l_qp, sh[h], cfg, wh[h]);
             if (ev) HIPCHK(ctx, hipEventRecord(ev[1], sh[h]));
             if (only_qp) continue;
-            hipLaunchKernelGGL(k_step<NSEG>, dim3(Bh[h]), dim3(D::NT), l_step, sh[h], cfg, ctx->model, wh[h], it == iters - 1 ? 1 : 0, it,
+            hipLaunchKernelGGL(k_step<NSEG>, dim3(Bh[h]), dim3(D::NT), l_step, sh[h], cfg, wh[h], it == iters - 1 ? 1 : 0, it,
                                ox[h], ou[h], oT[h], oi[h]);
         }
     }
@@ -1088,7 +1088,7 @@ extern "C" int mpcmp_warm_start_batch(mpcmp_ctx *ctx, int B, const double *x0, c
     const mpcmp_config save = run_config(ctx);
     WS w = ctx->ws; w.x0 = ctx->d_x0; w.xf = ctx->d_xf;
 #define LAUNCH_INIT(NS) { const size_t l = InitLds<NS>::size * sizeof(double); \
-        hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, ctx->model, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); }
+        hipLaunchKernelGGL(k_init<NS>, dim3(B), dim3(Dim<NS>::NT), l, st, save, w, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); }
     switch (ctx->nseg) { case 1: LAUNCH_INIT(1) break; case 2: LAUNCH_INIT(2) break; case 4: LAUNCH_INIT(4) break; case 6: LAUNCH_INIT(6) break;
         case 8: { const size_t l = DimM<8, 1>::size * sizeof(double);
                   hipLaunchKernelGGL((k_init_m<8, 1>), dim3(B), dim3(512), l, st, save, ctx->d_model, w, ctx->xch, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0); } break; }
@@ -1394,7 +1394,7 @@ extern "C" int mpcmp_eval_constraints_batch(mpcmp_ctx *ctx, int n, const double 
     const size_t l = EvalLds<NS>::size * sizeof(double);
     if (int rc = set_lds(ctx, k_eval_constraints<NS>, l)) return rc;
     const int N = Dim<NS>::N;
-    hipLaunchKernelGGL(k_eval_constraints<NS>, dim3((n + N - 1) / N), dim3(Dim<NS>::NT), l, st, ctx->cfg, ctx->model, n, dx, du, dg, dG);
+    hipLaunchKernelGGL(k_eval_constraints<NS>, dim3((n + N - 1) / N), dim3(Dim<NS>::NT), l, st, ctx->cfg, (const mpcmp_model *)ctx->d_model, n, dx, du, dg, dG);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(g, dg, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(G, dG, sizeof(double) * 176 * n, hipMemcpyDeviceToHost, st));

@@ -143,9 +143,15 @@ struct LinLds {
 // GMODEL: mdl points to global memory (WS::model), and the recursion reads the constants of a joint where it processes it (rnea_dir's RELOAD)
 template <int NSEG, bool GMODEL = false>
 __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const mpcmp_model *__restrict__ mdl, const double *zl,
-                                double *scr, double *g_out, double *Gk_out, double *ceq_out, int tid) {
+                                double *scr, double *g_out, double *Gk_out, double *ceq_out, int tid, unsigned long long *stamps = nullptr) {
     using D = Dim<NSEG>;
     constexpr int N = D::N;
+#ifdef MPCMP_STAMPS
+    unsigned long long lst_t = clock64();
+#define LSTAMP(slot) do { if (stamps != nullptr && tid == 0) { const unsigned long long now_ = clock64(); stamps[slot] = now_ - lst_t; lst_t = now_; } } while (0)
+#else
+#define LSTAMP(slot) do { } while (0)
+#endif
     double *sc = scr;               // [N][14]
     double *raw = scr + N * 14;     // [N][7][21]
     double *tw = raw + N * 147;     // [42][NT] tangent wrenches of rnea_dir (lane-transposed)
@@ -155,6 +161,7 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
         sc[2 * t] = s; sc[2 * t + 1] = c;
     }
     __syncthreads();
+    LSTAMP(0);
     // one pass (a plain `if`, not a loop: a loop makes the compiler hoist the ~180 model constants of the recursion
     // out of it as loop invariants and spill them)
     static_assert(N * 22 <= D::NT, "one (node, direction) pair per thread");
@@ -184,6 +191,7 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
         }
     }
     __syncthreads();
+    LSTAMP(1);
     // rows 0..6 of every node: [dtau/dq | dtau/dqd | M symmetrised | quirk column]  (robot_ocp.hpp:129-142)
     for (int t = tid; t < N * 7 * 22; t += D::NT) {
         const int k = t / 154, i = (t % 154) / 22, c = t % 22;
@@ -202,6 +210,7 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
         }
         Gk_out[(k * 8 + i) * 22 + c] = val;
     }
+    LSTAMP(2);
     if (ceq_out) {
         const double T = zl[D::n - 1], ts = 1.0 / (2.0 * NSEG);
         for (int r = tid; r < D::meq; r += D::NT) {
@@ -214,16 +223,17 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
         }
     }
     __syncthreads();
+    LSTAMP(3);
 }
 
 
 // ------------------------------------------------------------------------------------------------
 // k_init
 template <int NSEG>
-__global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, mpcmp_model mdl, WS ws, const double *warm_x,
+__global__ __launch_bounds__(Dim<NSEG>::NT) void k_init(mpcmp_config cfg, WS ws, const double *warm_x,
                                                         const double *warm_u, const double *warm_T, int reguess) {
-    // (the model is a by-value kernel argument: its ~180 constants become scalar-load operands of the recursion
-    //  instead of vector loads that get hoisted and spilled)
+    // (the model is read from the context's device copy, WS::model, joint by joint: rnea_dir's RELOAD.  Until round 5 it was a by-value kernel
+    //  argument whose ~180 constants the compiler loaded once, ahead of everything, and parked in VGPR lanes for lack of SGPRs)
     using D = Dim<NSEG>;
     constexpr int N = D::N, n = D::n;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -813,7 +823,7 @@ __device__ __forceinline__ void step_tail(const WS &ws, double *lds, int tid, in
 }
 
 template <int NSEG>
-__global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_model mdl, WS ws, int final_iter, int sqp_it,
+__global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, WS ws, int final_iter, int sqp_it,
                                                         double *sol_x, double *sol_u, double *sol_T, mpcmp_info *info) {
     using D = Dim<NSEG>;
     using L = StepLds<NSEG>;
@@ -928,7 +938,11 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_step(mpcmp_config cfg, mpcmp_
     __syncthreads();
     double *gout = ws.g + (size_t)b * 8 * N, *ceqo = ws.ceq + (size_t)b * meq;
     KSTAMP(5);
+#ifdef MPCMP_STAMPS
+    linearise_block<NSEG, true>(cfg, ws.model, zl, scr, gout, ws.Gk + (size_t)b * N * 176, ceqo, tid, ws.dbg + (size_t)b * MPCMP_DBG_WORDS + 152);
+#else
     linearise_block<NSEG, true>(cfg, ws.model, zl, scr, gout, ws.Gk + (size_t)b * N * 176, ceqo, tid);
+#endif
     KSTAMP(6);
     if (tid == 0) ws.alpha[b] = alpha;
     if (final_iter) {
@@ -979,7 +993,7 @@ __global__ __launch_bounds__(64) void k_rnea_batch(const mpcmp_model *mdl, int n
 
 // evalConstraints AD overload for a list of (x,u): processed in chunks of N "nodes" per workgroup
 template <int NSEG>
-__global__ __launch_bounds__(Dim<NSEG>::NT) void k_eval_constraints(mpcmp_config cfg, mpcmp_model mdl, int total,
+__global__ __launch_bounds__(Dim<NSEG>::NT) void k_eval_constraints(mpcmp_config cfg, const mpcmp_model *mdl, int total,
                                                                     const double *x, const double *u, double *g,
                                                                     double *G) {
     using D = Dim<NSEG>;
@@ -996,7 +1010,7 @@ __global__ __launch_bounds__(Dim<NSEG>::NT) void k_eval_constraints(mpcmp_config
     __syncthreads();
     double *gl = scr + LinLds<NSEG>::size, *Gl = gl + 8 * N;
     // write into LDS staging first (tail chunk may be partial), then copy the valid part out
-    linearise_block<NSEG>(cfg, &mdl, zl, scr, gl, Gl, nullptr, tid);
+    linearise_block<NSEG, true>(cfg, mdl, zl, scr, gl, Gl, nullptr, tid);
     const int valid = (total - base < N) ? total - base : N;
     for (int t = tid; t < valid * 8; t += D::NT) g[(size_t)base * 8 + t] = gl[t];
     for (int t = tid; t < valid * 176; t += D::NT) G[(size_t)base * 176 + t] = Gl[t];

@@ -93,6 +93,13 @@ def _hot_loop_scratch(asm_path, prefix):
     return nloops, nscr
 
 
+def _count_ops(asm_path, prefix, op):
+    lines = open(asm_path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(re.escape(prefix) + r"\S*:", l))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+    return sum(1 for l in lines[start:end] if l.startswith("\t") and l.split()[:1] == [op])
+
+
 def test_qp_kernels_stay_inside_their_register_and_scratch_budgets():
     with tempfile.TemporaryDirectory() as tmp:
         p_main, d_main = _compile("mpcmp.hip", ["-DMPCMP_SPLIT_N25"], tmp, "main")
@@ -112,3 +119,8 @@ def test_qp_kernels_stay_inside_their_register_and_scratch_budgets():
             else:
                 # k_qp5: two reloads per role loop are known and measured harmless (docs/HISTORY.md C.9); more means a factor entry was spilled
                 assert nscr <= 2 * nloops, "%s: %d scratch operations inside its %d ADMM iteration loops" % (prefix, nscr, nloops)
+        # the step kernels read the robot model joint by joint (rbd_device.hpp, RELOAD); loaded once per kernel its ~180 constants do not fit the
+        # SGPR file and come back through v_readlane_b32: 3,216 of them in k_step<4> until round 5 (now ~200: the config's box limits)
+        for prefix in ("_ZN5mpcmp6k_stepILi4E", "_ZN5mpcmp6k_stepILi6E", "_ZN5mpcmp6k_initILi4E"):
+            nrl = _count_ops(asm, prefix, "v_readlane_b32")
+            assert nrl <= 400, "%s: %d v_readlane_b32 (SGPR spills of the model constants are back)" % (prefix, nrl)

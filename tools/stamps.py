@@ -58,3 +58,6 @@ if ks.sum() > 0:
                             "reduction of the 9 merits", "Armijo, update of z and lambda", "re-linearisation (tangent RNEA, Jacobian rows, defects)", "final report"]):
         print("k_step %-52s %9.0f cycles" % (nm, ks[:, k].mean()))
     print("k_step total %9.0f cycles" % ks.sum(axis=1).mean())
+    ls = st2[:, 152:156].astype(np.float64)
+    for k, nm in enumerate(["sincos of the iterate", "tangent RNEA, one (node, direction) per thread, + FK row", "Jacobian rows -> Gk (global)", "defects -> ceq (global)"]):
+        print("   re-linearisation: %-56s %9.0f cycles" % (nm, ls[:, k].mean()))
