@@ -37,6 +37,14 @@ extern template __global__ void k_qp3<8, 2>(mpcmp_config, WS, const Qp3Pat *, Xc
 }  // namespace mpcmp
 #endif
 
+#ifdef MPCMP_SPLIT_N19
+// the N = 19 one-arm pair lives in qp5_n19.hip (its own scheduler strategy: see there)
+namespace mpcmp {
+extern template __global__ void k_qp3f<6, 1, 5>(mpcmp_config, WS, const Qp3Pat *, Xch, int, double *);
+extern template __global__ void k_qp5<6>(mpcmp_config, WS, const Qp3Pat *, Xch, int, const double *);
+}  // namespace mpcmp
+#endif
+
 using namespace mpcmp;
 
 struct mpcmp_ctx {

@@ -1,6 +1,6 @@
 """Register / scratch budget of the QP kernels, from the compiler's resource remarks and the ISA (hipcc cross-compiles for gfx950: no GPU needed).
 
-The loop kernels live at the edge of their register files (k_qp2: 1024 threads x 128 VGPRs, k_qp5: 768 x 168, k_qp3<8, 2>: 512 x 256), and their
+The loop kernels live at the edge of their register files (k_qp2: 1024 threads x 128 VGPRs, k_qp5: 768 x 168 (its own translation unit, like the N = 25 kernels), k_qp3<8, 2>: 512 x 256), and their
 speed collapses when a change elsewhere tips the allocator: round 5's early exit for retired receding-horizon instances cost k_qp3<8, 2> 20 B of
 scratch and 8 % of its speed until it was taken back, a what-if with 36-double blocks in k_qp2's role B (224 B of scratch) ran 2 x slower.  This test
 pins what the committed sources compile to: scratch bytes per lane of every QP kernel (upper bounds = the round-5 product build), and NO scratch
@@ -20,11 +20,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 BUDGET_MAIN = {
     "_ZN5mpcmp5k_qp2ILi4E": (128, 100),          # scratch: the cold termination-test block only (hot loops checked below)
     "_ZN5mpcmp5k_qp2ILi2E": (128, 100),
-    "_ZN5mpcmp5k_qp5ILi6E": (168, 68),
-    "_ZN5mpcmp6k_qp3fILi6ELi1ELi5E": (128, 0),
     "_ZN5mpcmp6k_qp3fILi6ELi2ELi3E": (128, 0),
     "_ZN5mpcmp5k_qp3ILi6ELi2E": (256, 44),
     "_ZN5mpcmp5k_qp3ILi6ELi1E": (256, 36),
+}
+BUDGET_N19 = {                                    # csrc/qp5_n19.hip, built with max-memory-clause
+    "_ZN5mpcmp5k_qp5ILi6E": (168, 72),
+    "_ZN5mpcmp6k_qp3fILi6ELi1ELi5E": (128, 0),
 }
 BUDGET_N25 = {
     "_ZN5mpcmp5k_qp3ILi8ELi2E": (256, 96),        # configs[3] (iterative-minreg; 144 B with max-ilp is 5 % of dual14, 164 B another 8 %: DESIGN.md 5)
@@ -32,6 +34,14 @@ BUDGET_N25 = {
     "_ZN5mpcmp6k_qp3fILi8ELi2E": (128, 0),
     "_ZN5mpcmp6k_qp3fILi8ELi1E": (128, 0),
 }
+
+
+def _strategy(src):
+    """the scheduler strategy csrc/Makefile builds `src` with"""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    mk = re.sub(r"\$\(N19_STRATEGY\)", re.search(r"^N19_STRATEGY\s*:=\s*(\S+)", mk, re.M).group(1), mk)
+    m = re.search(r"-mllvm -amdgpu-sched-strategy=(\S+) -c -o \$@ " + re.escape(src), mk)
+    return ["-mllvm", "-amdgpu-sched-strategy=" + m.group(1)]
 
 
 def _flags():
@@ -102,17 +112,22 @@ def _count_ops(asm_path, prefix, op):
 
 def test_qp_kernels_stay_inside_their_register_and_scratch_budgets():
     with tempfile.TemporaryDirectory() as tmp:
-        p_main, d_main = _compile("mpcmp.hip", ["-DMPCMP_SPLIT_N25"], tmp, "main")
-        p_n25, d_n25 = _compile("qp3_n25.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"], tmp, "n25")      # (as csrc/Makefile builds it)
+        p_main, d_main = _compile("mpcmp.hip", ["-DMPCMP_SPLIT_N25", "-DMPCMP_SPLIT_N19"], tmp, "main")
+        p_n25, d_n25 = _compile("qp3_n25.hip", _strategy("qp3_n25.hip"), tmp, "n25")      # (as csrc/Makefile builds it)
+        p_n19, d_n19 = _compile("qp5_n19.hip", _strategy("qp5_n19.hip"), tmp, "n19")
         _, e_main = p_main.communicate(timeout=900)
         _, e_n25 = p_n25.communicate(timeout=900)
+        _, e_n19 = p_n19.communicate(timeout=900)
         assert p_main.returncode == 0, e_main[-3000:]
         assert p_n25.returncode == 0, e_n25[-3000:]
+        assert p_n19.returncode == 0, e_n19[-3000:]
         _check(_resources(e_main), BUDGET_MAIN)
         _check(_resources(e_n25), BUDGET_N25)
+        _check(_resources(e_n19), BUDGET_N19)
         asm = os.path.join(d_main, "mpcmp-hip-amdgcn-amd-amdhsa-gfx950.s")
+        asm19 = os.path.join(d_n19, "qp5_n19-hip-amdgcn-amd-amdhsa-gfx950.s")
         for prefix, min_loops in (("_ZN5mpcmp5k_qp2ILi4E", 3), ("_ZN5mpcmp5k_qp5ILi6E", 2)):
-            nloops, nscr = _hot_loop_scratch(asm, prefix)
+            nloops, nscr = _hot_loop_scratch(asm19 if "k_qp5" in prefix else asm, prefix)
             assert nloops >= min_loops, (prefix, nloops)
             if prefix.endswith("k_qp2ILi4E"):
                 assert nscr == 0, "%s: %d scratch operations inside its ADMM iteration loops" % (prefix, nscr)

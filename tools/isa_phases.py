@@ -32,13 +32,15 @@ LDS_R = {"ds_read_b128": 4, "ds_read_b64": 2, "ds_read_b32": 2, "ds_read2_b64": 
 LDS_W = {"ds_write_b128": 8, "ds_write_b64": 4, "ds_write_b32": 2, "ds_write2_b64": 8, "ds_write2_b32": 4, "ds_write_b96": 8, "ds_write_b16": 2}
 
 
-def compile_isa(tmp, extra, n25=False):
-    src = "qp3_n25.hip" if n25 else "mpcmp.hip"
+def compile_isa(tmp, extra, n25=False, n19=False):
+    src = "qp3_n25.hip" if n25 else ("qp5_n19.hip" if n19 else "mpcmp.hip")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang",
            "-load-store-opt", "-falign-loops=64", "-DMPCMP_SPLIT_N25", "-DMPCMP_NOCHECK", "--save-temps", "-I", os.path.join(ROOT, "include"),
            "-c", "-o", os.path.join(tmp, "m.o"), os.path.join(CSRC, src)] + extra
     if n25:
         cmd += ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]      # (as csrc/Makefile builds that translation unit)
+    if n19:
+        cmd += ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
     r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
     if r.returncode:
         sys.exit(r.stderr[-4000:])
@@ -140,7 +142,7 @@ def main():
     name = args[0] if args else "k_qp2"
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
     with tempfile.TemporaryDirectory() as tmp:
-        path = compile_isa(tmp, extra, name.endswith("n25"))
+        path = compile_isa(tmp, extra, name.endswith("n25"), name == "k_qp5")
         loops = role_loops(path, KERNELS.get(name, name))
         print("%s: %d role loops (five barriers each)" % (name, len(loops)))
         for r, (lo, hi, seg) in enumerate(loops):
