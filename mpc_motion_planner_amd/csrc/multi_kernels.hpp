@@ -55,16 +55,23 @@ __device__ __forceinline__ void linearise_arm(const mpcmp_config &cfg, const mpc
         sc[2 * t] = s; sc[2 * t + 1] = c;
     }
     __syncthreads();
+    // Item order: the 14 N directions in (q, v) — the generic tangent recursion —, then the 7 N directions in a (mass-matrix columns: rnea_mcol, a
+    // quarter of the instructions), then the N tool rows.  N = 25 has 550 items for 512 lanes: the 38 of the second pass (short ones) go to the LAST
+    // lanes, whose first-pass items are short as well; in node-major order wave 0 ran two generic streams while seven waves waited.
+    constexpr int LH = 14 * N, LF0 = 21 * N, LTOT = 22 * N;
 #pragma nounroll
-    for (int t = tid; t < N * 22; t += NT) {
+    for (int u0 = 0; u0 < LTOT; u0 += NT) {
+        const int t = u0 == 0 ? tid : u0 + (NT - 1 - tid);
+        if (t >= LTOT) continue;
         // (an opaque copy of the model pointer per pass: the ~180 model constants of the recursion are otherwise hoisted out of the loop
         //  as invariants and spilled - 1.7 KB of scratch per lane; with it they are scalar loads inside the pass)
         const mpcmp_model *mdl = mdl_;
         asm volatile("" : "+s"(mdl));
-        const int k = t / 22, d = t % 22;
+        const int k = t < LH ? t / 14 : (t < LF0 ? (t - LH) / 7 : t - LF0);
+        const int d = t < LH ? t % 14 : (t < LF0 ? 14 + (t - LH) % 7 : 21);
         const double *q_sc = sc + 14 * k;
         const double *v = zl + 14 * k + 7, *a = zl + 14 * N + 7 * k;
-        if (d < 21) {
+        if (d < 14) {
             double tau[7], dtau[7];
             rnea_dir<true, false>(mdl, q_sc, v, a, d / 7, d % 7, tau, dtau);
 #pragma unroll
@@ -73,6 +80,11 @@ __device__ __forceinline__ void linearise_arm(const mpcmp_config &cfg, const mpc
 #pragma unroll
                 for (int i = 0; i < 7; i++) g_out[8 * k + i] = tau[i];
             }
+        } else if (d < 21) {
+            double dtau[7];
+            rnea_mcol<false, false>(mdl, q_sc, d - 14, dtau);
+#pragma unroll
+            for (int i = 0; i < 7; i++) raw[(k * 7 + i) * 21 + d] = dtau[i];
         } else {
             V3 pt; double Jz[7];
             fk_tool(mdl, q_sc, &pt, Jz, nullptr, nullptr);
@@ -86,22 +98,28 @@ __device__ __forceinline__ void linearise_arm(const mpcmp_config &cfg, const mpc
     }
     __syncthreads();
     // rows 0..6 of every node: [dtau/dq | dtau/dqd | M symmetrised | quirk column]  (robot_ocp.hpp:129-142)
+    // (the quirk column — a 14-term sum — has a pass of its own: inside the pass below one lane in 22 ran its loop and the other 21 waited, in every
+    //  round of the pass: 9.5 k of k_step<4>'s 93 k cycles)
     for (int t = tid; t < N * 7 * 22; t += NT) {
         const int k = t / 154, i = (t % 154) / 22, c = t % 22;
         const double *rk = raw + k * 147;
+        if (c == 21) continue;
         double val;
         if (c < 14) val = rk[i * 21 + c];
-        else if (c < 21) { const int j = c - 14; val = (i <= j) ? rk[i * 21 + 14 + j] : rk[j * 21 + 14 + i]; }
-        else {
-            val = 0.0;
-            if (cfg.quirk_dtau_dT) {
-                for (int j = 0; j < 7; j++) {
-                    val += rk[i * 21 + 7 + j] * zl[14 * k + 7 + j];
-                    if (j >= i) val += rk[i * 21 + 14 + j] * zl[14 * N + 7 * k + j];
-                }
+        else { const int j = c - 14; val = (i <= j) ? rk[i * 21 + 14 + j] : rk[j * 21 + 14 + i]; }
+        Gk_out[(k * 8 + i) * 22 + c] = val;
+    }
+    for (int t = tid; t < N * 7; t += NT) {
+        const int k = t / 7, i = t % 7;
+        const double *rk = raw + k * 147;
+        double val = 0.0;
+        if (cfg.quirk_dtau_dT) {
+            for (int j = 0; j < 7; j++) {
+                val += rk[i * 21 + 7 + j] * zl[14 * k + 7 + j];
+                if (j >= i) val += rk[i * 21 + 14 + j] * zl[14 * N + 7 * k + j];
             }
         }
-        Gk_out[(k * 8 + i) * 22 + c] = val;
+        Gk_out[(k * 8 + i) * 22 + 21] = val;
     }
     const double ts = 1.0 / (2.0 * NSEG);
     for (int r = tid; r < 14 * (N - 1); r += NT) {

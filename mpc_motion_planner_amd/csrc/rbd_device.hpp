@@ -171,6 +171,58 @@ __device__ __forceinline__ void rnea_dir(const mpcmp_model *__restrict__ M, cons
     }
 }
 
+// Column j of the joint-space inertia matrix, d tau / d a_j: rnea_dir's tangent for type 2, where the tangent angular velocity is zero and the
+// nominal motion (w, wd, al, F, N) drops out of every term — a quarter of the generic recursion's instructions.  Every term left out is an exact
+// zero in rnea_dir<true> (products with dq = dv = 0 and dw = 0), so the two agree to the sign of zeros (finite inputs).
+template <bool TW_LDS = false, bool RELOAD = false>
+__device__ __forceinline__ void rnea_mcol(const mpcmp_model *__restrict__ M, const double *sc, int j, double *dtau, double *tw = nullptr, int tws = 0) {
+    V3 dF[TW_LDS ? 1 : 7], dN[TW_LDS ? 1 : 7];
+    V3 dwd = mk(0, 0, 0), dal = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        JointK K;
+        joint_consts<RELOAD, true>(M, i, i, K);
+        const M3 R = joint_rot(K.R0, sc[2 * i], sc[2 * i + 1]);
+        const V3 p = ld3(K.p), c = ld3(K.com);
+        const double da = (i == j) ? 1.0 : 0.0;
+        const V3 dud = mulT(R, dwd);
+        const V3 db = dal + cross(dwd, p);
+        const V3 dwdn = mk(dud.x, dud.y, dud.z + da);
+        const V3 daln = mulT(R, db);
+        const V3 dac = daln + cross(dwdn, c);
+        const V3 dFi = K.mass * dac;
+        const V3 dNi = mulI(K.I, dwdn);
+        if (TW_LDS) {
+            tw[(6 * i + 0) * tws] = dFi.x; tw[(6 * i + 1) * tws] = dFi.y; tw[(6 * i + 2) * tws] = dFi.z;
+            tw[(6 * i + 3) * tws] = dNi.x; tw[(6 * i + 4) * tws] = dNi.y; tw[(6 * i + 5) * tws] = dNi.z;
+        } else { dF[i] = dFi; dN[i] = dNi; }
+        dwd = dwdn; dal = daln;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    V3 df = mk(0, 0, 0), dn = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 6; i >= 0; i--) {
+        JointK K;
+        joint_consts<RELOAD, false>(M, i < 6 ? i + 1 : 6, i, K);
+        const V3 c = ld3(K.com);
+        V3 dFi, dNi;
+        if (TW_LDS) {
+            dFi = mk(tw[(6 * i + 0) * tws], tw[(6 * i + 1) * tws], tw[(6 * i + 2) * tws]);
+            dNi = mk(tw[(6 * i + 3) * tws], tw[(6 * i + 4) * tws], tw[(6 * i + 5) * tws]);
+        } else { dFi = dF[i]; dNi = dN[i]; }
+        V3 dfi = dFi, dni = dNi + cross(c, dFi);
+        if (i < 6) {
+            const M3 R = joint_rot(K.R0, sc[2 * (i + 1)], sc[2 * (i + 1) + 1]);
+            const V3 p = ld3(K.p);
+            const V3 dgf = mul(R, df), dgn = mul(R, dn);
+            dfi = dfi + dgf; dni = dni + dgn + cross(p, dgf);
+        }
+        df = dfi; dn = dni;
+        dtau[i] = dn.z;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Forward kinematics of the chain: tool position and the z-row of the world-aligned tool Jacobian
 // (robot_ocp.hpp:145-160: J = blockdiag(R,R) * J_local, row 2).  Also returns joint-7 origin height
 // (MotionPlanner::sample_random_state rejects on oMi[7].z, motionPlanner.cpp:111) and link8 position.

@@ -163,14 +163,19 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
     __syncthreads();
     LSTAMP(0);
     // one pass (a plain `if`, not a loop: a loop makes the compiler hoist the ~180 model constants of the recursion
-    // out of it as loop invariants and spill them)
-    static_assert(N * 22 <= D::NT, "one (node, direction) pair per thread");
-    if (tid < N * 22) {
+    // out of it as loop invariants and spill them).  Lane map: the 14 N directions in (q, v) first — the generic tangent recursion —, then, from
+    // the next wave boundary on, the 7 N directions in a (mass-matrix columns: rnea_mcol, a quarter of the instructions), then the N tool rows.
+    // With N = 13 the workgroup is five waves on four SIMDs; node-major order gave waves 0 and 4 — one SIMD — two generic streams (40 k cycles),
+    // now that SIMD runs one generic and one short stream.
+    constexpr int LH = 14 * N, LC0 = ((LH + 63) / 64 * 64 + 8 * N <= D::NT) ? (LH + 63) / 64 * 64 : LH, LF0 = LC0 + 7 * N;
+    static_assert(LF0 + N <= D::NT, "one (node, direction) pair per thread");
+    if (tid < LH || (tid >= LC0 && tid < LF0 + N)) {
         const int t = tid;
-        const int k = t / 22, d = t % 22;
+        const int k = t < LH ? t / 14 : (t < LF0 ? (t - LC0) / 7 : t - LF0);
+        const int d = t < LH ? t % 14 : (t < LF0 ? 14 + (t - LC0) % 7 : 21);
         const double *q_sc = sc + 14 * k;
         const double *v = zl + 14 * k + 7, *a = zl + 14 * N + 7 * k;
-        if (d < 21) {
+        if (d < 14) {
             double tau[7], dtau[7];
             rnea_dir<true, LinLds<NSEG>::TW, GMODEL>(mdl, q_sc, v, a, d / 7, d % 7, tau, dtau, tw + tid, D::NT);
 #pragma unroll
@@ -179,6 +184,11 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
 #pragma unroll
                 for (int i = 0; i < 7; i++) g_out[8 * k + i] = tau[i];
             }
+        } else if (d < 21) {
+            double dtau[7];
+            rnea_mcol<LinLds<NSEG>::TW, GMODEL>(mdl, q_sc, d - 14, dtau, tw + tid, D::NT);
+#pragma unroll
+            for (int i = 0; i < 7; i++) raw[(k * 7 + i) * 21 + d] = dtau[i];
         } else {
             V3 pt; double Jz[7];
             fk_tool(mdl, q_sc, &pt, Jz, nullptr, nullptr);
@@ -193,22 +203,28 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
     __syncthreads();
     LSTAMP(1);
     // rows 0..6 of every node: [dtau/dq | dtau/dqd | M symmetrised | quirk column]  (robot_ocp.hpp:129-142)
+    // (the quirk column — a 14-term sum — has a pass of its own: inside the pass below one lane in 22 ran its loop and the other 21 waited, in every
+    //  round of the pass: 9.5 k of k_step<4>'s 93 k cycles)
     for (int t = tid; t < N * 7 * 22; t += D::NT) {
         const int k = t / 154, i = (t % 154) / 22, c = t % 22;
         const double *rk = raw + k * 147;
+        if (c == 21) continue;
         double val;
         if (c < 14) val = rk[i * 21 + c];
-        else if (c < 21) { const int j = c - 14; val = (i <= j) ? rk[i * 21 + 14 + j] : rk[j * 21 + 14 + i]; }
-        else {
-            val = 0.0;
-            if (cfg.quirk_dtau_dT) {
-                for (int j = 0; j < 7; j++) {
-                    val += rk[i * 21 + 7 + j] * zl[14 * k + 7 + j];
-                    if (j >= i) val += rk[i * 21 + 14 + j] * zl[14 * N + 7 * k + j];
-                }
+        else { const int j = c - 14; val = (i <= j) ? rk[i * 21 + 14 + j] : rk[j * 21 + 14 + i]; }
+        Gk_out[(k * 8 + i) * 22 + c] = val;
+    }
+    for (int t = tid; t < N * 7; t += D::NT) {
+        const int k = t / 7, i = t % 7;
+        const double *rk = raw + k * 147;
+        double val = 0.0;
+        if (cfg.quirk_dtau_dT) {
+            for (int j = 0; j < 7; j++) {
+                val += rk[i * 21 + 7 + j] * zl[14 * k + 7 + j];
+                if (j >= i) val += rk[i * 21 + 14 + j] * zl[14 * N + 7 * k + j];
             }
         }
-        Gk_out[(k * 8 + i) * 22 + c] = val;
+        Gk_out[(k * 8 + i) * 22 + 21] = val;
     }
     LSTAMP(2);
     if (ceq_out) {
