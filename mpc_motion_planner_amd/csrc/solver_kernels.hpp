@@ -167,12 +167,17 @@ __device__ __forceinline__ void linearise_block(const mpcmp_config &cfg, const m
     // the next wave boundary on, the 7 N directions in a (mass-matrix columns: rnea_mcol, a quarter of the instructions), then the N tool rows.
     // With N = 13 the workgroup is five waves on four SIMDs; node-major order gave waves 0 and 4 — one SIMD — two generic streams (40 k cycles),
     // now that SIMD runs one generic and one short stream.
-    constexpr int LH = 14 * N, LC0 = ((LH + 63) / 64 * 64 + 8 * N <= D::NT) ? (LH + 63) / 64 * 64 : LH, LF0 = LC0 + 7 * N;
+    // Five waves (N = 13): waves 0 and 4 share a SIMD, so the generic block starts at wave 1 and the short items take wave 0 and wave 4.
+    constexpr int LG0 = (D::NW == 5 && 7 * N >= 64) ? 64 : 0, LH = 14 * N, LGE = LG0 + LH;          // generic items: lanes [LG0, LGE)
+    constexpr int LC1 = ((LGE + 63) / 64 * 64 + 8 * N - LG0 <= D::NT) ? (LGE + 63) / 64 * 64 : LGE;      // short items: lanes [0, LG0) and [LC1, LF0)
+    constexpr int LF0 = LC1 + 7 * N - LG0;
     static_assert(LF0 + N <= D::NT, "one (node, direction) pair per thread");
-    if (tid < LH || (tid >= LC0 && tid < LF0 + N)) {
+    if (tid < LGE || (tid >= LC1 && tid < LF0 + N)) {
         const int t = tid;
-        const int k = t < LH ? t / 14 : (t < LF0 ? (t - LC0) / 7 : t - LF0);
-        const int d = t < LH ? t % 14 : (t < LF0 ? 14 + (t - LC0) % 7 : 21);
+        const bool gen = t >= LG0 && t < LGE, tool = t >= LF0;
+        const int ci = t < LG0 ? t : LG0 + (t - LC1);                  // index of a short item
+        const int k = gen ? (t - LG0) / 14 : (tool ? t - LF0 : ci / 7);
+        const int d = gen ? (t - LG0) % 14 : (tool ? 21 : 14 + ci % 7);
         const double *q_sc = sc + 14 * k;
         const double *v = zl + 14 * k + 7, *a = zl + 14 * N + 7 * k;
         if (d < 14) {
