@@ -310,13 +310,24 @@ __device__ __forceinline__ double s_blk(const double (&m)[4 * SC], const double 
 }
 
 #define QP3_PROLOGUE(NT_, FILL_CT_) QP3_PROLOGUE_L(Qp3<NSEG>, NT_, FILL_CT_)
+// Logical thread index.  The 768-thread kernel (k_qp5) may run its logical waves on other hardware waves: hardware wave w runs on SIMD w % 4 and the roles
+// are ranges of LOGICAL waves, so the permutation decides which roles share a SIMD's issue slots (nibble w of MPCMP_WPERM5 = logical wave of hardware wave w).
+#ifndef MPCMP_WPERM5
+#define MPCMP_WPERM5 0xBA9876543210ull
+#endif
+template <int NT_>
+__device__ __forceinline__ int q3_logical_tid() {
+    if (NT_ == 768 && MPCMP_WPERM5 != 0xBA9876543210ull)
+        return (int)((MPCMP_WPERM5 >> (4 * (threadIdx.x >> 6))) & 15ull) * 64 + (int)(threadIdx.x & 63);
+    return (int)threadIdx.x;
+}
 #define QP3_PROLOGUE_L(LT_, NT_, FILL_CT_) \
     using D = Dim3<NSEG>; \
     using L = LT_; \
     constexpr int N = D::N, na = D::na, meq = D::meq, ma = D::ma, nJ = D::nJ, nI = D::nI, NT = NT_, GS = L::GS, JS = L::JS, SC = L::SC; \
     constexpr int n_tot = NARM * na + 1, mn_tot = NARM * (ma + na) + 1; \
     extern __shared__ __attribute__((aligned(16))) double lds[]; \
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = tid & 63; \
+    const int tid = q3_logical_tid<NT_>(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; \
     int slot, arm; \
     if (NARM == 1) { slot = blockIdx.x; arm = 0; } \
     else { const int bi = blockIdx.x; slot = (bi >> 4) * 8 + (bi & 7); arm = (bi >> 3) & 1; } \

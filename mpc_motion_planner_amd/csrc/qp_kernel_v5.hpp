@@ -582,6 +582,17 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
                 });
             }
         } else if (Q5_ON(6)) {
+            // (this wave runs two jobs one after the other and is the last one to reach the phase's barrier: the operands of the second job — the
+            //  sixteen variables — are read before the first job's arithmetic, one LDS round trip instead of two in a row)
+            const int vi = L::NG + ((laneV ? sio : L::tV5) - L::tV5);
+            double *vst = lds + L::vVst + ((laneV ? sio : L::tV5) - L::tV5);
+            const double *vcl = lds + L::vVc + vi;
+            double vx = 0.0, vzb = 0.0, vyb = 0.0, xtv = 0.0, vlb = 0.0, vub = 0.0, rb = 0.0, rbi = 0.0;
+            if (laneV) {
+                vx = ldv(vst); vzb = ldv(vst + 16); vyb = ldv(vst + 32);
+                xtv = ldv(lds + L::vXn + lo16(pxr)); vlb = ldv(vcl + 1 * L::NVL); vub = ldv(vcl + 2 * L::NVL);
+                rb = ldv(vcl + 4 * L::NVL); rbi = ldv(vcl + 5 * L::NVL);
+            }
             if (laneD) {        // dynamics rows DR0 .. meq - 1
                 const int r = L::DR0 + (sio - L::tV5);
                 const double *rcl = lds + L::vRc + r;
@@ -595,13 +606,6 @@ __device__ __forceinline__ void qp5_role_g(const Qp5Ctx<NSEG> &c) {
                 lds[L::vRedT + (r >> 3)] = tp;
             }
             if (laneV) {
-                const int vi = L::NG + (sio - L::tV5);
-                double *vst = lds + L::vVst + (sio - L::tV5);
-                const double *vcl = lds + L::vVc + vi;
-                double vx = ldv(vst), vzb = ldv(vst + 16), vyb = ldv(vst + 32);
-                const int xpos = lo16(pxr);
-                const double xtv = ldv(lds + L::vXn + xpos), vlb = ldv(vcl + 1 * L::NVL), vub = ldv(vcl + 2 * L::NVL);
-                const double rb = ldv(vcl + 4 * L::NVL), rbi = ldv(vcl + 5 * L::NVL);
                 vx = alpha * xtv + c.oma * vx;
                 const double zrv = alpha * xtv + c.oma * vzb;
                 const double znv = clip(zrv + vyb * rbi, vlb, vub);
