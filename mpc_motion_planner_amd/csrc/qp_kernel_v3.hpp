@@ -1238,6 +1238,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     double *stz = lds + L::oSt, *sty = stz + 512, *stg = stz + 1024, *sth = stz + 1536;
     double *s1x = lds + L::oS1, *s1z = s1x + 32, *s1y = s1x + 64, *s1zg = s1x + 96, *s1yg = s1x + 128;
     static_assert(na - 512 <= 32 && ma - 512 <= 32 && SEC0V + 32 <= 512 && SEC0R + 32 <= 512, "second-pass state");
+    static_assert(NV == 1 || 14 * N <= 512, "the lanes' second variables are controls (col_gather_u)");
     unsigned dv[NV], dr[NR];
 #pragma unroll
     for (int h = 0; h < NV; h++) {
@@ -1286,6 +1287,22 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
 #pragma unroll
             for (int q = 0; q < QB_; q += 2) { sacc += g8[q] * w8[q]; sac2 += g8[q + 1] * w8[q + 1]; }
         }
+        return sacc + sac2;
+    };
+    // the same for a control variable (no differentiation-matrix terms: their coefficient rows are the zero rows behind D, and the generic form reads
+    // them and their six operands all the same): the lanes' SECOND variables (N = 25: controls of the last two nodes) are all of this kind, and their
+    // pass is on the critical path of phase A.  Bitwise the generic result (0 * finite + x = x).
+    auto col_gather_u = [&](const double *w, unsigned d) -> double {
+        const int av = d & 0xFFFF, o = (d >> 16) & 31, nb = av - o, it_ = av - 7;
+        const double ct = (d >> 31) ? -tsT : 0.0;
+        const double *gc = gkl + 8 * nb + o, *wp = w + nb + 14;
+        const double wtv = ldv(w + (it_ > 0 ? it_ : 0));
+        double g8[8], w8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { g8[q] = ldv(gc + q * GS); w8[q] = ldv(wp + q); }
+        double sacc = ct * wtv, sac2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) { sacc += g8[q] * w8[q]; sac2 += g8[q + 1] * w8[q + 1]; }
         return sacc + sac2;
     };
     // (A x)[r]; x in node order (slot 21 of every node: x_T)
@@ -1390,7 +1407,7 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                     if (v < na) {
                         const double xx = h ? s1x[sio - SEC0V] : xv0, zz = h ? s1z[sio - SEC0V] : (L::STL ? ldv(stz + sio) : zb0), yy = h ? s1y[sio - SEC0V] : (L::STL ? ldv(sty + sio) : yb0);
                         const double rbv = (dro[h < NR ? h : 0] >> 20) & 1u ? rho_eq : rho_in, wv_ = ldv(wvv + (dvo[h] & 0xFFFF));     // (issued with the gather's reads)
-                        const double r = (sigma * xx + (rbv * zz - yy)) + col_gather(wg, dvo[h]);
+                        const double r = (sigma * xx + (rbv * zz - yy)) + (h ? col_gather_u(wg, dvo[h]) : col_gather(wg, dvo[h]));
                         lds[h ? rpos[v] : (int)((unsigned)pky >> 16)] = r;
                         bp += wv_ * r;
                     }
