@@ -119,10 +119,10 @@ struct Qp3 {
     static constexpr bool P8 = NSEG < 8;                            // N = 19: partial sums per 8 lanes (half the DPP chain in A and E); wave 7, idle in P1, adds them up
     static constexpr int oRedB = oWg + NXP;                         // [64] partial sums of w^T rhs (per wave, or per 8 lanes)
     static constexpr int oRedT = oRedB + 64;                        // [64] partial sums of the T column of A^T w
-    static constexpr int oS1 = oRedT + 64;                          // [5][32] ADMM state of the second variable / row of the lanes that own two (N = 25)
+    static constexpr int oS1 = oRedT + 64;                          // ADMM state of the second variable ([3][32]) / row ([2][96]) of the lanes that own two (N = 25)
     static constexpr bool LCT = NSEG < 8;                           // lane-constant table (N = 25: measured slower with it — the register allocator answers with copies and spills)
     static constexpr int NLC = 21;                                  // fields of LaneC1 + LaneC3 + LaneC4
-    static constexpr int oLCT = oS1 + 160;                          // [NLC][512] 16-bit words
+    static constexpr int oLCT = oS1 + 96 + 2 * 96;                  // [NLC][512] 16-bit words   (oS1: [3][32] second variables, [2][96] second rows)
     static constexpr int oXdG = oLCT;                               // [8][64] ints, set-up only (before the table is filled): where the G lanes' x~ entries go
     static constexpr bool STL = false;                                    // (option: z_b, y_b, z_g, y_g of the lane's first variable / row in LDS; measured: no gain at N = 25)
     static constexpr int oSt = oLCT + (LCT ? NLC * 128 : 256);      // [4][512]
@@ -1217,27 +1217,38 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
     // (5) | the same for the previous segment (5) | has a -ts T term (1); one per row: first operand slot (16) | i = k % 3 (2).
     constexpr int NV = (na + 511) / 512, NR = (ma + 511) / 512;
     static_assert(NV <= 2 && NR <= 2, "two variables and two rows per lane at most");
-    // WHICH lanes own a second item (N = 25: 13 variables, 24 rows): lanes SEC0V .. / SEC0R .. of the last waves since round 5 (second item of lane t:
-    // index 512 + t - SEC0x).  Their first-pass rows are dynamics rows (7 LDS reads); until round 4 the surplus sat on lanes 0 .. of wave 0, whose first pass
-    // is a path row (44 reads), so that wave's two passes in phase E set the phase for all eight: -6.7 % per QP with the surplus on waves 6 and 7
+    // WHICH lanes own a second item (N = 25: 13 variables, and the rows that do not fit the first pass): lanes SEC0V .. (wave 6) / SEC0R .. (waves 4, 5)
+    // since round 5.  Their first-pass rows are dynamics rows (7 LDS reads); until round 4 the surplus sat on lanes 0 .. of wave 0, whose first pass
+    // is a path row (44 reads), so that wave's two passes in phase E set the phase for all eight: -8.5 % per QP with the surplus on the dynamics-row waves
     // (tools/dual_fixed.py: 4.47 -> 4.09 ms per 700 iterations).
 #ifndef MPCMP_Q3_SEC0V
 #define MPCMP_Q3_SEC0V 384
 #endif
 #ifndef MPCMP_Q3_SEC0R
-#define MPCMP_Q3_SEC0R 448
+#define MPCMP_Q3_SEC0R 256
 #endif
     constexpr int SEC0V = NV == 2 ? MPCMP_Q3_SEC0V : 0, SEC0R = NR == 2 ? MPCMP_Q3_SEC0R : 0;
     auto iv2 = [&](int t, int h) -> int { return h == 0 ? t : (t >= SEC0V ? 512 + (t - SEC0V) : (1 << 20)); };      // variable index of lane t's h-th variable
-    auto ir2 = [&](int t, int h) -> int { return h == 0 ? t : (t >= SEC0R ? 512 + (t - SEC0R) : (1 << 20)); };      // row slot of lane t's h-th row
+    // Row slots q (row_of: the 8 N path rows, 44 LDS reads each, then the dynamics rows, 7 reads).  At N = 25 the 200 path rows end inside wave 3: with
+    // slot = lane that wave held 8 path rows and 56 dynamics rows, ran BOTH instruction streams in phase E and was the last at its barrier, while the
+    // dynamics-row waves 4 .. 7 were done in half the time.  Now the lanes behind the last path row of that wave own no first row (PW = 256), the dynamics
+    // rows start at the next wave, and what does not fit the first pass (80 rows) is the second row of the lanes from SEC0R = PW on (waves 4 and 5).
+    constexpr int PW = NR == 2 ? (8 * N + 63) / 64 * 64 : 8 * N;                 // first lane of the dynamics rows
+    constexpr int DR1 = NR == 2 ? 512 - PW : ma - 8 * N, DRX = (ma - 8 * N) - DR1;   // dynamics rows of the first pass / of the second
+    static_assert(NR == 1 || (DRX >= 0 && DRX <= 96 && SEC0R == PW), "second rows");
+    auto ir2 = [&](int t, int h) -> int {      // row slot of lane t's h-th row (none: 1 << 20)
+        if (NR == 1) return h == 0 ? t : (1 << 20);
+        if (h == 0) return t < 8 * N ? t : (t >= PW ? 8 * N + (t - PW) : (1 << 20));
+        return (t >= SEC0R && t - SEC0R < DRX) ? 8 * N + DR1 + (t - SEC0R) : (1 << 20);
+    };
     // Rows in lane order: the 8 N path rows first (44 LDS reads each), then the dynamics rows (7 reads): the few lanes that own a
     // second row (N = 25: 24 of them) get a cheap one.  The state of a lane's second variable / row lives in LDS (the 10 registers
     // it would take in EVERY lane are needed elsewhere).
     auto row_of = [&](int q) -> int { return q < 8 * N ? meq + q : q - 8 * N; };
     double xv0 = 0, zb0 = 0, yb0 = 0, zg0 = 0, yg0 = 0;             // (z_b .. y_g: registers unless L::STL)
     double *stz = lds + L::oSt, *sty = stz + 512, *stg = stz + 1024, *sth = stz + 1536;
-    double *s1x = lds + L::oS1, *s1z = s1x + 32, *s1y = s1x + 64, *s1zg = s1x + 96, *s1yg = s1x + 128;
-    static_assert(na - 512 <= 32 && ma - 512 <= 32 && SEC0V + 32 <= 512 && SEC0R + 32 <= 512, "second-pass state");
+    double *s1x = lds + L::oS1, *s1z = s1x + 32, *s1y = s1x + 64, *s1zg = s1x + 96, *s1yg = s1x + 192;
+    static_assert(na - 512 <= 32 && SEC0V + 32 <= 512 && SEC0R + 96 <= 512, "second-pass state");
     static_assert(NV == 1 || 14 * N <= 512, "the lanes' second variables are controls (col_gather_u)");
     unsigned dv[NV], dr[NR];
 #pragma unroll
@@ -1423,12 +1434,13 @@ __global__ __launch_bounds__(512) void k_qp3(mpcmp_config cfg, WS ws, const Qp3P
                 double tp = 0.0;
                 {   // first row and first variable of the lane: every constant it needs is read up front (lanes without one read
                     // valid neighbouring words)
-                    const int r = sio < ma ? row_of(sio) : 0;
+                    const int q0 = ir2(sio, 0);
+                    const int r = q0 < ma ? row_of(q0) : 0;
                     const double rr = (dro[0] >> 21) & 1u ? rho_eq : rho_in, lg = ldv(lds + L::oLg + r), ug = ldv(lds + L::oUg + r), cf = ldv(lds + L::oCf + r);
                     const double xtv = ldv(xt + (dvo[0] & 0xFFFF)), rb = (dro[0] >> 20) & 1u ? rho_eq : rho_in, lb = ldv(lds + L::oLb + sio), ub = ldv(lds + L::oUb + sio);
                     double zgv = zg0, ygv = yg0, zbv = zb0, ybv = yb0;
                     if (L::STL) { zgv = ldv(stg + sio); ygv = ldv(sth + sio); zbv = ldv(stz + sio); ybv = ldv(sty + sio); }
-                    if (sio < ma) {
+                    if (q0 < ma) {
                         const double zt = row_dot(xt, dro[0], r, cf);
                         const double zr = alpha * zt + (1.0 - alpha) * zgv;
                         const double zn = clip(zr + ygv * (rr == rho_eq ? inv_eq : inv_in), lg, ug);
